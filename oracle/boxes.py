@@ -1,0 +1,309 @@
+"""
+ORACLE (test infrastructure only) -- CPU restatement of the reference's box math.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (ssd_tensorflow_amd/) never does.
+
+Restates, array-oriented, the numpy half of ljanyst/ssd-tensorflow:
+
+  presets / anchors      ssdutils.py:36-62, 76-117
+  prop2abs / abs2prop    utils.py:85-108
+  normalize_box          utils.py:118-135
+  anchors on 1000 grid   ssdutils.py:120-135
+  IoU (+1 convention)    ssdutils.py:138-152
+  overlap good/best      ssdutils.py:155-170
+  location encode        ssdutils.py:173-179
+  label vector           transforms.py:47-114
+  decode                 ssdutils.py:182-229
+  greedy per-class NMS   ssdutils.py:232-318
+
+Pinned: checked bit-exactly against the reference itself imported in the build
+container (tools/make_golden.py, numpy 2.2.6) and against the fixtures under
+tests/golden/.  The reference's arithmetic is mixed f32/f64 under numpy >= 2
+(NEP 50 weak Python scalars); this file spells every dtype out explicitly.
+"""
+import math
+import numpy as np
+
+F32 = np.float32
+GRID = 1000  # the reference normalises every box on a 1000x1000 integer grid
+
+# ssdutils.py:36-62
+PRESETS = {
+    'vgg300': dict(name='vgg300', image_size=(300, 300), extra_scale=1.075,
+                   num_anchors=8732,
+                   maps=[(38, 0.1, [2, 0.5]),
+                         (19, 0.2, [2, 3, 0.5, 1. / 3.]),
+                         (10, 0.375, [2, 3, 0.5, 1. / 3.]),
+                         (5, 0.55, [2, 3, 0.5, 1. / 3.]),
+                         (3, 0.725, [2, 0.5]),
+                         (1, 0.9, [2, 0.5])]),
+    'vgg512': dict(name='vgg512', image_size=(512, 512), extra_scale=1.05,
+                   num_anchors=24564,
+                   maps=[(64, 0.07, [2, 0.5]),
+                         (32, 0.15, [2, 3, 0.5, 1. / 3.]),
+                         (16, 0.3, [2, 3, 0.5, 1. / 3.]),
+                         (8, 0.45, [2, 3, 0.5, 1. / 3.]),
+                         (4, 0.6, [2, 3, 0.5, 1. / 3.]),
+                         (2, 0.75, [2, 0.5]),
+                         (1, 0.9, [2, 0.5])]),
+}
+
+
+def get_preset(name):
+    """ssdutils.py:70-73 -- unknown name raises RuntimeError."""
+    if name not in PRESETS:
+        raise RuntimeError('No such preset: ' + name)
+    return PRESETS[name]
+
+
+def box_sizes(preset):
+    """Per map, the (w, h) of every box type.  ssdutils.py:83-99."""
+    maps = preset['maps']
+    out = []
+    for k, (_, s, ars) in enumerate(maps):
+        roots = [math.sqrt(r) for r in [1] + list(ars)]
+        sizes = [(s * r, s / r) for r in roots]
+        nxt = maps[k + 1][1] if k < len(maps) - 1 else preset['extra_scale']
+        sp = math.sqrt(s * nxt)
+        sizes.append((sp, sp))
+        out.append(sizes)
+    return out
+
+
+def anchors(preset):
+    """[A,4] f64 (cx, cy, w, h); order map -> type -> row -> col.
+    ssdutils.py:104-116."""
+    rows = []
+    for (fk, _, _), sizes in zip(preset['maps'], box_sizes(preset)):
+        c = (np.arange(fk, dtype=np.float64) + 0.5) / float(fk)
+        for (w, h) in sizes:
+            cy, cx = np.meshgrid(c, c, indexing='ij')   # row j -> y, col i -> x
+            blk = np.empty((fk * fk, 4), dtype=np.float64)
+            blk[:, 0] = cx.ravel()
+            blk[:, 1] = cy.ravel()
+            blk[:, 2] = w
+            blk[:, 3] = h
+            rows.append(blk)
+    return np.concatenate(rows, axis=0)
+
+
+def _trunc(x):
+    """Python int(): truncation toward zero (utils.py:108)."""
+    return np.trunc(x).astype(np.int64)
+
+
+def prop2abs(cx, cy, w, h, W=GRID, H=GRID):
+    """utils.py:100-108 for f64 inputs.  Returns int64 xmin,xmax,ymin,ymax."""
+    cx = np.asarray(cx, np.float64); cy = np.asarray(cy, np.float64)
+    w = np.asarray(w, np.float64); h = np.asarray(h, np.float64)
+    w2 = w * W / 2
+    h2 = h * H / 2
+    ax = cx * W
+    ay = cy * H
+    return _trunc(ax - w2), _trunc(ax + w2), _trunc(ay - h2), _trunc(ay + h2)
+
+
+def abs2prop(xmin, xmax, ymin, ymax, W=GRID, H=GRID):
+    """utils.py:85-97.  Returns f64 cx, cy, w, h."""
+    xmin = np.asarray(xmin, np.int64); xmax = np.asarray(xmax, np.int64)
+    ymin = np.asarray(ymin, np.int64); ymax = np.asarray(ymax, np.int64)
+    width = (xmax - xmin).astype(np.float64)
+    height = (ymax - ymin).astype(np.float64)
+    cx = xmin.astype(np.float64) + width / 2
+    cy = ymin.astype(np.float64) + height / 2
+    return cx / W, cy / H, width / W, height / H
+
+
+def anchors_abs(anch):
+    """anchors2array(anchors, Size(1000,1000)): [A,4] f64 holding truncated
+    ints (xmin, xmax, ymin, ymax).  ssdutils.py:120-130."""
+    x0, x1, y0, y1 = prop2abs(anch[:, 0], anch[:, 1], anch[:, 2], anch[:, 3])
+    return np.stack([x0, x1, y0, y1], axis=1).astype(np.float64)
+
+
+def iou_plus1(box_abs, anch_abs):
+    """jaccard_overlap with the +1 pixel convention.  ssdutils.py:138-152."""
+    a = anch_abs
+    areaa = (a[:, 1] - a[:, 0] + 1) * (a[:, 3] - a[:, 2] + 1)
+    areab = (box_abs[1] - box_abs[0] + 1) * (box_abs[3] - box_abs[2] + 1)
+    xxmin = np.maximum(box_abs[0], a[:, 0]); xxmax = np.minimum(box_abs[1], a[:, 1])
+    yymin = np.maximum(box_abs[2], a[:, 2]); yymax = np.minimum(box_abs[3], a[:, 3])
+    w = np.maximum(0, xxmax - xxmin + 1)
+    h = np.maximum(0, yymax - yymin + 1)
+    inter = w * h
+    return inter / (areab + areaa - inter)
+
+
+def overlap(box_abs, anch_abs, thr):
+    """compute_overlap: (best or None, good idx list, iou).  ssdutils.py:155-170."""
+    iou = iou_plus1(box_abs, anch_abs)
+    good = np.nonzero(iou > thr)[0]
+    b = int(np.argmax(iou))
+    best = b if iou[b] > thr else None
+    return best, good, iou
+
+
+def encode_location(b, a):
+    """compute_location: f64.  b, a = (cx, cy, w, h).  ssdutils.py:173-179."""
+    return np.array([(b[0] - a[0]) / a[2] * 10,
+                     (b[1] - a[1]) / a[3] * 10,
+                     math.log(b[2] / a[2]) * 5,
+                     math.log(b[3] / a[3]) * 5], dtype=np.float64)
+
+
+def encode_labels(gt_boxes, gt_cls, preset, num_classes, anch=None, anch_abs=None):
+    """LabelCreatorTransform.__call__.  transforms.py:72-114.
+
+    gt_boxes [n,4] f64 proportional (cx,cy,w,h); gt_cls [n] int.
+    Returns vec [A, num_classes+5] f32."""
+    if anch is None:
+        anch = anchors(preset)
+    if anch_abs is None:
+        anch_abs = anchors_abs(anch)
+    gt_boxes = np.asarray(gt_boxes, np.float64).reshape(-1, 4)
+    A = anch.shape[0]
+    C = num_classes
+    vec = np.zeros((A, C + 5), dtype=F32)
+    vec[:, C] = 1
+
+    ov = []
+    for g in gt_boxes:
+        x0, x1, y0, y1 = prop2abs(g[0], g[1], g[2], g[3])
+        ov.append(overlap(np.array([x0, x1, y0, y1], np.float64), anch_abs, 0.5))
+
+    def assign(idx, score, bi, matches):
+        # process_overlap, transforms.py:47-55: '>=' keeps the incumbent on a tie
+        if idx in matches and matches[idx] >= score:
+            return
+        matches[idx] = score
+        vec[idx, 0:C + 1] = 0
+        vec[idx, int(gt_cls[bi])] = 1
+        vec[idx, C + 1:] = encode_location(gt_boxes[bi], anch[idx])
+
+    matches = {}
+    for bi, (best, good, iou) in enumerate(ov):
+        for idx in good:
+            assign(int(idx), iou[idx], bi, matches)
+    matches = {}                       # transforms.py:106 -- reset
+    for bi, (best, good, iou) in enumerate(ov):
+        if best is None:
+            continue
+        assign(best, iou[best], bi, matches)
+    return vec
+
+
+# ----------------------------------------------------------------------------
+# decode + NMS
+# ----------------------------------------------------------------------------
+def decode_location_np2(loc, a):
+    """decode_location under numpy>=2 promotion (ssdutils.py:182-189):
+    x, y are float32; w, h are float64 (math.exp returns a Python float).
+    loc: 4 f32 (already clamped to <=100); a: f64 (cx, cy, w, h)."""
+    x = F32(F32(F32(loc[0]) / F32(10)) * F32(a[2])) + F32(a[0])
+    y = F32(F32(F32(loc[1]) / F32(10)) * F32(a[3])) + F32(a[1])
+    w = math.exp(float(F32(loc[2]) / F32(5))) * float(a[2])
+    h = math.exp(float(F32(loc[3]) / F32(5))) * float(a[3])
+    return F32(x), F32(y), w, h
+
+
+def normalize_abs_np2(x, y, w, h):
+    """normalize_box's integer box for a decoded (x f32, y f32, w f64, h f64).
+    utils.py:118-135 + prop2abs:100-108 with np.float32 centre:
+    centre*1000 is f32, half-extent is cast to f32 before the subtract."""
+    w2 = F32(w * GRID / 2)
+    h2 = F32(h * GRID / 2)
+    cx = F32(x * F32(GRID))
+    cy = F32(y * F32(GRID))
+    xmin = int(F32(cx - w2)); xmax = int(F32(cx + w2))
+    ymin = int(F32(cy - h2)); ymax = int(F32(cy + h2))
+    xmin = max(xmin, 0); xmax = min(xmax, GRID - 1)
+    ymin = max(ymin, 0); ymax = min(ymax, GRID - 1)
+    xmin = min(xmin, xmax); ymin = min(ymin, ymax)
+    return xmin, xmax, ymin, ymax
+
+
+def decode(pred, anch, thr=0.01, cap=200):
+    """decode_boxes.  ssdutils.py:192-229.
+
+    pred [A, C+5] f32 (C fg classes + background + 4 offsets).  Not mutated
+    (the reference clamps offsets > 100 in place; the clamp is applied to a copy).
+    Order: confidence descending; exact ties resolved by LOWER anchor index
+    first (the reference's argsort is unstable: tie order is not contractual).
+    Returns dict of arrays: idx, cls, conf (f32), box (int64 [n,4] on the grid)."""
+    pred = np.asarray(pred, F32)
+    ncls = pred.shape[1] - 4
+    cls = np.argmax(pred[:, :ncls - 1], axis=1)
+    conf = pred[np.arange(pred.shape[0]), cls]
+    order = np.lexsort((np.arange(conf.shape[0]), -conf.astype(np.float64)))
+    if cap is not None:
+        order = order[:cap]
+    oi, oc, ocf, ob = [], [], [], []
+    for i in order:
+        if conf[i] < thr:
+            break
+        loc = pred[i, ncls:].copy()
+        loc[loc > 100] = 100
+        x, y, w, h = decode_location_np2(loc, anch[i])
+        oi.append(int(i)); oc.append(int(cls[i])); ocf.append(conf[i])
+        ob.append(normalize_abs_np2(x, y, w, h))
+    return dict(idx=np.array(oi, np.int64), cls=np.array(oc, np.int64),
+                conf=np.array(ocf, F32),
+                box=np.array(ob, np.int64).reshape(-1, 4))
+
+
+def nms_roundtrip(box):
+    """prop2abs(abs2prop(ints)) as non_maximum_suppression re-derives pixel
+    coordinates (ssdutils.py:243-249).  NOT the identity."""
+    cx, cy, w, h = abs2prop(box[:, 0], box[:, 1], box[:, 2], box[:, 3])
+    x0, x1, y0, y1 = prop2abs(cx, cy, w, h)
+    return np.stack([x0, x1, y0, y1], axis=1)
+
+
+def nms_class(box, thr_num=9, thr_den=20):
+    """Greedy NMS over boxes already in descending-confidence order.
+    IoU(+1) > 0.45 evaluated as the exact integer test 20*inter > 9*union.
+    ssdutils.py:262-298.  Returns kept positions."""
+    b = nms_roundtrip(box)
+    area = (b[:, 1] - b[:, 0] + 1) * (b[:, 3] - b[:, 2] + 1)
+    alive = np.ones(b.shape[0], bool)
+    keep = []
+    for i in range(b.shape[0]):
+        if not alive[i]:
+            continue
+        keep.append(i)
+        j = np.nonzero(alive)[0]
+        j = j[j > i]
+        if j.size == 0:
+            continue
+        w = np.maximum(0, np.minimum(b[i, 1], b[j, 1]) - np.maximum(b[i, 0], b[j, 0]) + 1)
+        h = np.maximum(0, np.minimum(b[i, 3], b[j, 3]) - np.maximum(b[i, 2], b[j, 2]) + 1)
+        inter = w * h
+        union = area[i] + area[j] - inter
+        alive[j[thr_den * inter > thr_num * union]] = False
+    return keep
+
+
+def suppress(det, max_out=None):
+    """suppress_overlaps (ssdutils.py:310-318) on a decode() result: classes in
+    first-appearance order, each class's keeps in descending confidence; then
+    the caller's [:max_out] (infer.py:235).  Returns positions into det."""
+    order = []
+    seen = []
+    for c in det['cls']:
+        if int(c) not in seen:
+            seen.append(int(c))
+    for c in seen:
+        pos = np.nonzero(det['cls'] == c)[0]
+        kept = nms_class(det['box'][pos])
+        order.extend(int(pos[k]) for k in kept)
+    if max_out is not None:
+        order = order[:max_out]
+    return np.array(order, np.int64)
+
+
+def detect(pred, anch, thr, cap, max_out=None):
+    """decode + suppress; returns dict(idx, cls, conf, box) of survivors."""
+    det = decode(pred, anch, thr, cap)
+    keep = suppress(det, max_out)
+    return {k: v[keep] for k, v in det.items()}
