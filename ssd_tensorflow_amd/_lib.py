@@ -1,0 +1,105 @@
+"""ctypes binding of libssdvgg_hip.so (include/ssdvgg_hip.h).
+
+The library is the product; there is no Python or CPU fallback.  If it is missing or
+does not load, importing this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libssdvgg_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        f'or `make -C {os.path.join(_HERE, "csrc")}` (hipcc, gfx950). There is no CPU fallback.')
+
+lib = C.CDLL(LIB_PATH)
+
+p_f32 = C.POINTER(C.c_float)
+p_f64 = C.POINTER(C.c_double)
+p_i32 = C.POINTER(C.c_int)
+p_i64 = C.POINTER(C.c_longlong)
+vp = C.c_void_p
+i32 = C.c_int
+f32 = C.c_float
+sz = C.c_size_t
+cstr = C.c_char_p
+handle = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/ssdvgg_hip.h declares
+SIGNATURES = {
+    'ssd_last_error': (cstr, []),
+    'ssd_version': (cstr, []),
+    'ssd_preset_info': (i32, [cstr, p_i32, p_i32, p_i32, p_i32]),
+    'ssd_preset_map': (i32, [cstr, i32, p_i32, p_f64, p_i32]),
+    'ssd_anchors': (i32, [cstr, i32, vp]),
+    'ssd_anchors_abs': (i32, [cstr, i32, vp]),
+    'ssd_encode_labels': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp]),
+    'ssd_encode_labels_dev': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp, vp]),
+    'ssd_decode_nms': (i32, [cstr, i32, i32, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'ssd_decode_nms_ws_bytes': (sz, [cstr, i32]),
+    'ssd_decode_nms_dev': (i32, [cstr, i32, vp, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'ssd_anchors_dev': (i32, [cstr, vp, vp, vp]),
+    'ssd_arena_floats': (sz, [cstr, i32]),
+    'ssd_create': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, C.POINTER(handle)]),
+    'ssd_destroy': (i32, [handle]),
+    'ssd_set_stream': (i32, [handle, vp]),
+    'ssd_num_variables': (i32, [handle]),
+    'ssd_variable_info': (i32, [handle, i32, C.c_char_p, i32, p_i32, p_i32]),
+    'ssd_load_variable': (i32, [handle, cstr, vp, sz]),
+    'ssd_save_variable': (i32, [handle, cstr, vp, sz]),
+    'ssd_save_gradient': (i32, [handle, cstr, vp, sz]),
+    'ssd_save_momentum': (i32, [handle, cstr, vp, sz]),
+    'ssd_load_momentum': (i32, [handle, cstr, vp, sz]),
+    'ssd_set_optimizer': (i32, [handle, vp, vp, i32, f32, f32]),
+    'ssd_get_global_step': (i32, [handle, p_i64]),
+    'ssd_set_global_step': (i32, [handle, C.c_longlong]),
+    'ssd_train_step': (i32, [handle, vp, vp, i32, vp, vp]),
+    'ssd_eval_step': (i32, [handle, vp, vp, i32, vp, vp]),
+    'ssd_infer': (i32, [handle, vp, i32, vp]),
+    'ssd_forward_backward_dev': (i32, [handle, vp, vp, i32]),
+    'ssd_apply_gradients_dev': (i32, [handle, f32]),
+    'ssd_train_step_dev': (i32, [handle, vp, vp, i32]),
+    'ssd_eval_step_dev': (i32, [handle, vp, vp, i32]),
+    'ssd_infer_dev': (i32, [handle, vp, i32]),
+    'ssd_result_dev': (i32, [handle, C.POINTER(vp)]),
+    'ssd_get_losses': (i32, [handle, vp]),
+    'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
+    'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'ssd_activation_shape': (i32, [handle, cstr, p_i32, p_i32, p_i32]),
+    'ssd_activation': (i32, [handle, cstr, i32, vp, sz]),
+    'ssd_op_conv2d_fwd': (i32, [vp, vp, vp, vp] + [i32] * 14 + [vp]),
+    'ssd_op_conv2d_dgrad': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_wgrad_ws_floats': (sz, [i32] * 13),
+    'ssd_op_conv2d_wgrad': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
+    'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),
+    'ssd_op_maxpool_bwd': (i32, [vp, vp, vp, i32, i32] + [i32] * 10 + [vp]),
+    'ssd_op_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, vp]),
+    'ssd_op_l2norm_bwd_ws_floats': (sz, [i32, i32]),
+    'ssd_op_l2norm_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)        # AttributeError here = the .so does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return (lib.ssd_last_error() or b'').decode()
+
+
+def check(rc, exc=RuntimeError):
+    """0 = ok; anything else raises with the library's message."""
+    if rc != 0:
+        raise exc(last_error())
+
+
+def np_ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    if not a.flags['C_CONTIGUOUS']:
+        raise ValueError('array must be C-contiguous')
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,454 @@
+// extern "C" boundary of libssdvgg_hip.so (include/ssdvgg_hip.h).
+#include "../../include/ssdvgg_hip.h"
+#include "net.h"
+#include <vector>
+
+namespace ssd {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char* get_error() { return g_err.c_str(); }
+}  // namespace ssd
+
+using namespace ssd;
+
+struct ssd_net {
+    Net* net;
+};
+
+#define API_BEGIN try {
+#define API_END                                  \
+    return 0;                                    \
+    }                                            \
+    catch (const std::exception& e) {            \
+        ssd::set_error("%s", e.what());          \
+        return 1;                                \
+    }                                            \
+    catch (...) {                                \
+        ssd::set_error("unknown error");         \
+        return 1;                                \
+    }
+
+static Net& N(ssd_handle h) {
+    if (!h || !h->net) fail("null handle");
+    return *h->net;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { HIP_OK(hipMalloc(&p, bytes ? bytes : 16)); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() { return (T*)p; }
+};
+}  // namespace
+
+extern "C" {
+
+const char* ssd_last_error(void) { return ssd::get_error(); }
+const char* ssd_version(void) { return "ssdvgg_hip 0.1 gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32)"; }
+
+int ssd_preset_info(const char* preset, int* image_w, int* image_h, int* num_anchors, int* num_maps) {
+    API_BEGIN
+    const Preset& p = get_preset(preset);
+    if (image_w) *image_w = p.image_w;
+    if (image_h) *image_h = p.image_h;
+    if (num_anchors) *num_anchors = p.num_anchors;
+    if (num_maps) *num_maps = p.nmaps;
+    API_END
+}
+
+int ssd_preset_map(const char* preset, int map, int* size, double* scale, int* num_types) {
+    API_BEGIN
+    const Preset& p = get_preset(preset);
+    SSD_REQUIRE(map >= 0 && map < p.nmaps, "map %d outside 0..%d", map, p.nmaps - 1);
+    if (size) *size = p.map_size[map];
+    if (scale) *scale = p.scale[map];
+    if (num_types) *num_types = p.ntypes[map];
+    API_END
+}
+
+int ssd_anchors_dev(const char* preset, double* anchors_dev, int* anchors_abs_dev, void* stream) {
+    API_BEGIN
+    anchors_device(get_preset(preset), anchors_dev, anchors_abs_dev, (hipStream_t)stream);
+    API_END
+}
+
+static void anchors_host(const char* preset, int device, double* out, int* out_abs) {
+    const Preset& p = get_preset(preset);
+    HIP_OK(hipSetDevice(device));
+    const size_t A = p.num_anchors;
+    DevBuf a(A * 4 * sizeof(double)), b(A * 4 * sizeof(int));
+    anchors_device(p, a.as<double>(), b.as<int>(), nullptr);
+    if (out) HIP_OK(hipMemcpy(out, a.p, A * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_abs) HIP_OK(hipMemcpy(out_abs, b.p, A * 4 * sizeof(int), hipMemcpyDeviceToHost));
+}
+
+int ssd_anchors(const char* preset, int device, double* out) {
+    API_BEGIN
+    anchors_host(preset, device, out, nullptr);
+    API_END
+}
+
+int ssd_anchors_abs(const char* preset, int device, int* out) {
+    API_BEGIN
+    anchors_host(preset, device, nullptr, out);
+    API_END
+}
+
+static void encode_labels_impl(const char* preset, int num_classes, int device, const double* gt, const int* cls,
+                               const int* offsets, int b, float* vec_dev, float* vec_host, hipStream_t s) {
+    const Preset& p = get_preset(preset);
+    SSD_REQUIRE(b >= 1, "batch must be >= 1");
+    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27");
+    HIP_OK(hipSetDevice(device));
+    const int ntot = offsets[b];
+    SSD_REQUIRE(offsets[0] == 0 && ntot >= 0, "gt_offsets must start at 0 and be non-decreasing");
+    for (int i = 0; i < ntot; ++i)
+        SSD_REQUIRE(cls[i] >= 0 && cls[i] < num_classes, "gt_cls[%d] = %d outside 0..%d", i, cls[i], num_classes - 1);
+    const size_t A = p.num_anchors;
+    DevBuf anc(A * 4 * sizeof(double)), aabs(A * 4 * sizeof(int));
+    DevBuf dgt((size_t)(ntot ? ntot : 1) * 4 * sizeof(double)), dcls((size_t)(ntot ? ntot : 1) * sizeof(int));
+    DevBuf doff((size_t)(b + 1) * sizeof(int)), ws(encode_labels_ws_bytes(ntot));
+    anchors_device(p, anc.as<double>(), aabs.as<int>(), s);
+    if (ntot) {
+        HIP_OK(hipMemcpyAsync(dgt.p, gt, (size_t)ntot * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dcls.p, cls, (size_t)ntot * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    HIP_OK(hipMemcpyAsync(doff.p, offsets, (size_t)(b + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    const size_t n = (size_t)b * A * (num_classes + 5);
+    DevBuf tmp(vec_dev ? 16 : n * sizeof(float));
+    float* out = vec_dev ? vec_dev : tmp.as<float>();
+    encode_labels(p, num_classes, anc.as<double>(), aabs.as<int>(), dgt.as<double>(), dcls.as<int>(), doff.as<int>(), b, ntot,
+                  out, ws.p, s);
+    if (vec_host) HIP_OK(hipMemcpyAsync(vec_host, out, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));     // temporaries die here
+}
+
+int ssd_encode_labels(const char* preset, int num_classes, int device, const double* gt_boxes, const int* gt_cls,
+                      const int* gt_offsets, int b, float* vec_out) {
+    API_BEGIN
+    encode_labels_impl(preset, num_classes, device, gt_boxes, gt_cls, gt_offsets, b, nullptr, vec_out, nullptr);
+    API_END
+}
+
+int ssd_encode_labels_dev(const char* preset, int num_classes, int device, const double* gt_boxes, const int* gt_cls,
+                          const int* gt_offsets, int b, float* vec_out_dev, void* stream) {
+    API_BEGIN
+    encode_labels_impl(preset, num_classes, device, gt_boxes, gt_cls, gt_offsets, b, vec_out_dev, nullptr, (hipStream_t)stream);
+    API_END
+}
+
+size_t ssd_decode_nms_ws_bytes(const char* preset, int b) {
+    try {
+        return detect_ws_bytes(b, get_preset(preset).num_anchors);
+    } catch (const std::exception& e) {
+        ssd::set_error("%s", e.what());
+        return 0;
+    }
+}
+
+int ssd_decode_nms_dev(const char* preset, int num_classes, const double* anchors_dev, const float* pred_dev, int b,
+                       float conf_thr, int cap, int max_out, int out_cap, int nms, int* count_dev, float* conf_dev,
+                       int* cls_dev, int* idx_dev, int* box_dev, void* ws_dev, void* stream) {
+    API_BEGIN
+    const Preset& p = get_preset(preset);
+    DetectOut o{count_dev, conf_dev, cls_dev, idx_dev, box_dev};
+    detect(p.num_anchors, num_classes, anchors_dev, pred_dev, b, conf_thr, cap, max_out, out_cap, nms != 0, o, ws_dev,
+           (hipStream_t)stream);
+    API_END
+}
+
+int ssd_decode_nms(const char* preset, int num_classes, int device, const float* pred, int b, float conf_thr, int cap,
+                   int max_out, int out_cap, int nms, int* count, float* conf, int* cls, int* idx, int* box) {
+    API_BEGIN
+    const Preset& p = get_preset(preset);
+    SSD_REQUIRE(b >= 1 && out_cap >= 1, "batch and out_cap must be >= 1");
+    HIP_OK(hipSetDevice(device));
+    const size_t A = p.num_anchors, nv = num_classes + 5, n = (size_t)b * out_cap;
+    DevBuf anc(A * 4 * sizeof(double)), dpred((size_t)b * A * nv * sizeof(float)), ws(detect_ws_bytes(b, (int)A));
+    DevBuf dcount((size_t)b * 4), dconf(n * 4), dcls(n * 4), didx(n * 4), dbox(n * 16);
+    anchors_device(p, anc.as<double>(), nullptr, nullptr);
+    HIP_OK(hipMemcpy(dpred.p, pred, (size_t)b * A * nv * sizeof(float), hipMemcpyHostToDevice));
+    DetectOut o{dcount.as<int>(), dconf.as<float>(), dcls.as<int>(), didx.as<int>(), dbox.as<int>()};
+    detect((int)A, num_classes, anc.as<double>(), dpred.as<float>(), b, conf_thr, cap, max_out, out_cap, nms != 0, o, ws.p, nullptr);
+    HIP_OK(hipMemcpy(count, dcount.p, (size_t)b * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(conf, dconf.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(cls, dcls.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(idx, didx.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(box, dbox.p, n * 16, hipMemcpyDeviceToHost));
+    API_END
+}
+
+// ------------------------------------------------------------------------------ model
+size_t ssd_arena_floats(const char* preset, int num_classes) {
+    try {
+        return Net::arena_floats(preset, num_classes);
+    } catch (const std::exception& e) {
+        ssd::set_error("%s", e.what());
+        return 0;
+    }
+}
+
+int ssd_create(const char* preset, int num_classes, int max_batch, int device, int training, unsigned long long seed,
+               float* ext_params_dev, float* ext_grads_dev, float* ext_momentum_dev, ssd_handle* out) {
+    API_BEGIN
+    SSD_REQUIRE(out != nullptr, "out handle pointer is null");
+    *out = nullptr;
+    Net* n = new Net(preset, num_classes, max_batch, device, training != 0, seed, ext_params_dev, ext_grads_dev,
+                     ext_momentum_dev);
+    SSD_REQUIRE(n->nparams() == Net::arena_floats(preset, num_classes), "arena size mismatch");
+    *out = new ssd_net{n};
+    API_END
+}
+
+int ssd_destroy(ssd_handle h) {
+    API_BEGIN
+    if (h) {
+        delete h->net;
+        delete h;
+    }
+    API_END
+}
+
+int ssd_set_stream(ssd_handle h, void* stream) {
+    API_BEGIN
+    N(h).set_stream((hipStream_t)stream);
+    API_END
+}
+
+int ssd_num_variables(ssd_handle h) {
+    try {
+        return (int)N(h).variables().size();
+    } catch (const std::exception& e) {
+        ssd::set_error("%s", e.what());
+        return -1;
+    }
+}
+
+int ssd_variable_info(ssd_handle h, int i, char* name, int name_cap, int* ndim, int shape[4]) {
+    API_BEGIN
+    const auto& vars = N(h).variables();
+    SSD_REQUIRE(i >= 0 && i < (int)vars.size(), "variable index %d outside 0..%zu", i, vars.size() - 1);
+    const Variable& v = vars[i];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", v.name.c_str());
+    if (ndim) *ndim = v.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = v.shape[k];
+    API_END
+}
+
+int ssd_load_variable(ssd_handle h, const char* name, const float* data, size_t count) {
+    API_BEGIN
+    N(h).load_variable(name, data, count, 0);
+    API_END
+}
+int ssd_save_variable(ssd_handle h, const char* name, float* data, size_t count) {
+    API_BEGIN
+    N(h).save_variable(name, data, count, 0);
+    API_END
+}
+int ssd_save_gradient(ssd_handle h, const char* name, float* data, size_t count) {
+    API_BEGIN
+    N(h).save_variable(name, data, count, 1);
+    API_END
+}
+int ssd_save_momentum(ssd_handle h, const char* name, float* data, size_t count) {
+    API_BEGIN
+    N(h).save_variable(name, data, count, 2);
+    API_END
+}
+int ssd_load_momentum(ssd_handle h, const char* name, const float* data, size_t count) {
+    API_BEGIN
+    N(h).load_variable(name, data, count, 2);
+    API_END
+}
+
+int ssd_set_optimizer(ssd_handle h, const float* lr_values, const long long* lr_boundaries, int n_values, float momentum,
+                      float weight_decay) {
+    API_BEGIN
+    N(h).set_optimizer(lr_values, lr_boundaries, n_values, momentum, weight_decay);
+    API_END
+}
+int ssd_get_global_step(ssd_handle h, long long* step) {
+    API_BEGIN
+    *step = N(h).global_step;
+    API_END
+}
+int ssd_set_global_step(ssd_handle h, long long step) {
+    API_BEGIN
+    N(h).global_step = step;
+    API_END
+}
+
+int ssd_forward_backward_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
+    API_BEGIN
+    Net& n = N(h);
+    n.forward(x_dev, b, true, y_dev);
+    n.backward(b, y_dev);
+    API_END
+}
+int ssd_apply_gradients_dev(ssd_handle h, float grad_scale) {
+    API_BEGIN
+    N(h).apply_gradients(grad_scale);
+    API_END
+}
+int ssd_train_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
+    API_BEGIN
+    Net& n = N(h);
+    n.forward(x_dev, b, true, y_dev);
+    n.backward(b, y_dev);
+    n.apply_gradients(1.f);
+    API_END
+}
+int ssd_eval_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
+    API_BEGIN
+    N(h).forward(x_dev, b, true, y_dev);
+    API_END
+}
+int ssd_infer_dev(ssd_handle h, const float* x_dev, int b) {
+    API_BEGIN
+    N(h).forward(x_dev, b, false, nullptr);
+    API_END
+}
+int ssd_result_dev(ssd_handle h, const float** result_dev) {
+    API_BEGIN
+    *result_dev = N(h).result();
+    API_END
+}
+int ssd_get_losses(ssd_handle h, float losses_out[4]) {
+    API_BEGIN
+    N(h).get_losses(losses_out);
+    API_END
+}
+int ssd_arenas(ssd_handle h, float** params_dev, float** grads_dev, float** momentum_dev, size_t* floats,
+               size_t* filter_floats) {
+    API_BEGIN
+    Net& n = N(h);
+    if (params_dev) *params_dev = n.params();
+    if (grads_dev) *grads_dev = n.grads();
+    if (momentum_dev) *momentum_dev = n.momentum();
+    if (floats) *floats = n.nparams();
+    if (filter_floats) *filter_floats = n.nfilters();
+    API_END
+}
+
+int ssd_train_step(ssd_handle h, const float* x, const float* y, int b, float* result_out, float losses_out[4]) {
+    API_BEGIN
+    Net& n = N(h);
+    n.upload_xy(x, y, b);
+    n.forward(n.x_stage(), b, true, n.y_stage());
+    n.backward(b, n.y_stage());
+    n.apply_gradients(1.f);
+    if (result_out) n.copy_result(result_out, b);
+    if (losses_out) n.get_losses(losses_out);
+    HIP_OK(hipStreamSynchronize(n.stream()));
+    API_END
+}
+int ssd_eval_step(ssd_handle h, const float* x, const float* y, int b, float* result_out, float losses_out[4]) {
+    API_BEGIN
+    Net& n = N(h);
+    n.upload_xy(x, y, b);
+    n.forward(n.x_stage(), b, true, n.y_stage());
+    if (result_out) n.copy_result(result_out, b);
+    if (losses_out) n.get_losses(losses_out);
+    HIP_OK(hipStreamSynchronize(n.stream()));
+    API_END
+}
+int ssd_infer(ssd_handle h, const float* x, int b, float* result_out) {
+    API_BEGIN
+    Net& n = N(h);
+    n.upload_xy(x, nullptr, b);
+    n.forward(n.x_stage(), b, false, nullptr);
+    if (result_out) n.copy_result(result_out, b);
+    HIP_OK(hipStreamSynchronize(n.stream()));
+    API_END
+}
+
+int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, int out_cap, int nms, int* count, float* conf,
+                    int* cls, int* idx, int* box) {
+    API_BEGIN
+    N(h).detect_last(b, conf_thr, cap, max_out, out_cap, nms != 0, count, conf, cls, idx, box);
+    API_END
+}
+
+int ssd_activation_shape(ssd_handle h, const char* name, int* height, int* width, int* channels) {
+    API_BEGIN
+    N(h).activation_shape(name, height, width, channels);
+    API_END
+}
+
+int ssd_activation(ssd_handle h, const char* name, int b, float* out, size_t count) {
+    API_BEGIN
+    N(h).activation(name, b, out, count);
+    API_END
+}
+
+// --------------------------------------------------------------------- single kernels
+static ConvDesc mk(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h,
+                   int pad_w) {
+    ConvDesc d;
+    d.B = b; d.Hi = hi; d.Wi = wi; d.Ci = ci; d.Ho = ho; d.Wo = wo; d.Co = co;
+    d.KH = kh; d.KW = kw; d.stride = stride; d.dil = dil; d.pad_h = pad_h; d.pad_w = pad_w;
+    return d;
+}
+
+int ssd_op_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int b, int hi, int wi, int ci, int ho,
+                      int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, int relu, void* stream) {
+    API_BEGIN
+    conv_fwd(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), x, w, bias, y, relu != 0, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_dgrad(const float* dy, const float* w, float* dx, const float* mask, int accumulate, int b, int hi, int wi,
+                        int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w,
+                        void* stream) {
+    API_BEGIN
+    conv_dgrad(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), dy, w, dx, mask, accumulate != 0,
+               (hipStream_t)stream);
+    API_END
+}
+size_t ssd_op_conv2d_wgrad_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                                     int dil, int pad_h, int pad_w) {
+    return conv_wgrad_ws_floats(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w));
+}
+int ssd_op_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const float* w, float weight_decay,
+                        float* ws, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil,
+                        int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    conv_wgrad(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), x, dy, dw, dbias, w, weight_decay, ws,
+               (hipStream_t)stream);
+    API_END
+}
+int ssd_op_maxpool_fwd(const float* x, float* y, int b, int hi, int wi, int c, int ho, int wo, int k, int stride, int pad_h,
+                       int pad_w, void* stream) {
+    API_BEGIN
+    PoolDesc d{b, hi, wi, c, ho, wo, k, stride, pad_h, pad_w};
+    maxpool_fwd(d, x, y, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_maxpool_bwd(const float* x, const float* dy, float* dx, int accumulate, int relu_mask, int b, int hi, int wi, int c,
+                       int ho, int wo, int k, int stride, int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    PoolDesc d{b, hi, wi, c, ho, wo, k, stride, pad_h, pad_w};
+    maxpool_bwd(d, x, dy, dx, accumulate != 0, relu_mask != 0, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_l2norm_fwd(const float* x, const float* scale, float* y, int npix, int c, void* stream) {
+    API_BEGIN
+    l2norm_fwd(npix, c, x, scale, y, (hipStream_t)stream);
+    API_END
+}
+size_t ssd_op_l2norm_bwd_ws_floats(int npix, int c) { return l2norm_bwd_ws_floats(npix, c); }
+int ssd_op_l2norm_bwd(const float* x, const float* scale, const float* dy, float* dx, float* dscale, float* ws, int npix,
+                      int c, void* stream) {
+    API_BEGIN
+    l2norm_bwd(npix, c, x, scale, dy, dx, dscale, ws, (hipStream_t)stream);
+    API_END
+}
+
+}  // extern "C"

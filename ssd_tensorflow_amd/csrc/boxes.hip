@@ -1,0 +1,527 @@
+// Box math of the SSD hot path for gfx950.  Integer / index results are bit-exact with the
+// reference's numpy code (ssdutils.py, transforms.py, utils.py geometry) as it runs under
+// numpy >= 2: the mixed f32/f64 arithmetic of decode_location / normalize_box is spelled out
+// with explicitly rounded operations.  This file is compiled with -ffp-contract=off.
+#include "boxes.h"
+#include <cmath>
+#include <climits>
+
+namespace ssd {
+
+typedef unsigned long long u64;
+
+// =================================================================================
+// presets (ssdutils.py:36-62) and box sizes (ssdutils.py:83-99) -- host
+// =================================================================================
+static Preset make_preset(const char* name, int img, int nmaps, const int* sizes, const double* scales, int last_two,
+                          double extra, int A) {
+    Preset p{};
+    p.name = name; p.image_w = p.image_h = img; p.nmaps = nmaps; p.extra_scale = extra; p.num_anchors = A;
+    for (int k = 0; k < nmaps; ++k) {
+        p.map_size[k] = sizes[k];
+        p.scale[k] = scales[k];
+        const bool two = (k == 0) || (k >= nmaps - last_two);
+        if (two) {
+            p.nratios[k] = 2; p.ratios[k][0] = 2; p.ratios[k][1] = 0.5;
+        } else {
+            p.nratios[k] = 4; p.ratios[k][0] = 2; p.ratios[k][1] = 3; p.ratios[k][2] = 0.5; p.ratios[k][3] = 1. / 3.;
+        }
+    }
+    int off = 0;
+    for (int k = 0; k < nmaps; ++k) {
+        const double s = p.scale[k];
+        int t = 0;
+        double r = std::sqrt(1.0);
+        p.bw[k][t] = s * r; p.bh[k][t] = s / r; ++t;
+        for (int q = 0; q < p.nratios[k]; ++q) {
+            r = std::sqrt(p.ratios[k][q]);
+            p.bw[k][t] = s * r; p.bh[k][t] = s / r; ++t;
+        }
+        const double nxt = k < nmaps - 1 ? p.scale[k + 1] : extra;
+        const double sp = std::sqrt(s * nxt);
+        p.bw[k][t] = sp; p.bh[k][t] = sp; ++t;
+        p.ntypes[k] = t;
+        p.off[k] = off;
+        off += t * sizes[k] * sizes[k];
+    }
+    p.off[nmaps] = off;
+    if (off != A) fail("preset %s: anchor count %d != %d", name, off, A);
+    return p;
+}
+
+const Preset& get_preset(const char* name) {
+    static const int s300[] = {38, 19, 10, 5, 3, 1};
+    static const double c300[] = {0.1, 0.2, 0.375, 0.55, 0.725, 0.9};
+    static const int s512[] = {64, 32, 16, 8, 4, 2, 1};
+    static const double c512[] = {0.07, 0.15, 0.3, 0.45, 0.6, 0.75, 0.9};
+    static const Preset p300 = make_preset("vgg300", 300, 6, s300, c300, 2, 1.075, 8732);
+    static const Preset p512 = make_preset("vgg512", 512, 7, s512, c512, 2, 1.05, 24564);
+    if (name && !strcmp(name, "vgg300")) return p300;
+    if (name && !strcmp(name, "vgg512")) return p512;
+    fail("No such preset: %s", name ? name : "(null)");
+    return p300;
+}
+
+// =================================================================================
+// anchors (ssdutils.py:104-130): order map -> type -> row -> col
+// =================================================================================
+struct AnchorArgs {
+    int nmaps, A;
+    int fk[PRESET_MAX_MAPS], off[PRESET_MAX_MAPS + 1];
+    double bw[PRESET_MAX_MAPS][PRESET_MAX_TYPES], bh[PRESET_MAX_MAPS][PRESET_MAX_TYPES];
+};
+
+// utils.py:100-108 in f64: int() truncates toward zero
+__device__ __forceinline__ void prop2abs_f64(double cx, double cy, double w, double h, int* o) {
+    const double w2 = __ddiv_rn(__dmul_rn(w, 1000.0), 2.0);
+    const double h2 = __ddiv_rn(__dmul_rn(h, 1000.0), 2.0);
+    const double ax = __dmul_rn(cx, 1000.0), ay = __dmul_rn(cy, 1000.0);
+    o[0] = (int)(long long)__dsub_rn(ax, w2);
+    o[1] = (int)(long long)__dadd_rn(ax, w2);
+    o[2] = (int)(long long)__dsub_rn(ay, h2);
+    o[3] = (int)(long long)__dadd_rn(ay, h2);
+}
+
+__global__ void anchors_kernel(AnchorArgs p, double* __restrict__ anchors, int* __restrict__ aabs) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.A) return;
+    int k = 0;
+    for (int q = 1; q < p.nmaps; ++q)
+        if (a >= p.off[q]) k = q;
+    const int fk = p.fk[k];
+    const int al = a - p.off[k];
+    const int t = al / (fk * fk);
+    const int cell = al - t * fk * fk;
+    const int j = cell / fk, i = cell - j * fk;
+    const double x = __ddiv_rn((double)i + 0.5, (double)fk);
+    const double y = __ddiv_rn((double)j + 0.5, (double)fk);
+    const double w = p.bw[k][t], h = p.bh[k][t];
+    anchors[a * 4 + 0] = x; anchors[a * 4 + 1] = y; anchors[a * 4 + 2] = w; anchors[a * 4 + 3] = h;
+    if (aabs) prop2abs_f64(x, y, w, h, aabs + a * 4);
+}
+
+void anchors_device(const Preset& p, double* anchors, int* anchors_abs, hipStream_t s) {
+    AnchorArgs a{};
+    a.nmaps = p.nmaps; a.A = p.num_anchors;
+    for (int k = 0; k < p.nmaps; ++k) {
+        a.fk[k] = p.map_size[k];
+        a.off[k] = p.off[k];
+        for (int t = 0; t < PRESET_MAX_TYPES; ++t) { a.bw[k][t] = p.bw[k][t]; a.bh[k][t] = p.bh[k][t]; }
+    }
+    a.off[p.nmaps] = p.off[p.nmaps];
+    hipLaunchKernelGGL(anchors_kernel, dim3((a.A + 255) / 256), dim3(256), 0, s, a, anchors, anchors_abs);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// label encoding (transforms.py:57-114).  IoU uses the +1 pixel convention on integer
+// boxes (ssdutils.py:138-152); ratios are compared exactly by cross-multiplication.
+// =================================================================================
+__device__ __forceinline__ void iou_terms(const int* g, long long areab, const int* a, long long* inter, long long* uni) {
+    const long long areaa = (long long)(a[1] - a[0] + 1) * (a[3] - a[2] + 1);
+    const int w = max(0, min(g[1], a[1]) - max(g[0], a[0]) + 1);
+    const int h = max(0, min(g[3], a[3]) - max(g[2], a[2]) + 1);
+    *inter = (long long)w * h;
+    *uni = areab + areaa - *inter;
+}
+
+// one workgroup per GT box: its best anchor (np.argmax: first maximum), ssdutils.py:159-165
+__global__ __launch_bounds__(256) void gt_best_kernel(int A, const int* __restrict__ aabs, const double* __restrict__ gt,
+                                                      int ntot, int* __restrict__ gabs, int* __restrict__ best_a,
+                                                      int* __restrict__ best_i, int* __restrict__ best_u) {
+    __shared__ long long s_i[256], s_u[256];
+    __shared__ int s_a[256];
+    __shared__ int gb[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        prop2abs_f64(gt[g * 4 + 0], gt[g * 4 + 1], gt[g * 4 + 2], gt[g * 4 + 3], gb);
+        for (int e = 0; e < 4; ++e) gabs[g * 4 + e] = gb[e];
+    }
+    __syncthreads();
+    const int box[4] = {gb[0], gb[1], gb[2], gb[3]};
+    const long long areab = (long long)(box[1] - box[0] + 1) * (box[3] - box[2] + 1);
+    long long bi = -1, bu = 1;
+    int ba = INT_MAX;
+    for (int a = tid; a < A; a += 256) {
+        long long in, un;
+        iou_terms(box, areab, aabs + a * 4, &in, &un);
+        if (in * bu > bi * un) { bi = in; bu = un; ba = a; }     // strict: the earlier index keeps a tie
+    }
+    s_i[tid] = bi; s_u[tid] = bu; s_a[tid] = ba;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            const long long i2 = s_i[tid + st], u2 = s_u[tid + st];
+            const int a2 = s_a[tid + st];
+            const long long l = i2 * s_u[tid], r = s_i[tid] * u2;
+            if (l > r || (l == r && a2 < s_a[tid])) { s_i[tid] = i2; s_u[tid] = u2; s_a[tid] = a2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool ok = 2 * s_i[0] > s_u[0];                      // iou > 0.5
+        best_a[g] = ok ? s_a[0] : -1;
+        best_i[g] = (int)s_i[0];
+        best_u[g] = (int)s_u[0];
+    }
+}
+
+// one thread per (image, anchor): the winning GT box (pass 1: every 'good' overlap, higher IoU
+// wins, earlier box keeps a tie; pass 2: 'best' matches override, same rule among them) and
+// the encoded row (ssdutils.py:173-179, transforms.py:47-55).
+__global__ __launch_bounds__(256) void label_rows_kernel(int A, int C, int B, const double* __restrict__ anchors,
+                                                         const int* __restrict__ aabs, const double* __restrict__ gt,
+                                                         const int* __restrict__ cls, const int* __restrict__ offsets,
+                                                         const int* __restrict__ gabs, const int* __restrict__ best_a,
+                                                         float* __restrict__ vec) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * A) return;
+    const int b = idx / A, a = idx - b * A;
+    const int an[4] = {aabs[a * 4], aabs[a * 4 + 1], aabs[a * 4 + 2], aabs[a * 4 + 3]};
+    int w1 = -1, w2 = -1;
+    long long i1 = 0, u1 = 1, i2 = 0, u2 = 1;
+    for (int g = offsets[b]; g < offsets[b + 1]; ++g) {
+        const int box[4] = {gabs[g * 4], gabs[g * 4 + 1], gabs[g * 4 + 2], gabs[g * 4 + 3]};
+        const long long areab = (long long)(box[1] - box[0] + 1) * (box[3] - box[2] + 1);
+        long long in, un;
+        iou_terms(box, areab, an, &in, &un);
+        if (2 * in > un) {
+            if (w1 < 0 || in * u1 > i1 * un) { w1 = g; i1 = in; u1 = un; }
+        }
+        if (best_a[g] == a) {
+            if (w2 < 0 || in * u2 > i2 * un) { w2 = g; i2 = in; u2 = un; }
+        }
+    }
+    const int win = w2 >= 0 ? w2 : w1;
+    float* row = vec + (size_t)idx * (C + 5);
+    for (int c = 0; c < C + 5; ++c) row[c] = 0.f;
+    if (win < 0) {
+        row[C] = 1.f;
+        return;
+    }
+    row[cls[win]] = 1.f;
+    const double acx = anchors[a * 4], acy = anchors[a * 4 + 1], aw = anchors[a * 4 + 2], ah = anchors[a * 4 + 3];
+    const double bcx = gt[win * 4], bcy = gt[win * 4 + 1], bw = gt[win * 4 + 2], bh = gt[win * 4 + 3];
+    row[C + 1] = (float)__dmul_rn(__ddiv_rn(__dsub_rn(bcx, acx), aw), 10.0);
+    row[C + 2] = (float)__dmul_rn(__ddiv_rn(__dsub_rn(bcy, acy), ah), 10.0);
+    row[C + 3] = (float)__dmul_rn(log(__ddiv_rn(bw, aw)), 5.0);
+    row[C + 4] = (float)__dmul_rn(log(__ddiv_rn(bh, ah)), 5.0);
+}
+
+size_t encode_labels_ws_bytes(int ntot) { return (size_t)(ntot > 0 ? ntot : 1) * 7 * sizeof(int) + 64; }
+
+void encode_labels(const Preset& p, int num_classes, const double* anchors, const int* anchors_abs, const double* gt,
+                   const int* cls, const int* offsets, int B, int ntot, float* vec, void* ws, hipStream_t s) {
+    int* gabs = (int*)ws;
+    int* best_a = gabs + (size_t)(ntot > 0 ? ntot : 1) * 4;
+    int* best_i = best_a + (ntot > 0 ? ntot : 1);
+    int* best_u = best_i + (ntot > 0 ? ntot : 1);
+    const int A = p.num_anchors;
+    if (ntot > 0)
+        hipLaunchKernelGGL(gt_best_kernel, dim3(ntot), dim3(256), 0, s, A, anchors_abs, gt, ntot, gabs, best_a, best_i, best_u);
+    hipLaunchKernelGGL(label_rows_kernel, dim3((B * A + 255) / 256), dim3(256), 0, s, A, num_classes, B, anchors, anchors_abs,
+                       gt, cls, offsets, gabs, best_a, vec);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// decode (ssdutils.py:192-229) + per-class greedy NMS (ssdutils.py:232-318)
+// =================================================================================
+// Pass 1, HBM-bound: every anchor row [C+5] f32 is read exactly once through LDS (coalesced
+// float4 loads; rows are then read at an odd stride: conflict-free).  Candidates with
+// confidence >= thr are appended to the image's list as one 64-bit sort key:
+//   conf bits << 32 | (32767 - anchor) << 8 | class      (descending sort == conf desc, anchor asc)
+constexpr int SCAN_ROWS = 256;
+
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          int A2, int* __restrict__ counts, u64* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const size_t total_rows = (size_t)B * A;
+    const size_t r0 = (size_t)blockIdx.x * SCAN_ROWS;
+    const size_t nrows = min((size_t)SCAN_ROWS, total_rows - r0);
+    const size_t nfl = nrows * nv;
+    const float* src = pred + r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
+    const size_t n4 = nfl >> 2;
+    for (size_t i = threadIdx.x; i < n4; i += 256)
+        *reinterpret_cast<float4*>(rows + i * 4) = *reinterpret_cast<const float4*>(src + i * 4);
+    for (size_t i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x >= nrows) return;
+    const float* r = rows + (size_t)threadIdx.x * nv;
+    const int nfg = nv - 5;                      // argmax excludes the background class
+    int best = 0;
+    float conf = r[0];
+    for (int c = 1; c < nfg; ++c)
+        if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
+    if (!(conf < thr)) {                         // the reference breaks at the first conf < thr
+        const size_t row = r0 + threadIdx.x;
+        const int b = (int)(row / A), a = (int)(row - (size_t)b * A);
+        const int slot = atomicAdd(&counts[b], 1);
+        keys[(size_t)b * A2 + slot] = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best;
+    }
+}
+
+// descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
+__device__ void bitonic_desc(u64* keys, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if (up ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// decode_location under numpy>=2 promotion (x, y float32; w, h float64) followed by
+// normalize_box's integer box (utils.py:118-135; centre*1000 in f32, half extent cast to f32).
+__device__ __forceinline__ void decode_box(const float* loc, const double* an, int* o) {
+    float l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = loc[e] > 100.f ? 100.f : loc[e];      // ssdutils.py:183
+    const double acx = an[0], acy = an[1], aw = an[2], ah = an[3];
+    const float x = __fadd_rn(__fmul_rn(__fdiv_rn(l[0], 10.f), (float)aw), (float)acx);
+    const float y = __fadd_rn(__fmul_rn(__fdiv_rn(l[1], 10.f), (float)ah), (float)acy);
+    const double w = __dmul_rn(exp((double)__fdiv_rn(l[2], 5.f)), aw);
+    const double h = __dmul_rn(exp((double)__fdiv_rn(l[3], 5.f)), ah);
+    if (!(isfinite(x) && isfinite(y) && isfinite(w) && isfinite(h))) {
+        // the reference passes such a box through un-normalised and then fails in NMS's int();
+        // here it becomes an empty corner box
+        o[0] = o[1] = o[2] = o[3] = 0;
+        return;
+    }
+    const float w2 = (float)__ddiv_rn(__dmul_rn(w, 1000.0), 2.0);
+    const float h2 = (float)__ddiv_rn(__dmul_rn(h, 1000.0), 2.0);
+    const float cx = __fmul_rn(x, 1000.f), cy = __fmul_rn(y, 1000.f);
+    const float fx0 = __fsub_rn(cx, w2), fx1 = __fadd_rn(cx, w2), fy0 = __fsub_rn(cy, h2), fy1 = __fadd_rn(cy, h2);
+    const float big = 9.0e18f;
+    long long xmin = (long long)fminf(fmaxf(fx0, -big), big), xmax = (long long)fminf(fmaxf(fx1, -big), big);
+    long long ymin = (long long)fminf(fmaxf(fy0, -big), big), ymax = (long long)fminf(fmaxf(fy1, -big), big);
+    xmin = xmin > 0 ? xmin : 0; xmax = xmax < 999 ? xmax : 999;
+    ymin = ymin > 0 ? ymin : 0; ymax = ymax < 999 ? ymax : 999;
+    xmin = xmin < xmax ? xmin : xmax;
+    ymin = ymin < ymax ? ymin : ymax;
+    const long long lo = -(1LL << 30);
+    o[0] = (int)(xmin > lo ? xmin : lo); o[1] = (int)(xmax > lo ? xmax : lo);
+    o[2] = (int)(ymin > lo ? ymin : lo); o[3] = (int)(ymax > lo ? ymax : lo);
+}
+
+// prop2abs(abs2prop(ints)) as non_maximum_suppression recomputes it (not the identity)
+__device__ __forceinline__ void nms_roundtrip(const int* b, int* o) {
+    const double width = (double)(b[1] - b[0]), height = (double)(b[3] - b[2]);
+    const double cx = __ddiv_rn(__dadd_rn((double)b[0], __ddiv_rn(width, 2.0)), 1000.0);
+    const double cy = __ddiv_rn(__dadd_rn((double)b[2], __ddiv_rn(height, 2.0)), 1000.0);
+    prop2abs_f64(cx, cy, __ddiv_rn(width, 1000.0), __ddiv_rn(height, 1000.0), o);
+}
+
+constexpr int DET_THREADS = 256;
+constexpr int DET_LDS_KEYS = 2048;       // sort in LDS up to this many keys, else in (L2-resident) global
+constexpr int DET_MAX_ALIVE = 32768;
+
+struct DetectArgs {
+    int A, A2, nv, B;
+    const double* anchors;
+    const float* pred;
+    int cap, max_out, out_cap, do_nms;
+    const int* counts;
+    u64* keys1;
+    u64* keys2;
+    int* box;       // [B][A][4]
+    int* nbox;      // [B][A][4]
+    DetectOut out;
+};
+
+__global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p) {
+    __shared__ u64 lkeys[DET_LDS_KEYS];
+    __shared__ unsigned char alive[DET_MAX_ALIVE];
+    __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
+    __shared__ int s_npresent, s_wtot[DET_THREADS / 64], s_base;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(p.counts[b], p.A);
+    u64* g1 = p.keys1 + (size_t)b * p.A2;
+    u64* g2 = p.keys2 + (size_t)b * p.A2;
+    int* box = p.box + (size_t)b * p.A * 4;
+    int* nbox = p.nbox + (size_t)b * p.A * 4;
+
+    // ---- sort 1: confidence descending, anchor ascending ------------------------------
+    const int n2 = next_pow2(n > 1 ? n : 1);
+    if (n2 <= DET_LDS_KEYS) {
+        for (int i = tid; i < n2; i += DET_THREADS) lkeys[i] = i < n ? g1[i] : 0ull;
+        __syncthreads();
+        bitonic_desc(lkeys, n2);
+        for (int i = tid; i < n; i += DET_THREADS) g1[i] = lkeys[i];
+    } else {
+        for (int i = n + tid; i < n2; i += DET_THREADS) g1[i] = 0ull;
+        __syncthreads();
+        bitonic_desc(g1, n2);
+    }
+    __syncthreads();
+    const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
+
+    // ---- class groups in first-appearance order (defaultdict, ssdutils.py:311-314) ----
+    if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
+    __syncthreads();
+    for (int i = tid; i < m; i += DET_THREADS) {
+        const int c = (int)(g1[i] & 31ull);
+        atomicMin(&firstpos[c], i);
+        atomicAdd(&ccount[c], 1);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        int r = 0;
+        for (int c = 0; c < 32; ++c)
+            if (firstpos[c] < firstpos[tid]) ++r;
+        crank[tid] = (firstpos[tid] == INT_MAX) ? 31 : (p.do_nms ? r : 0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int np = 0;
+        if (p.do_nms) {     // decode-only mode: one group in confidence order, no suppression
+            for (int c = 0; c < 32; ++c)
+                if (firstpos[c] != INT_MAX) { order_cls[crank[c]] = c; ++np; }
+            int acc = 0;
+            for (int r = 0; r < np; ++r) { segstart[r] = acc; acc += ccount[order_cls[r]]; }
+            segstart[np] = acc;
+        }
+        s_npresent = np;
+    }
+    __syncthreads();
+
+    // ---- sort 2: (class rank, position) ascending == descending of the complement -----
+    const int m2 = next_pow2(m > 1 ? m : 1);
+    u64* k2 = m2 <= DET_LDS_KEYS ? lkeys : g2;
+    for (int i = tid; i < m2; i += DET_THREADS) {
+        u64 key = ~0ull;
+        if (i < m) key = ((u64)crank[(int)(g1[i] & 31ull)] << 32) | (u64)i;
+        k2[i] = ~key;
+    }
+    __syncthreads();
+    bitonic_desc(k2, m2);
+
+    // ---- decode every candidate in class-grouped order ----------------------------------
+    for (int q = tid; q < m; q += DET_THREADS) {
+        const int pos = (int)((~k2[q]) & 0xFFFFFFFFull);
+        const u64 key = g1[pos];
+        const int a = 32767 - (int)((key >> 8) & 0xFFFFull);
+        int bx[4], nb[4];
+        decode_box(p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4), p.anchors + (size_t)a * 4, bx);
+        nms_roundtrip(bx, nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { box[q * 4 + e] = bx[e]; nbox[q * 4 + e] = nb[e]; }
+        if (q < DET_MAX_ALIVE) alive[q] = 1;
+    }
+    __syncthreads();
+
+    // ---- greedy NMS: one wave per class segment; IoU(+1) > 0.45 as 20*inter > 9*union ---
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        volatile unsigned char* al = alive;
+        for (int r = wave; r < s_npresent; r += DET_THREADS / 64) {
+            const int s0 = segstart[r], len = segstart[r + 1] - s0;
+            for (int i = 0; i < len; ++i) {
+                if (!al[s0 + i]) continue;
+                const int* bi = nbox + (size_t)(s0 + i) * 4;
+                const int x0 = bi[0], x1 = bi[1], y0 = bi[2], y1 = bi[3];
+                const int area_i = (x1 - x0 + 1) * (y1 - y0 + 1);
+                for (int j = i + 1 + lane; j < len; j += 64) {
+                    if (!al[s0 + j]) continue;
+                    const int* bj = nbox + (size_t)(s0 + j) * 4;
+                    const int w = max(0, min(x1, bj[1]) - max(x0, bj[0]) + 1);
+                    const int h = max(0, min(y1, bj[3]) - max(y0, bj[2]) + 1);
+                    const int inter = w * h;
+                    const int uni = area_i + (bj[1] - bj[0] + 1) * (bj[3] - bj[2] + 1) - inter;
+                    if (20 * inter > 9 * uni) al[s0 + j] = 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- compact survivors in order; the caller's [:max_out] -------------------------------
+    int limit = p.out_cap;
+    if (p.max_out >= 0 && p.max_out < limit) limit = p.max_out;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    int total = 0;
+    for (int q0 = 0; q0 < m; q0 += DET_THREADS) {
+        const int q = q0 + tid;
+        const bool keep = q < m && alive[q];
+        const u64 bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = total, tot = 0;
+#pragma unroll
+        for (int i = 0; i < DET_THREADS / 64; ++i) {
+            if (i < wv) wbase += s_wtot[i];
+            tot += s_wtot[i];
+        }
+        const int o = wbase + before;
+        if (keep && o < limit) {
+            const int pos = (int)((~k2[q]) & 0xFFFFFFFFull);
+            const u64 key = g1[pos];
+            const size_t dst = (size_t)b * p.out_cap + o;
+            p.out.conf[dst] = __uint_as_float((unsigned)(key >> 32));
+            p.out.cls[dst] = (int)(key & 31ull);
+            p.out.idx[dst] = 32767 - (int)((key >> 8) & 0xFFFFull);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p.out.box[dst * 4 + e] = box[q * 4 + e];
+        }
+        total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) p.out.count[b] = p.max_out >= 0 ? min(total, p.max_out) : total;
+}
+
+static int pow2_ge(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+size_t detect_ws_bytes(int B, int A) {
+    const size_t A2 = pow2_ge(A);
+    return 256 + ((size_t)B * 4 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
+}
+
+void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
+            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s) {
+    SSD_REQUIRE(A <= 32767 && A <= DET_MAX_ALIVE, "detect: at most 32767 anchors (got %d)", A);
+    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
+    SSD_REQUIRE(out_cap >= 1, "detect: out_cap must be >= 1");
+    const int nv = num_classes + 5;
+    const int A2 = pow2_ge(A);
+    char* base = (char*)ws;
+    int* counts = (int*)base;
+    base += ((size_t)B * 4 + 255) / 256 * 256;
+    u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
+    u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
+    int* box = (int*)base; base += (size_t)B * A * 16;
+    int* nbox = (int*)base;
+    HIP_OK(hipMemsetAsync(counts, 0, (size_t)B * 4, s));
+    const size_t rows = (size_t)B * A;
+    const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
+    hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
+                       conf_thr, A2, counts, keys1);
+    DetectArgs a{};
+    a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.counts = counts;
+    a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
+    hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+}  // namespace ssd

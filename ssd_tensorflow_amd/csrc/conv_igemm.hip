@@ -1,0 +1,614 @@
+// im2col-free direct convolution for gfx950 (MI355X), fp32 in / fp32 accumulate on
+// the matrix cores (v_mfma_f32_32x32x2_f32, exact f32 == an fmaf chain).
+//
+// Forward and data-gradient are ONE gather-GEMM kernel:
+//     dst[m][n] = sum_{tap, c} src[pix(m, tap)][c] * Wt(tap, c, n)
+// with m = (b, oh, ow) the NHWC pixel index of dst, and the source pixel
+// pix = ((oh*mul + dh[tap]) / div, (ow*mul + dw[tap]) / div), zero outside the image.
+//   forward : src = x,  mul = stride, div = 1,      dh = kh*dil - pad, Wt = W[tap][c][n]
+//   dgrad   : src = dy, mul = 1,      div = stride, dh = pad - kh*dil, Wt = W[tap][n][c]
+// The weight gradient is a second kernel (reduction over pixels, split-M slabs).
+//
+// Tiling (per 256-thread workgroup = 4 wave64): block tile (32*TM*WM) x (32*TN*WN),
+// BK = 32 channels of one tap per k-iteration, iteration order channel-chunk outer /
+// tap inner so the 9 taps re-read the same pixels from L1/L2.  LDS tiles:
+//   A  [BM][36]   (k contiguous, +4 pad): ds_read_b128 gives each lane 4 consecutive
+//                 k of its row, conflict-free (36*i mod 64 distinct over 16 rows);
+//   B  fwd  [32][BN]  read as ds_read_b32 (lanes consecutive in n),
+//      dgrad[BN][36]  read as ds_read_b128 like A (the HWIO filter is consumed
+//                     transposed straight from its canonical layout, no repack).
+// The MFMA k-index is permuted (lane-half h owns k = 4h..4h+3 of each group of 8) so
+// one b128 read feeds 4 MFMAs; a permutation of the reduction index is harmless as
+// long as A and B use the same one.
+// Global->LDS goes through registers (the gather needs zero fill), issued one
+// k-iteration ahead of the MFMAs that consume it (two LDS buffers, one barrier / iter).
+#include "conv.h"
+
+namespace ssd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDA = 36;
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct GatherArgs {
+    const float* src;
+    const float* wgt;
+    const float* bias;
+    const float* mask;
+    float* dst;
+    int M, DH, DW, DN;
+    int SH, SW, SC;
+    int ntaps, mul, div;
+    int wci, wco;
+    int relu, accum;
+    int NT;                 // number of n tiles
+    int tap_dh[9], tap_dw[9];
+};
+
+// XCD-aware bijective remap: workgroup b runs on XCD b % 8; give every XCD a
+// contiguous run of tiles so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
+__global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_ROWS = BM / 32;                   // rows staged per thread
+    constexpr int B_CPR = BN / 4;                     // fwd: float4 per k-row
+    constexpr int B_RPP = 256 / B_CPR;                // fwd: k-rows per pass
+    constexpr int B_FWD_N = (BK + B_RPP - 1) / B_RPP; // fwd: passes
+    constexpr int B_DG_N = BN / 32;                   // dgrad: rows per thread
+    constexpr int B_N = MODE == MODE_FWD ? B_FWD_N : B_DG_N;
+    constexpr int A_LDS = BM * LDA;
+    constexpr int B_LDS = MODE == MODE_FWD ? BK * BN : BN * LDA;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(B_RPP <= BK, "tile too narrow");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / p.NT, nt = wg - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread staging rows of the A (pixel gather) tile ------------------
+    const int a_c4 = (tid & 7) * 4;
+    int rb[A_ROWS], rh[A_ROWS], rw[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.DW;
+        const int t2 = mm / p.DW;
+        const int oh = t2 % p.DH;
+        const int b = t2 / p.DH;
+        rb[i] = b * p.SH * p.SW;
+        rh[i] = m < p.M ? oh * p.mul : -(1 << 20);
+        rw[i] = ow * p.mul;
+    }
+
+    const int nchunks = SMALLC ? 1 : (p.SC + BK - 1) / BK;
+    const int nk = SMALLC ? 1 : nchunks * p.ntaps;
+
+    f32x4 areg[A_ROWS];
+    f32x4 breg[B_N];
+
+    auto load_tiles = [&](int kiter) {
+        const int cc = kiter / p.ntaps;
+        const int tap = kiter - cc * p.ntaps;
+        if constexpr (SMALLC) {
+            // K = ntaps*SC (27 for conv1_1) packed k = tap*SC + c; scalar gather.
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = a_c4 + e;
+                    if (k < p.ntaps * p.SC) {
+                        const int tp = k / p.SC, c = k - tp * p.SC;
+                        const int sh = rh[i] + p.tap_dh[tp], sw = rw[i] + p.tap_dw[tp];
+                        if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW)
+                            v[e] = p.src[(size_t)(rb[i] + sh * p.SW + sw) * p.SC + c];
+                    }
+                }
+                areg[i] = v;
+            }
+        } else {
+            const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+            const int c = cc * BK + a_c4;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                int sh = rh[i] + dh, sw = rw[i] + dw;
+                bool ok = c < p.SC;
+                if constexpr (STRIDED) {
+                    ok = ok && (sh % p.div == 0) && (sw % p.div == 0);
+                    sh /= p.div;
+                    sw /= p.div;
+                }
+                ok = ok && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = ld4(p.src + (size_t)(rb[i] + sh * p.SW + sw) * p.SC + c);
+                areg[i] = v;
+            }
+        }
+        if constexpr (MODE == MODE_FWD) {
+            const int col = (tid % B_CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < B_FWD_N; ++i) {
+                const int kr = tid / B_CPR + B_RPP * i;
+                const int c = cc * BK + kr;            // SMALLC: cc == 0, c is the packed k
+                const bool ok = (SMALLC ? c < p.ntaps * p.SC : c < p.SC) && (n0 + col) < p.DN && kr < BK;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = ld4(p.wgt + (size_t)((SMALLC ? 0 : tap * p.wci) + c) * p.wco + n0 + col);
+                breg[i] = v;
+            }
+        } else {
+            const int c = cc * BK + a_c4;              // k index = dy channel (filter's Co axis)
+#pragma unroll
+            for (int i = 0; i < B_DG_N; ++i) {
+                const int n = n0 + (tid >> 3) + 32 * i;   // n index = dx channel (filter's Ci axis)
+                const bool ok = n < p.DN && c < p.SC;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = ld4(p.wgt + (size_t)(tap * p.wci + n) * p.wco + c);
+                breg[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * (A_LDS + B_LDS);
+        float* Bs = As + A_LDS;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i)
+            *reinterpret_cast<f32x4*>(As + ((tid >> 3) + 32 * i) * LDA + a_c4) = areg[i];
+        if constexpr (MODE == MODE_FWD) {
+            const int col = (tid % B_CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < B_FWD_N; ++i) {
+                const int kr = tid / B_CPR + B_RPP * i;
+                if (kr < BK) *reinterpret_cast<f32x4*>(Bs + kr * BN + col) = breg[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_DG_N; ++i)
+                *reinterpret_cast<f32x4*>(Bs + ((tid >> 3) + 32 * i) * LDA + a_c4) = breg[i];
+        }
+    };
+
+    // ---- accumulators ---------------------------------------------------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * (A_LDS + B_LDS);
+        const float* Bs = As + A_LDS;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const int kb = g * 8 + lh * 4;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * TM + mi * 32 + li) * LDA + kb);
+            if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[ni][t] = Bs[(kb + t) * BN + wn * 32 * TN + ni * 32 + li];
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    b[ni] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 * TN + ni * 32 + li) * LDA + kb);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop --------------------------------------------------------------
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        const bool more = k + 1 < nk;
+        if (more) load_tiles(k + 1);
+        compute(k & 1);
+        if (more) store_tiles((k + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.DN) continue;
+            float bv = 0.f;
+            if constexpr (MODE == MODE_FWD) bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const size_t o = (size_t)m * p.DN + n;
+                float v = acc[mi][ni][r];
+                if constexpr (MODE == MODE_FWD) {
+                    v += bv;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                } else {
+                    if (p.accum) v += p.dst[o];
+                    if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
+                }
+                p.dst[o] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================
+// weight gradient:  dW[(tap, c)][n] = sum_m x[pix(m, tap)][c] * dy[m][n]
+// One workgroup owns (tap, channel tile, n tile, pixel split); 32 pixels per iteration.
+// MFMA roles: A[i = channel][k = pixel], B[k = pixel][j = n]; both tiles are stored
+// pixel-major in LDS and read with conflict-free ds_read_b32.
+// =================================================================================
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* ws;              // [nsplit][ntaps*Ci*Co + Co]
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int ntaps, stride;
+    int CT, NT;             // channel tiles, n tiles
+    int mchunk, nsplit;
+    int tap_dh[9], tap_dw[9];
+};
+
+template <int WM, int WN, int TM, int TN, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 32;
+    constexpr int X_CPR = BKT / 4, X_RPP = 256 / X_CPR, X_N = (BP + X_RPP - 1) / X_RPP;
+    constexpr int Y_CPR = BNT / 4, Y_RPP = 256 / Y_CPR, Y_N = (BP + Y_RPP - 1) / Y_RPP;
+    constexpr int X_LDS = BP * BKT, Y_LDS = BP * BNT;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x;
+    int tile = blockIdx.y;
+    const int nt = tile % p.NT;
+    tile /= p.NT;
+    const int ct = tile % p.CT;
+    const int tap = tile / p.CT;
+    const int c0 = ct * BKT, n0 = nt * BNT;
+    const int mbeg = split * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int niter = (mend - mbeg + BP - 1) / BP;
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const bool do_bias = (tap == 0 && ct == 0);
+
+    f32x4 xreg[X_N], yreg[Y_N];
+
+    auto load_tiles = [&](int it) {
+        const int mb = mbeg + it * BP;
+#pragma unroll
+        for (int i = 0; i < X_N; ++i) {
+            const int r = tid / X_CPR + X_RPP * i;
+            const int col = (tid % X_CPR) * 4;
+            const int m = mb + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < BP && m < mend) {
+                const int ow = m % p.Wo;
+                const int t2 = m / p.Wo;
+                const int oh = t2 % p.Ho;
+                const int b = t2 / p.Ho;
+                if constexpr (SMALLC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = col + e;
+                        if (k < p.ntaps * p.Ci) {
+                            const int tp = k / p.Ci, c = k - tp * p.Ci;
+                            const int sh = oh * p.stride + p.tap_dh[tp], sw = ow * p.stride + p.tap_dw[tp];
+                            if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi)
+                                v[e] = p.x[((size_t)(b * p.Hi + sh) * p.Wi + sw) * p.Ci + c];
+                        }
+                    }
+                } else {
+                    const int sh = oh * p.stride + dh, sw = ow * p.stride + dw;
+                    const int c = c0 + col;
+                    if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi && c < p.Ci)
+                        v = ld4(p.x + ((size_t)(b * p.Hi + sh) * p.Wi + sw) * p.Ci + c);
+                }
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Y_N; ++i) {
+            const int r = tid / Y_CPR + Y_RPP * i;
+            const int col = (tid % Y_CPR) * 4;
+            const int m = mb + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < BP && m < mend && n0 + col < p.Co) v = ld4(p.dy + (size_t)m * p.Co + n0 + col);
+            yreg[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* Xs = smem + buf * (X_LDS + Y_LDS);
+        float* Ys = Xs + X_LDS;
+#pragma unroll
+        for (int i = 0; i < X_N; ++i) {
+            const int r = tid / X_CPR + X_RPP * i;
+            if (r < BP) *reinterpret_cast<f32x4*>(Xs + r * BKT + (tid % X_CPR) * 4) = xreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Y_N; ++i) {
+            const int r = tid / Y_CPR + Y_RPP * i;
+            if (r < BP) *reinterpret_cast<f32x4*>(Ys + r * BNT + (tid % Y_CPR) * 4) = yreg[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const float* Xs = smem + buf * (X_LDS + Y_LDS);
+        const float* Ys = Xs + X_LDS;
+#pragma unroll 4
+        for (int st = 0; st < BP / 2; ++st) {
+            const int r = st * 2 + lh;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = Xs[r * BKT + wm * 32 * TM + mi * 32 + li];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = Ys[r * BNT + wn * 32 * TN + ni * 32 + li];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (do_bias && tid < BNT) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BP; ++r) s += Ys[r * BNT + tid];
+            bsum += s;
+        }
+    };
+
+    if (niter > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const bool more = it + 1 < niter;
+        if (more) load_tiles(it + 1);
+        compute(it & 1);
+        if (more) store_tiles((it + 1) & 1);
+        __syncthreads();
+    }
+
+    const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                size_t row;
+                if constexpr (SMALLC) {
+                    if (kl >= p.ntaps * p.Ci) continue;
+                    row = kl;
+                } else {
+                    if (c0 + kl >= p.Ci) continue;
+                    row = (size_t)tap * p.Ci + c0 + kl;
+                }
+                slab[row * p.Co + n] = acc[mi][ni][r];
+            }
+        }
+    }
+    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+}
+
+// Fixed-order reduce of the split slabs: dw = sum_s slab_s + wd*w ; db = sum_s bias_s.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t wcount,
+                                                           int Co, float* __restrict__ dw, float* __restrict__ db,
+                                                           const float* __restrict__ w, float wd) {
+    const size_t total = wcount + Co;
+    const size_t stride = total;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+        // wcount and Co are multiples of 4: a float4 never straddles the weight/bias boundary
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsplit; ++k) s += ld4(ws + (size_t)k * stride + i);
+        if (i < wcount) {
+            if (wd != 0.f) s += wd * ld4(w + i);
+            *reinterpret_cast<f32x4*>(dw + i) = s;
+        } else if (db) {
+            *reinterpret_cast<f32x4*>(db + (i - wcount)) = s;
+        }
+    }
+}
+
+// =================================================================================
+// host launchers
+// =================================================================================
+template <typename K>
+static void set_lds(K kern, size_t bytes) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
+static void launch_gather(GatherArgs& a, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)(BM * LDA + (MODE == MODE_FWD ? BK * BN : BN * LDA)) * sizeof(float);
+    auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    const int MT = cdiv(a.M, BM);
+    a.NT = cdiv(a.DN, BN);
+    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+static void check_desc(const ConvDesc& d) {
+    SSD_REQUIRE(d.KH * d.KW <= 9 && d.KH * d.KW >= 1, "conv: at most 9 taps (got %dx%d)", d.KH, d.KW);
+    SSD_REQUIRE(d.Co % 4 == 0, "conv: Co must be a multiple of 4 (got %d)", d.Co);
+    SSD_REQUIRE(d.Ci % 4 == 0 || d.Ci * d.KH * d.KW <= 32, "conv: Ci must be a multiple of 4 or Ci*taps <= 32 (got %d)", d.Ci);
+    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 31) && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 31),
+                "conv: tensor too large for 32-bit pixel indexing");
+}
+
+void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s) {
+    check_desc(d);
+    GatherArgs a{};
+    a.src = x; a.wgt = w; a.bias = bias; a.mask = nullptr; a.dst = y;
+    a.M = d.B * d.Ho * d.Wo; a.DH = d.Ho; a.DW = d.Wo; a.DN = d.Co;
+    a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
+    a.ntaps = d.KH * d.KW; a.mul = d.stride; a.div = 1;
+    a.wci = d.Ci; a.wco = d.Co; a.relu = relu; a.accum = 0;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+    const bool smallc = d.Ci % 4 != 0;
+    if (smallc) {
+        launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, s);
+    } else if (d.Co <= 64) {
+        launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, s);
+    } else {
+        launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, s);
+    }
+}
+
+void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* mask, bool accumulate,
+                hipStream_t s) {
+    check_desc(d);
+    SSD_REQUIRE(d.Ci % 4 == 0, "conv_dgrad: Ci must be a multiple of 4");
+    GatherArgs a{};
+    a.src = dy; a.wgt = w; a.bias = nullptr; a.mask = mask; a.dst = dx;
+    a.M = d.B * d.Hi * d.Wi; a.DH = d.Hi; a.DW = d.Wi; a.DN = d.Ci;
+    a.SH = d.Ho; a.SW = d.Wo; a.SC = d.Co;
+    a.ntaps = d.KH * d.KW; a.mul = 1; a.div = d.stride;
+    a.wci = d.Ci; a.wco = d.Co; a.relu = 0; a.accum = accumulate;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = d.pad_h - kh * d.dil;
+            a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
+        }
+    if (d.stride > 1) {
+        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, true>(a, s);
+        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, s);
+    } else {
+        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, s);
+        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, s);
+    }
+}
+
+// ---- wgrad planning ---------------------------------------------------------------
+struct WgradPlan {
+    int cfg;        // 0: 128x128, 1: 64x64, 2: 64x128
+    int bkt, bnt, CT, NT, tiles, nsplit, mchunk;
+    bool smallc;
+};
+
+static WgradPlan plan_wgrad(const ConvDesc& d) {
+    WgradPlan p{};
+    const int M = d.B * d.Ho * d.Wo;
+    p.smallc = d.Ci % 4 != 0;
+    if (p.smallc || (d.Ci <= 64 && d.Co <= 64)) p.cfg = 1;
+    else if (d.Ci <= 64) p.cfg = 2;
+    else p.cfg = 0;
+    p.bkt = p.cfg == 0 ? 128 : 64;
+    p.bnt = p.cfg == 1 ? 64 : 128;
+    p.CT = p.smallc ? 1 : cdiv(d.Ci, p.bkt);
+    p.NT = cdiv(d.Co, p.bnt);
+    const int taps = p.smallc ? 1 : d.KH * d.KW;
+    p.tiles = taps * p.CT * p.NT;
+    int want = cdiv(1536, p.tiles);
+    int maxs = cdiv(M, 256);
+    p.nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);
+    if (p.nsplit < 1) p.nsplit = 1;
+    p.mchunk = cdiv(cdiv(M, p.nsplit), 32) * 32;
+    p.nsplit = cdiv(M, p.mchunk);
+    return p;
+}
+
+size_t conv_wgrad_ws_floats(const ConvDesc& d) {
+    WgradPlan p = plan_wgrad(d);
+    return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
+}
+
+template <int WM, int WN, int TM, int TN, bool SMALLC>
+static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)(32 * BKT + 32 * BNT) * sizeof(float);
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, SMALLC>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.tiles), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
+                float weight_decay, float* ws, hipStream_t s) {
+    check_desc(d);
+    WgradPlan pl = plan_wgrad(d);
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.ws = ws;
+    a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
+    a.ntaps = d.KH * d.KW; a.stride = d.stride; a.CT = pl.CT; a.NT = pl.NT;
+    a.mchunk = pl.mchunk; a.nsplit = pl.nsplit;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+    if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, s);
+    else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, s);
+    else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, s);
+    else launch_wgrad<2, 2, 2, 2, false>(a, pl, s);
+
+    const size_t wcount = (size_t)a.ntaps * d.Ci * d.Co;
+    const size_t total = wcount + d.Co;
+    int blocks = cdiv((long long)total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, pl.nsplit, wcount, d.Co, dw, dbias, w,
+                       weight_decay);
+    HIP_OK(hipGetLastError());
+}
+
+}  // namespace ssd

@@ -1,0 +1,142 @@
+// The SSD-VGG step executor: layer table, HBM arenas, forward / backward schedules.
+// Mirrors the graph SSDVGG.build_from_vgg assembles (ssdvgg.py:96-118, 190-372) and the
+// loss/optimizer of build_optimizer (ssdvgg.py:375-599).
+#pragma once
+#include "common.h"
+#include "conv.h"
+#include "ops.h"
+#include "boxes.h"
+#include <string>
+#include <vector>
+#include <map>
+
+namespace ssd {
+
+struct Tensor {
+    std::string name;        // TF scope of the producing op ("conv4_3", "pool3", "norm_conv4_3", "head2")
+    int H = 0, W = 0, C = 0;
+    bool relu_out = false;   // produced by conv+relu: gradients written into it get the relu mask
+    int consumers = 0;       // ops reading it in forward
+    int done = 0;            // backward bookkeeping
+    float* data = nullptr;
+    float* grad = nullptr;
+    size_t per_image() const { return (size_t)H * W * C; }
+};
+
+enum OpKind { OP_CONV, OP_POOL, OP_L2NORM };
+
+struct Op {
+    OpKind kind;
+    std::string name;        // TF variable scope for conv ops
+    int in = -1, out = -1;   // tensor ids
+    // conv
+    int KH = 1, KW = 1, stride = 1, dil = 1, pad_h = 0, pad_w = 0;
+    bool relu = true;
+    size_t w_off = 0, b_off = 0;     // offsets (floats) into the arenas
+    // pool
+    int k = 2;
+    // head op: index of the feature map, else -1
+    int head = -1;
+};
+
+struct Variable {
+    std::string name;        // reference TF variable name
+    int ndim;
+    int shape[4];
+    // location inside the arena: `rows` rows of `width` floats, `pitch` apart, from `off`
+    size_t off, rows, width, pitch;
+    size_t count() const { return rows * width; }
+};
+
+class Net {
+public:
+    Net(const char* preset, int num_classes, int max_batch, int device, bool training, unsigned long long seed,
+        float* ext_params, float* ext_grads, float* ext_momentum);
+    ~Net();
+
+    static size_t arena_floats(const char* preset, int num_classes);
+
+    void set_stream(hipStream_t s) { stream_ = s; }
+    hipStream_t stream() const { return stream_; }
+
+    // steps; x/y device pointers
+    void forward(const float* x, int b, bool train_mode, const float* y);
+    void backward(int b, const float* y);
+    void apply_gradients(float grad_scale);
+    void set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd);
+
+    // host-buffer conveniences
+    void upload_xy(const float* x, const float* y, int b);
+    const float* x_stage() const { return x_stage_; }
+    const float* y_stage() const { return y_stage_; }
+
+    void get_losses(float out[4]);
+    void copy_result(float* out, int b);
+
+    const std::vector<Variable>& variables() const { return vars_; }
+    void load_variable(const char* name, const float* host, size_t count, int which);   // 0 params, 2 momentum
+    void save_variable(const char* name, float* host, size_t count, int which);         // 0 params, 1 grads, 2 momentum
+    void activation(const char* name, int b, float* out, size_t count);
+    void activation_shape(const char* name, int* H, int* W, int* C) const;
+
+    void detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls, int* idx, int* box);
+
+    const Preset& preset() const { return *preset_; }
+    int num_classes() const { return C_; }
+    int nvars() const { return C_ + 5; }
+    int max_batch() const { return Bmax_; }
+    bool training() const { return training_; }
+    int device() const { return device_; }
+    float* params() { return params_; }
+    float* grads() { return grads_; }
+    float* momentum() { return mom_; }
+    size_t nparams() const { return nparams_; }
+    size_t nfilters() const { return nfilters_; }
+    float* result() { return result_; }
+    long long global_step = 0;
+
+private:
+    int add_tensor(const std::string& name, int H, int W, int C, bool relu_out);
+    void build_graph();
+    void alloc();
+    void init_weights(unsigned long long seed);
+    ConvDesc conv_desc(const Op& op, int b) const;
+    float current_lr() const;
+    const Variable& find_var(const char* name) const;
+    void* dalloc(size_t bytes);
+
+    const Preset* preset_;
+    int C_, Bmax_, device_;
+    bool training_;
+    hipStream_t stream_ = nullptr;
+
+    std::vector<Tensor> tensors_;
+    std::vector<Op> ops_;
+    std::vector<Variable> vars_;
+    int input_t_ = -1;
+    std::vector<int> head_t_;             // head output tensors per map
+    HeadLayout heads_{};
+
+    size_t nparams_ = 0, nfilters_ = 0, scale_off_ = 0;
+    float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr;
+    bool own_params_ = false, own_grads_ = false, own_mom_ = false;
+
+    float* result_ = nullptr;
+    float *x_stage_ = nullptr, *y_stage_ = nullptr;
+    float* wgrad_ws_ = nullptr;
+    float* l2_ws_ = nullptr;
+    void* loss_ws_ = nullptr;
+    LossWork lw_{};
+    float* losses_host_ = nullptr;        // pinned
+    double* anchors_dev_ = nullptr;
+    int* anchors_abs_dev_ = nullptr;
+    void* detect_ws_ = nullptr;
+    int detect_ws_b_ = 0;
+    std::vector<void*> allocs_;
+
+    std::vector<float> lr_values_{0.001f};
+    std::vector<long long> lr_bounds_;
+    float momentum_ = 0.9f, wd_ = 0.0005f;
+};
+
+}  // namespace ssd

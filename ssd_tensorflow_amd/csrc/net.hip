@@ -1,0 +1,482 @@
+// SSD-VGG step executor for gfx950.  See net.h.
+#include "net.h"
+#include <cmath>
+#include <algorithm>
+
+namespace ssd {
+
+static int round4(int n) { return (n + 3) / 4 * 4; }
+
+// ---------------------------------------------------------------------------------
+// graph (ssdvgg.py:190-372)
+// ---------------------------------------------------------------------------------
+int Net::add_tensor(const std::string& name, int H, int W, int C, bool relu_out) {
+    Tensor t;
+    t.name = name; t.H = H; t.W = W; t.C = C; t.relu_out = relu_out;
+    tensors_.push_back(t);
+    return (int)tensors_.size() - 1;
+}
+
+enum PadMode { PAD_SAME, PAD_VALID, PAD_BR1_VALID };
+
+void Net::build_graph() {
+    const Preset& p = *preset_;
+    const int nv = C_ + 5;
+    input_t_ = add_tensor("image_input", p.image_h, p.image_w, 3, false);
+    int cur = input_t_;
+
+    auto conv = [&](const std::string& name, int cout, int k, int stride, PadMode pm, int dil, bool relu, int head,
+                    int from) -> int {
+        const Tensor in = tensors_[from];
+        Op op;
+        op.kind = OP_CONV; op.name = name; op.in = from; op.KH = op.KW = k; op.stride = stride; op.dil = dil;
+        op.relu = relu; op.head = head;
+        int Ho, Wo;
+        if (pm == PAD_SAME) {
+            tf_same(in.H, k, stride, dil, &op.pad_h, &Ho);
+            tf_same(in.W, k, stride, dil, &op.pad_w, &Wo);
+        } else {
+            const int keff = (k - 1) * dil + 1;
+            const int extra = pm == PAD_BR1_VALID ? 1 : 0;     // tf.pad bottom/right +1 (ssdvgg.py:328-329)
+            op.pad_h = op.pad_w = 0;
+            Ho = (in.H + extra - keff) / stride + 1;
+            Wo = (in.W + extra - keff) / stride + 1;
+        }
+        op.out = add_tensor(head >= 0 ? "head" + std::to_string(head) : name, Ho, Wo, cout, relu);
+        tensors_[from].consumers++;
+        ops_.push_back(op);
+        return op.out;
+    };
+    auto pool = [&](const std::string& name, int k, int stride, int from) -> int {
+        const Tensor in = tensors_[from];
+        Op op;
+        op.kind = OP_POOL; op.name = name; op.in = from; op.k = k; op.stride = stride;
+        int Ho, Wo;
+        tf_same(in.H, k, stride, 1, &op.pad_h, &Ho);
+        tf_same(in.W, k, stride, 1, &op.pad_w, &Wo);
+        op.out = add_tensor(name, Ho, Wo, in.C, false);
+        tensors_[from].consumers++;
+        ops_.push_back(op);
+        return op.out;
+    };
+
+    // VGG-16 trunk (external SavedModel in the reference; ssdvgg.py:195-207)
+    cur = conv("conv1_1", 64, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv1_2", 64, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = pool("pool1", 2, 2, cur);
+    cur = conv("conv2_1", 128, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv2_2", 128, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = pool("pool2", 2, 2, cur);
+    cur = conv("conv3_1", 256, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv3_2", 256, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv3_3", 256, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = pool("pool3", 2, 2, cur);
+    cur = conv("conv4_1", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv4_2", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    const int c43 = cur = conv("conv4_3", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = pool("pool4", 2, 2, cur);
+    cur = conv("conv5_1", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv5_2", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv5_3", 512, 3, 1, PAD_SAME, 1, true, -1, cur);
+    // a-trous modifications (ssdvgg.py:231-292)
+    cur = pool("mod_pool5", 3, 1, cur);
+    cur = conv("mod_conv6", 1024, 3, 1, PAD_SAME, 6, true, -1, cur);
+    const int c7 = cur = conv("mod_conv7", 1024, 1, 1, PAD_SAME, 1, true, -1, cur);
+    // extra feature layers (ssdvgg.py:300-332)
+    const bool big = p.nmaps >= 7;
+    std::vector<int> fmaps{-1, c7};
+    cur = conv("conv8_1", 256, 1, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv8_2", 512, 3, 2, PAD_SAME, 1, true, -1, cur); fmaps.push_back(cur);
+    cur = conv("conv9_1", 128, 1, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv9_2", 256, 3, 2, PAD_SAME, 1, true, -1, cur); fmaps.push_back(cur);
+    cur = conv("conv10_1", 128, 1, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv10_2", 256, 3, big ? 2 : 1, big ? PAD_SAME : PAD_VALID, 1, true, -1, cur); fmaps.push_back(cur);
+    cur = conv("conv11_1", 128, 1, 1, PAD_SAME, 1, true, -1, cur);
+    cur = conv("conv11_2", 256, 3, 1, PAD_VALID, 1, true, -1, cur); fmaps.push_back(cur);
+    if (big) {
+        cur = conv("conv12_1", 128, 1, 1, PAD_SAME, 1, true, -1, cur);
+        cur = conv("conv12_2", 256, 3, 1, PAD_BR1_VALID, 1, true, -1, cur); fmaps.push_back(cur);
+    }
+    // l2 norm on conv4_3 (ssdvgg.py:335-337), then the fused multibox heads (ssdvgg.py:353-365)
+    {
+        Op op;
+        op.kind = OP_L2NORM; op.name = "l2_norm_conv4_3"; op.in = c43;
+        op.out = add_tensor("norm_conv4_3", tensors_[c43].H, tensors_[c43].W, tensors_[c43].C, false);
+        tensors_[c43].consumers++;
+        ops_.push_back(op);
+        fmaps[0] = op.out;
+    }
+    SSD_REQUIRE((int)fmaps.size() == p.nmaps, "feature map count mismatch");
+    heads_ = HeadLayout{};
+    heads_.nmaps = p.nmaps; heads_.A = p.num_anchors; heads_.nvars = nv;
+    for (int i = 0; i < p.nmaps; ++i) {
+        SSD_REQUIRE(tensors_[fmaps[i]].H == p.map_size[i], "feature map %d is %d, preset says %d", i, tensors_[fmaps[i]].H,
+                    p.map_size[i]);
+        const int co = round4(p.ntypes[i] * nv);
+        const int t = conv("heads/map" + std::to_string(i), co, 3, 1, PAD_SAME, 1, false, i, fmaps[i]);
+        head_t_.push_back(t);
+        heads_.hw[i] = p.map_size[i] * p.map_size[i];
+        heads_.nj[i] = p.ntypes[i];
+        heads_.ld[i] = co;
+        heads_.off[i] = p.off[i];
+    }
+    heads_.off[p.nmaps] = p.off[p.nmaps];
+
+    // ---- arena layout: all filters (forward order), all biases, the l2-norm scale ----
+    size_t off = 0;
+    for (auto& op : ops_)
+        if (op.kind == OP_CONV) {
+            op.w_off = off;
+            off += (size_t)op.KH * op.KW * tensors_[op.in].C * tensors_[op.out].C;
+        }
+    nfilters_ = off;
+    for (auto& op : ops_)
+        if (op.kind == OP_CONV) {
+            op.b_off = off;
+            off += tensors_[op.out].C;
+        }
+    scale_off_ = off;
+    off += 512;
+    nparams_ = off;
+
+    // ---- variables under the reference's names ------------------------------------------
+    auto add_var = [&](const std::string& n, int nd, int s0, int s1, int s2, int s3, size_t o, size_t rows, size_t width,
+                       size_t pitch) {
+        Variable v;
+        v.name = n; v.ndim = nd; v.shape[0] = s0; v.shape[1] = s1; v.shape[2] = s2; v.shape[3] = s3;
+        v.off = o; v.rows = rows; v.width = width; v.pitch = pitch;
+        vars_.push_back(v);
+    };
+    for (auto& op : ops_) {
+        if (op.kind != OP_CONV) continue;
+        const int ci = tensors_[op.in].C, co = tensors_[op.out].C;
+        if (op.head < 0) {
+            const size_t n = (size_t)op.KH * op.KW * ci * co;
+            add_var(op.name + "/filter", 4, op.KH, op.KW, ci, co, op.w_off, 1, n, n);
+            add_var(op.name + "/biases", 1, co, 0, 0, 0, op.b_off, 1, co, co);
+        } else {
+            for (int j = 0; j < p.ntypes[op.head]; ++j) {
+                const std::string base = "classifiers/classifier" + std::to_string(op.head) + "_" + std::to_string(j);
+                add_var(base + "/filter", 4, 3, 3, ci, nv, op.w_off + (size_t)j * nv, (size_t)9 * ci, nv, co);
+                add_var(base + "/biases", 1, nv, 0, 0, 0, op.b_off + (size_t)j * nv, 1, nv, nv);
+            }
+        }
+    }
+    add_var("l2_norm_conv4_3/scale", 1, 512, 0, 0, 0, scale_off_, 1, 512, 512);
+}
+
+size_t Net::arena_floats(const char* preset, int num_classes) {
+    // cheap: build the graph description only
+    const Preset& p = get_preset(preset);
+    const int nv = num_classes + 5;
+    size_t n = 0;
+    auto cv = [&](int k, int ci, int co) { n += (size_t)k * k * ci * co + co; };
+    cv(3, 3, 64); cv(3, 64, 64); cv(3, 64, 128); cv(3, 128, 128); cv(3, 128, 256); cv(3, 256, 256); cv(3, 256, 256);
+    cv(3, 256, 512); cv(3, 512, 512); cv(3, 512, 512); cv(3, 512, 512); cv(3, 512, 512); cv(3, 512, 512);
+    cv(3, 512, 1024); cv(1, 1024, 1024);
+    cv(1, 1024, 256); cv(3, 256, 512); cv(1, 512, 128); cv(3, 128, 256); cv(1, 256, 128); cv(3, 128, 256);
+    cv(1, 256, 128); cv(3, 128, 256);
+    if (p.nmaps >= 7) { cv(1, 256, 128); cv(3, 128, 256); }
+    static const int fch[] = {512, 1024, 512, 256, 256, 256, 256};
+    for (int i = 0; i < p.nmaps; ++i) cv(3, fch[i], round4(p.ntypes[i] * nv));
+    return n + 512;
+}
+
+// ---------------------------------------------------------------------------------
+// memory
+// ---------------------------------------------------------------------------------
+void* Net::dalloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_OK(hipMalloc(&p, bytes));
+    allocs_.push_back(p);
+    return p;
+}
+
+ConvDesc Net::conv_desc(const Op& op, int b) const {
+    const Tensor& in = tensors_[op.in];
+    const Tensor& out = tensors_[op.out];
+    ConvDesc d;
+    d.B = b; d.Hi = in.H; d.Wi = in.W; d.Ci = in.C; d.Ho = out.H; d.Wo = out.W; d.Co = out.C;
+    d.KH = op.KH; d.KW = op.KW; d.stride = op.stride; d.dil = op.dil; d.pad_h = op.pad_h; d.pad_w = op.pad_w;
+    return d;
+}
+
+void Net::alloc() {
+    const int B = Bmax_;
+    const int nv = C_ + 5;
+    const int A = preset_->num_anchors;
+    for (size_t i = 0; i < tensors_.size(); ++i) {
+        Tensor& t = tensors_[i];
+        if ((int)i == input_t_) continue;
+        t.data = (float*)dalloc(t.per_image() * B * sizeof(float));
+        if (training_) {
+            t.grad = (float*)dalloc(t.per_image() * B * sizeof(float));
+            HIP_OK(hipMemset(t.grad, 0, t.per_image() * B * sizeof(float)));   // head pad columns stay 0 forever
+        }
+    }
+    for (int i = 0; i < heads_.nmaps; ++i) {
+        heads_.buf[i] = tensors_[head_t_[i]].data;
+        heads_.dbuf[i] = tensors_[head_t_[i]].grad;
+    }
+    if (!params_) { params_ = (float*)dalloc(nparams_ * sizeof(float)); own_params_ = true; }
+    if (training_) {
+        if (!grads_) { grads_ = (float*)dalloc(nparams_ * sizeof(float)); own_grads_ = true; }
+        if (!mom_) { mom_ = (float*)dalloc(nparams_ * sizeof(float)); own_mom_ = true; }
+        HIP_OK(hipMemset(grads_, 0, nparams_ * sizeof(float)));
+        HIP_OK(hipMemset(mom_, 0, nparams_ * sizeof(float)));
+        size_t ws = 0;
+        for (auto& op : ops_)
+            if (op.kind == OP_CONV)
+                for (int b : {1, B}) ws = std::max(ws, conv_wgrad_ws_floats(conv_desc(op, b)));
+        wgrad_ws_ = (float*)dalloc(ws * sizeof(float));
+        l2_ws_ = (float*)dalloc(l2norm_bwd_ws_floats(B * 64 * 64, 512) * sizeof(float));
+    }
+    result_ = (float*)dalloc((size_t)B * A * nv * sizeof(float));
+    x_stage_ = (float*)dalloc((size_t)B * preset_->image_h * preset_->image_w * 3 * sizeof(float));
+    y_stage_ = (float*)dalloc((size_t)B * A * nv * sizeof(float));
+    loss_ws_ = dalloc(loss_work_bytes(B, A));
+    loss_work_carve(lw_, loss_ws_, B, A);
+    HIP_OK(hipMemset(loss_ws_, 0, loss_work_bytes(B, A)));
+    HIP_OK(hipHostMalloc((void**)&losses_host_, 4 * sizeof(float)));
+    for (int i = 0; i < 4; ++i) losses_host_[i] = 0.f;
+    anchors_dev_ = (double*)dalloc((size_t)A * 4 * sizeof(double));
+    anchors_abs_dev_ = (int*)dalloc((size_t)A * 4 * sizeof(int));
+    anchors_device(*preset_, anchors_dev_, anchors_abs_dev_, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+}
+
+// splitmix64 -> uniform [0,1)
+static inline double urand(unsigned long long& s) {
+    unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+void Net::init_weights(unsigned long long seed) {
+    std::vector<float> h(nparams_, 0.f);
+    unsigned long long s = seed * 0x2545F4914F6CDD1Dull + 1;
+    for (const Variable& v : vars_) {
+        if (v.ndim == 4) {   // xavier_initializer (uniform): limit = sqrt(6 / (fan_in + fan_out)), ssdvgg.py:46
+            const double fan_in = (double)v.shape[0] * v.shape[1] * v.shape[2];
+            const double fan_out = (double)v.shape[0] * v.shape[1] * v.shape[3];
+            const double lim = std::sqrt(6.0 / (fan_in + fan_out));
+            for (size_t r = 0; r < v.rows; ++r)
+                for (size_t c = 0; c < v.width; ++c) h[v.off + r * v.pitch + c] = (float)((urand(s) * 2.0 - 1.0) * lim);
+        } else if (v.name == "l2_norm_conv4_3/scale") {
+            for (size_t c = 0; c < v.width; ++c) h[v.off + c] = 20.f;   // ssdvgg.py:336
+        }
+    }
+    HIP_OK(hipMemcpy(params_, h.data(), nparams_ * sizeof(float), hipMemcpyHostToDevice));
+}
+
+Net::Net(const char* preset, int num_classes, int max_batch, int device, bool training, unsigned long long seed,
+         float* ext_params, float* ext_grads, float* ext_momentum)
+    : preset_(&get_preset(preset)), C_(num_classes), Bmax_(max_batch), device_(device), training_(training) {
+    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27 (got %d)", num_classes);
+    SSD_REQUIRE(max_batch >= 1, "max_batch must be >= 1");
+    HIP_OK(hipSetDevice(device));
+    params_ = ext_params; grads_ = ext_grads; mom_ = ext_momentum;
+    build_graph();
+    alloc();
+    init_weights(seed);
+}
+
+Net::~Net() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (void* p : allocs_) (void)hipFree(p);
+    if (losses_host_) (void)hipHostFree(losses_host_);
+}
+
+// ---------------------------------------------------------------------------------
+// steps
+// ---------------------------------------------------------------------------------
+void Net::forward(const float* x, int b, bool train_mode, const float* y) {
+    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
+    tensors_[input_t_].data = const_cast<float*>(x);
+    for (const Op& op : ops_) {
+        const Tensor& in = tensors_[op.in];
+        const Tensor& out = tensors_[op.out];
+        switch (op.kind) {
+        case OP_CONV:
+            conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, stream_);
+            break;
+        case OP_POOL: {
+            PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+            maxpool_fwd(d, in.data, out.data, stream_);
+            break;
+        }
+        case OP_L2NORM:
+            l2norm_fwd(b * in.H * in.W, in.C, in.data, params_ + scale_off_, out.data, stream_);
+            break;
+        }
+    }
+    if (train_mode) {
+        multibox_loss(heads_, b, result_, y, lw_, params_, nfilters_, wd_, stream_);
+        HIP_OK(hipMemcpyAsync(losses_host_, lw_.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    } else {
+        heads_result(heads_, b, result_, stream_);
+    }
+}
+
+void Net::backward(int b, const float* y) {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
+    for (Tensor& t : tensors_) t.done = 0;
+    for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
+        const Op& op = ops_[oi];
+        Tensor& in = tensors_[op.in];
+        const Tensor& out = tensors_[op.out];
+        const bool need_dx = op.in != input_t_;
+        const bool last = in.done + 1 == in.consumers;
+        switch (op.kind) {
+        case OP_CONV: {
+            const ConvDesc d = conv_desc(op, b);
+            conv_wgrad(d, in.data, out.grad, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, stream_);
+            if (need_dx)
+                conv_dgrad(d, out.grad, params_ + op.w_off, in.grad, (last && in.relu_out) ? in.data : nullptr, in.done > 0,
+                           stream_);
+            break;
+        }
+        case OP_POOL: {
+            PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+            maxpool_bwd(d, in.data, out.grad, in.grad, in.done > 0, last && in.relu_out, stream_);
+            break;
+        }
+        case OP_L2NORM:
+            SSD_REQUIRE(in.done == 0 && !last, "l2norm backward must be the first of several consumers");
+            l2norm_bwd(b * in.H * in.W, in.C, in.data, params_ + scale_off_, out.grad, in.grad, grads_ + scale_off_, l2_ws_,
+                       stream_);
+            break;
+        }
+        in.done++;
+    }
+}
+
+float Net::current_lr() const {
+    for (size_t i = 0; i < lr_bounds_.size(); ++i)
+        if (global_step <= lr_bounds_[i]) return lr_values_[i];
+    return lr_values_[lr_bounds_.size()];
+}
+
+void Net::apply_gradients(float grad_scale) {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    momentum_update(params_, mom_, grads_, nparams_, current_lr(), momentum_, grad_scale, stream_);
+    ++global_step;
+}
+
+void Net::set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd) {
+    SSD_REQUIRE(n >= 1, "need at least one learning rate value");
+    lr_values_.assign(lr_values, lr_values + n);
+    lr_bounds_.assign(bounds, bounds + (n - 1));
+    momentum_ = momentum;
+    wd_ = wd;
+}
+
+void Net::upload_xy(const float* x, const float* y, int b) {
+    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
+    const size_t nx = (size_t)b * preset_->image_h * preset_->image_w * 3;
+    HIP_OK(hipMemcpyAsync(x_stage_, x, nx * sizeof(float), hipMemcpyHostToDevice, stream_));
+    if (y) {
+        const size_t ny = (size_t)b * preset_->num_anchors * (C_ + 5);
+        HIP_OK(hipMemcpyAsync(y_stage_, y, ny * sizeof(float), hipMemcpyHostToDevice, stream_));
+    }
+}
+
+void Net::get_losses(float out[4]) {
+    HIP_OK(hipStreamSynchronize(stream_));
+    for (int i = 0; i < 4; ++i) out[i] = losses_host_[i];
+}
+
+void Net::copy_result(float* out, int b) {
+    const size_t n = (size_t)b * preset_->num_anchors * (C_ + 5);
+    HIP_OK(hipMemcpyAsync(out, result_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------------
+// variables
+// ---------------------------------------------------------------------------------
+const Variable& Net::find_var(const char* name) const {
+    for (const Variable& v : vars_)
+        if (v.name == name) return v;
+    fail("no such variable: %s", name ? name : "(null)");
+    return vars_[0];
+}
+
+void Net::load_variable(const char* name, const float* host, size_t count, int which) {
+    const Variable& v = find_var(name);
+    SSD_REQUIRE(count == v.count(), "variable %s holds %zu floats, got %zu", name, v.count(), count);
+    float* base = which == 0 ? params_ : mom_;
+    SSD_REQUIRE(base != nullptr, "arena not allocated (training = 0?)");
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipMemcpy2D(base + v.off, v.pitch * sizeof(float), host, v.width * sizeof(float), v.width * sizeof(float), v.rows,
+                       hipMemcpyHostToDevice));
+}
+
+void Net::save_variable(const char* name, float* host, size_t count, int which) {
+    const Variable& v = find_var(name);
+    SSD_REQUIRE(count == v.count(), "variable %s holds %zu floats, got %zu", name, v.count(), count);
+    const float* base = which == 0 ? params_ : (which == 1 ? grads_ : mom_);
+    SSD_REQUIRE(base != nullptr, "arena not allocated (training = 0?)");
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipMemcpy2D(host, v.width * sizeof(float), base + v.off, v.pitch * sizeof(float), v.width * sizeof(float), v.rows,
+                       hipMemcpyDeviceToHost));
+}
+
+void Net::activation_shape(const char* name, int* H, int* W, int* C) const {
+    for (const Tensor& t : tensors_)
+        if (t.name == name) {
+            *H = t.H; *W = t.W; *C = t.C;
+            return;
+        }
+    fail("no such activation: %s", name ? name : "(null)");
+}
+
+void Net::activation(const char* name, int b, float* out, size_t count) {
+    for (const Tensor& t : tensors_) {
+        if (t.name != name || !t.data) continue;
+        SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name, t.per_image() * b, b,
+                    count);
+        HIP_OK(hipStreamSynchronize(stream_));
+        HIP_OK(hipMemcpy(out, t.data, count * sizeof(float), hipMemcpyDeviceToHost));
+        return;
+    }
+    fail("no such activation: %s", name ? name : "(null)");
+}
+
+// ---------------------------------------------------------------------------------
+// decode + NMS of the last result
+// ---------------------------------------------------------------------------------
+void Net::detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls,
+                      int* idx, int* box) {
+    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
+    SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
+    const int A = preset_->num_anchors;
+    if (!detect_ws_ || detect_ws_b_ < b) {
+        detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
+        detect_ws_b_ = Bmax_;
+    }
+    const size_t n = (size_t)b * out_cap;
+    char* o = (char*)dalloc(n * 4 * 7 + (size_t)b * 4 + 256);     // small, freed with the handle
+    DetectOut d;
+    d.count = (int*)o;
+    d.conf = (float*)(o + ((size_t)b * 4 + 255) / 256 * 256);
+    d.cls = (int*)(d.conf + n);
+    d.idx = d.cls + n;
+    d.box = d.idx + n;
+    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
+    HIP_OK(hipMemcpyAsync(count, d.count, (size_t)b * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(conf, d.conf, n * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(cls, d.cls, n * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(idx, d.idx, n * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(box, d.box, n * 16, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipFree(o));
+    allocs_.pop_back();
+}
+
+}  // namespace ssd

@@ -1,0 +1,64 @@
+// HBM-bound layers around the convolutions: pooling, L2 normalisation, the multibox
+// head assembly + loss, the optimizer.  Host interface (all pointers are device memory).
+#pragma once
+#include "common.h"
+
+namespace ssd {
+
+// ---- max pooling, NHWC, TF SAME semantics (padded cells never win) ---------------
+// Replaces the SavedModel's pool1-4 and tf.nn.max_pool at ssdvgg.py:234-236.
+struct PoolDesc {
+    int B, Hi, Wi, C, Ho, Wo, k, stride, pad_h, pad_w;
+};
+void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s);
+// dx[cell] = sum of dy over the windows whose FIRST maximum (scan order) is this cell.
+// accumulate: += existing dx first; relu_mask: zero where x <= 0 (x is a relu output).
+void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
+                 hipStream_t s);
+
+// ---- l2_normalization (ssdvgg.py:80-84): y = scale * x * rsqrt(max(sum_c x^2, 1e-12))
+void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s);
+size_t l2norm_bwd_ws_floats(int npix, int C);
+void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale,
+                float* ws, hipStream_t s);
+
+// ---- multibox heads: layout + softmax + loss (ssdvgg.py:353-372, 375-580) ----------
+constexpr int MAX_MAPS = 8;
+struct HeadLayout {
+    int nmaps, A, nvars;             // nvars = num_classes + 5
+    int hw[MAX_MAPS];                // cells per map
+    int nj[MAX_MAPS];                // box types per map
+    int ld[MAX_MAPS];                // row stride of the fused head buffer (nj*nvars rounded up to 4)
+    int off[MAX_MAPS + 1];           // first anchor of each map
+    float* buf[MAX_MAPS];            // [B*hw][ld] raw fused head conv outputs
+    float* dbuf[MAX_MAPS];           // same shape, gradients
+};
+// result[b][a][:] = (softmax(logits), loc) in the reference's anchor order
+// (map -> box type -> row -> col, ssdvgg.py:63,365 == ssdutils.py:104-116).
+void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s);
+
+struct LossWork {                    // per-step scratch, all device
+    float* ce;                       // [B][A] cross entropy
+    float* sl1;                      // [B][A] smooth-L1 summed over the 4 offsets
+    unsigned char* pos;              // [B][A] 1 = positive anchor
+    unsigned char* sel;              // [B][A] 1 = contributes to the confidence loss
+    float* sample;                   // [B][4]: conf_b, loc_b, weight_b (1/(pos_n*B) or 0), pos_n
+    float* partial;                  // [1024] sum-of-squares partials
+    float* losses;                   // [4] total, localization, confidence, l2
+};
+size_t loss_work_bytes(int B, int A);
+void loss_work_carve(LossWork& w, void* base, int B, int A);
+// Forward of the loss; labels [B][A][nvars] device.  result must hold heads_result's output.
+void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
+                   const float* filters, size_t nfilters, float weight_decay, hipStream_t s);
+// d(loss)/d(head outputs) written into L.dbuf (pad columns stay zero).
+void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
+                        hipStream_t s);
+
+// ---- MomentumOptimizer without Nesterov (ssdvgg.py:586-588): acc = m*acc + g; w -= lr*acc
+void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, float momentum, float gscale,
+                     hipStream_t s);
+
+void fill_zero(void* p, size_t bytes, hipStream_t s);
+
+}  // namespace ssd

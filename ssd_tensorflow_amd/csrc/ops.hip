@@ -1,0 +1,567 @@
+// HBM-bound layers of the SSD-VGG step for gfx950: pooling, L2 normalisation, the
+// multibox head assembly / softmax / hard-negative-mined loss, momentum update.
+// All reductions use a fixed order (no float atomics): results are run-to-run identical.
+#include "ops.h"
+
+namespace ssd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
+    size_t g = (n + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// =================================================================================
+// max pooling
+// =================================================================================
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolDesc d, const float* __restrict__ x, float* __restrict__ y) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * d.stride - d.pad_h, w0 = ow * d.stride - d.pad_w;
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+        for (int kh = 0; kh < d.k; ++kh) {
+            const int h = h0 + kh;
+            if ((unsigned)h >= (unsigned)d.Hi) continue;
+            for (int kw = 0; kw < d.k; ++kw) {
+                const int w = w0 + kw;
+                if ((unsigned)w >= (unsigned)d.Wi) continue;
+                const f32x4 v = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        st4(y + idx * 4, m);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const float* __restrict__ x,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          int accumulate, int relu_mask) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Hi * d.Wi * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int w = (int)(pix % d.Wi);
+        pix /= d.Wi;
+        const int h = (int)(pix % d.Hi);
+        const int b = (int)(pix / d.Hi);
+        const f32x4 self = ld4(x + idx * 4);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        int n = h + d.pad_h - d.k + 1;
+        const int oh_lo = n <= 0 ? 0 : (n + d.stride - 1) / d.stride;
+        const int oh_hi = min(d.Ho - 1, (h + d.pad_h) / d.stride);
+        n = w + d.pad_w - d.k + 1;
+        const int ow_lo = n <= 0 ? 0 : (n + d.stride - 1) / d.stride;
+        const int ow_hi = min(d.Wo - 1, (w + d.pad_w) / d.stride);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int h0 = oh * d.stride - d.pad_h, w0 = ow * d.stride - d.pad_w;
+                bool first[4] = {true, true, true, true};
+                for (int kh = 0; kh < d.k; ++kh) {
+                    const int hh = h0 + kh;
+                    if ((unsigned)hh >= (unsigned)d.Hi) continue;
+                    for (int kw = 0; kw < d.k; ++kw) {
+                        const int ww = w0 + kw;
+                        if ((unsigned)ww >= (unsigned)d.Wi) continue;
+                        if (hh == h && ww == w) continue;
+                        const bool before = hh < h || (hh == h && ww < w);
+                        const f32x4 v = ld4(x + (((size_t)b * d.Hi + hh) * d.Wi + ww) * d.C + c4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (before ? v[e] >= self[e] : v[e] > self[e]) first[e] = false;
+                    }
+                }
+                const f32x4 gy = ld4(dy + (((size_t)b * d.Ho + oh) * d.Wo + ow) * d.C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first[e]) g[e] += gy[e];
+            }
+        }
+        if (accumulate) g += ld4(dx + idx * 4);
+        if (relu_mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = self[e] > 0.f ? g[e] : 0.f;
+        }
+        st4(dx + idx * 4, g);
+    }
+}
+
+void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
+    SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
+    HIP_OK(hipGetLastError());
+}
+
+void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
+                 hipStream_t s) {
+    SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
+    const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
+                       (int)accumulate, (int)relu_mask);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// L2 normalisation over channels: one wave64 per pixel, each lane owns float4 chunks
+// =================================================================================
+constexpr int L2_MAXJ = 4;   // C <= 1024
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const float* __restrict__ x,
+                                                         const float* __restrict__ scale, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int pix = wave; pix < npix; pix += nwaves) {
+        f32x4 v[L2_MAXJ];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < L2_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < C) v[j] = ld4(x + (size_t)pix * C + c);
+            ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int j = 0; j < L2_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < C) st4(y + (size_t)pix * C + c, ld4(scale + c) * v[j] * r);
+        }
+    }
+}
+
+// dx = scale*dy*r - x * (sum_c scale*dy*x) * r^3  (when sum x^2 > eps; else the norm is the
+// constant sqrt(eps) and only the first term remains).  dscale partials per block -> ws.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const float* __restrict__ x,
+                                                         const float* __restrict__ scale, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ ws) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    f32x4 ds[L2_MAXJ];
+#pragma unroll
+    for (int j = 0; j < L2_MAXJ; ++j) ds[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pix = wave; pix < npix; pix += nwaves) {
+        f32x4 v[L2_MAXJ], g[L2_MAXJ], sc[L2_MAXJ];
+        float ss = 0.f, t = 0.f;
+#pragma unroll
+        for (int j = 0; j < L2_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            v[j] = g[j] = sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < C) {
+                v[j] = ld4(x + (size_t)pix * C + c);
+                g[j] = ld4(dy + (size_t)pix * C + c);
+                sc[j] = ld4(scale + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += v[j][e] * v[j][e];
+                t += sc[j][e] * g[j][e] * v[j][e];
+            }
+        }
+        ss = wave_sum(ss);
+        t = wave_sum(t);
+        const float r = rsqrtf(fmaxf(ss, 1e-12f));
+        const float k = ss > 1e-12f ? t * r * r * r : 0.f;
+#pragma unroll
+        for (int j = 0; j < L2_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < C) st4(dx + (size_t)pix * C + c, sc[j] * g[j] * r - v[j] * k);
+            ds[j] += g[j] * v[j] * r;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < L2_MAXJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wib][lane * 4 + 256 * j + e] = ds[j][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        ws[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+__global__ void colsum_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += ws[(size_t)r * C + c];
+    out[c] = s;
+}
+
+static int l2_blocks(int npix) {
+    int b = (npix + 3) / 4;
+    return b > 512 ? 512 : (b < 1 ? 1 : b);
+}
+
+void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s) {
+    SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
+    int b = (npix + 3) / 4;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(b), dim3(256), 0, s, npix, C, x, scale, y);
+    HIP_OK(hipGetLastError());
+}
+
+size_t l2norm_bwd_ws_floats(int npix, int C) { return (size_t)l2_blocks(npix) * C; }
+
+void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale,
+                float* ws, hipStream_t s) {
+    SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
+    const int nb = l2_blocks(npix);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nb, C, dscale);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// multibox heads: anchor a of image b lives in map i at (box type j, cell hw):
+//   a = off[i] + j*hw[i] + cell ;  source row (b*hw[i] + cell) of buf[i], columns j*nvars..
+// =================================================================================
+struct AnchorLoc {
+    int map, col0;
+    size_t row;
+};
+__device__ __forceinline__ AnchorLoc locate(const HeadLayout& L, int b, int a) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_MAPS; ++k)
+        if (k < L.nmaps && a >= L.off[k]) i = k;
+    const int al = a - L.off[i];
+    const int j = al / L.hw[i];
+    const int cell = al - j * L.hw[i];
+    AnchorLoc r;
+    r.map = i;
+    r.col0 = j * L.nvars;
+    r.row = (size_t)b * L.hw[i] + cell;
+    return r;
+}
+
+constexpr int MAXV = 32;   // nvars <= 32  (num_classes <= 27)
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void heads_kernel(HeadLayout L, int B, float* __restrict__ result,
+                                                    const float* __restrict__ labels, float* __restrict__ ce_out,
+                                                    float* __restrict__ sl1_out, unsigned char* __restrict__ pos_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * L.A) return;
+    const int b = idx / L.A, a = idx - b * L.A;
+    const AnchorLoc p = locate(L, b, a);
+    const float* src = L.buf[p.map] + p.row * L.ld[p.map] + p.col0;
+    const int nv = L.nvars, nc = nv - 4;
+    float z[MAXV];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        z[c] = c < nv ? src[c] : 0.f;
+        if (c < nc) m = fmaxf(m, z[c]);
+    }
+    // accurate expf/logf (not the fast intrinsics): softmax must match an fp32 reference
+    // to 1e-3 rel even for tiny probabilities
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c)
+        if (c < nc) se += expf(z[c] - m);
+    const float lse = m + logf(se);
+    float* out = result + (size_t)idx * nv;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c)
+        if (c < nv) out[c] = c < nc ? expf(z[c] - lse) : z[c];
+    if constexpr (TRAIN) {
+        const float* y = labels + (size_t)idx * nv;
+        float ce = 0.f, sl = 0.f;
+        const bool pos = y[nc - 1] == 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            if (c < nc) {
+                const float yc = y[c];
+                if (yc != 0.f) ce += yc * (lse - z[c]);
+            } else if (c < nv) {
+                const float d = z[c] - y[c];
+                const float ad = fabsf(d);
+                sl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+            }
+        }
+        ce_out[idx] = ce;
+        sl1_out[idx] = pos ? sl : 0.f;
+        pos_out[idx] = pos ? 1 : 0;
+    }
+}
+
+void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s) {
+    SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
+    const int total = B * L.A;
+    hipLaunchKernelGGL(heads_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, nullptr, nullptr,
+                       nullptr, nullptr);
+    HIP_OK(hipGetLastError());
+}
+
+// ---- per-sample: counts, sums, hard-negative selection (top-k by radix select) ------
+constexpr int LS_THREADS = 1024;
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < LS_THREADS / 64; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, const float* __restrict__ ce,
+                                                                 const float* __restrict__ sl1,
+                                                                 const unsigned char* __restrict__ pos,
+                                                                 unsigned char* __restrict__ sel,
+                                                                 float* __restrict__ sample) {
+    __shared__ float red[LS_THREADS / 64];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_k, sh_wtot[LS_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* cb = ce + (size_t)b * A;
+    const float* lb = sl1 + (size_t)b * A;
+    const unsigned char* pb = pos + (size_t)b * A;
+    unsigned char* sb = sel + (size_t)b * A;
+
+    float npos = 0.f, psum = 0.f, lsum = 0.f;
+    for (int a = tid; a < A; a += LS_THREADS) {
+        const bool p = pb[a];
+        npos += p ? 1.f : 0.f;
+        psum += p ? cb[a] : 0.f;
+        lsum += lb[a];
+    }
+    npos = block_sum_1024(npos, red);
+    psum = block_sum_1024(psum, red);
+    lsum = block_sum_1024(lsum, red);
+    const int pos_n = (int)npos;
+    const int neg_n = A - pos_n;
+    const int k = min(neg_n, 3 * pos_n);
+    if (pos_n == 0) {   // ssdvgg.py:513-516,552-555: the sample contributes exactly 0
+        for (int a = tid; a < A; a += LS_THREADS) sb[a] = 0;
+        if (tid == 0) {
+            sample[b * 4 + 0] = 0.f; sample[b * 4 + 1] = 0.f; sample[b * 4 + 2] = 0.f; sample[b * 4 + 3] = 0.f;
+        }
+        return;
+    }
+    // negatives[a] = pos ? 0 : ce  (ssdvgg.py:459); k-th largest by MSB-first radix select
+    // on the float bit pattern (values are >= 0, so bits order like the floats).
+    unsigned prefix = 0, kk = (unsigned)k;   // kk-th largest among entries matching prefix
+    if (k > 0) {
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int a = tid; a < A; a += LS_THREADS) {
+                const unsigned u = pb[a] ? 0u : __float_as_uint(cb[a]);
+                if ((u & himask) == (prefix & himask)) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned acc = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) {
+                    if (acc + hist[bin] >= kk) break;
+                    acc += hist[bin];
+                }
+                sh_prefix = prefix | ((unsigned)bin << shift);
+                sh_k = kk - acc;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            kk = sh_k;
+        }
+    }
+    // prefix = bit pattern of the threshold T; kk = how many entries == T are taken
+    const float T = __uint_as_float(prefix);
+    float tsum = 0.f;
+    for (int a = tid; a < A; a += LS_THREADS) {
+        const float v = pb[a] ? 0.f : cb[a];
+        if (k > 0 && v > T) tsum += v;
+    }
+    tsum = block_sum_1024(tsum, red);
+    if (k > 0) tsum += (float)kk * T;
+    // selection mask; ties at T go to the LOWER index first (tf.nn.top_k)
+    unsigned base = 0;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int a0 = 0; a0 < A; a0 += LS_THREADS) {
+        const int a = a0 + tid;
+        const bool in = a < A;
+        const bool p = in ? (bool)pb[a] : false;
+        const float v = in ? (p ? 0.f : cb[a]) : -1.f;
+        const bool eq = in && k > 0 && v == T;
+        const unsigned long long bal = __ballot(eq);
+        const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) sh_wtot[wv] = __popcll(bal);
+        __syncthreads();
+        unsigned wbase = base, tot = 0;
+#pragma unroll
+        for (int i = 0; i < LS_THREADS / 64; ++i) {
+            if (i < wv) wbase += sh_wtot[i];
+            tot += sh_wtot[i];
+        }
+        const bool take = k > 0 && (v > T || (eq && wbase + before < kk));
+        if (in) sb[a] = p ? 1 : (take ? 1 : 0);
+        base += tot;
+    }
+    if (tid == 0) {
+        sample[b * 4 + 0] = (psum + tsum) / (float)pos_n;
+        sample[b * 4 + 1] = lsum / (float)pos_n;
+        sample[b * 4 + 2] = 1.f / ((float)pos_n * (float)B);
+        sample[b * 4 + 3] = (float)pos_n;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ w, size_t n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = ld4(w + i * 4);
+        s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void loss_final_kernel(int B, const float* __restrict__ sample, const float* __restrict__ partial, int npartial,
+                                  float wd, float* __restrict__ losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float conf = 0.f, loc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        conf += sample[b * 4 + 0];
+        loc += sample[b * 4 + 1];
+    }
+    conf /= (float)B;
+    loc /= (float)B;
+    double ss = 0.0;
+    for (int i = 0; i < npartial; ++i) ss += (double)partial[i];
+    const float l2 = wd * (float)(0.5 * ss);
+    losses[0] = conf + loc + l2;
+    losses[1] = loc;
+    losses[2] = conf;
+    losses[3] = l2;
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+size_t loss_work_bytes(int B, int A) {
+    const size_t n = (size_t)B * A;
+    size_t bytes = 0;
+    bytes += n * 4 * 2;                       // ce, sl1
+    bytes += ((n + 15) / 16) * 16 * 2;        // pos, sel
+    bytes += (size_t)B * 4 * 4 + SUMSQ_BLOCKS * 4 + 64;
+    return bytes + 256;
+}
+
+void loss_work_carve(LossWork& w, void* base, int B, int A) {
+    const size_t n = (size_t)B * A;
+    char* p = (char*)base;
+    w.ce = (float*)p; p += n * 4;
+    w.sl1 = (float*)p; p += n * 4;
+    w.pos = (unsigned char*)p; p += ((n + 15) / 16) * 16;
+    w.sel = (unsigned char*)p; p += ((n + 15) / 16) * 16;
+    w.sample = (float*)p; p += (size_t)B * 4 * 4;
+    w.partial = (float*)p; p += SUMSQ_BLOCKS * 4;
+    w.losses = (float*)p;
+}
+
+void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
+                   const float* filters, size_t nfilters, float weight_decay, hipStream_t s) {
+    SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
+    const int total = B * L.A;
+    hipLaunchKernelGGL(heads_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, const_cast<float*>(result),
+                       labels, w.ce, w.sl1, w.pos);
+    hipLaunchKernelGGL(loss_sample_kernel, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, w.ce, w.sl1, w.pos, w.sel, w.sample);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, filters, nfilters, w.partial);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, B, w.sample, w.partial, SUMSQ_BLOCKS, weight_decay,
+                       w.losses);
+    HIP_OK(hipGetLastError());
+}
+
+// d/d(logits) = sel * (softmax - labels) * w_b ; d/d(loc) = pos * clip(loc - gt, -1, 1) * w_b,
+// w_b = 1 / (pos_n_b * B)  (reduce_mean over the batch of per-sample normalised sums).
+__global__ __launch_bounds__(256) void loss_grad_kernel(HeadLayout L, int B, const float* __restrict__ result,
+                                                        const float* __restrict__ labels,
+                                                        const unsigned char* __restrict__ pos,
+                                                        const unsigned char* __restrict__ sel,
+                                                        const float* __restrict__ sample) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * L.A) return;
+    const int b = idx / L.A, a = idx - b * L.A;
+    const AnchorLoc p = locate(L, b, a);
+    float* dst = L.dbuf[p.map] + p.row * L.ld[p.map] + p.col0;
+    const int nv = L.nvars, nc = nv - 4;
+    const float wb = sample[b * 4 + 2];
+    const bool isel = sel[idx], ipos = pos[idx];
+    const float* r = result + (size_t)idx * nv;
+    const float* y = labels + (size_t)idx * nv;
+    for (int c = 0; c < nc; ++c) dst[c] = isel ? (r[c] - y[c]) * wb : 0.f;
+    for (int c = nc; c < nv; ++c) {
+        float d = r[c] - y[c];
+        d = fminf(fmaxf(d, -1.f), 1.f);
+        dst[c] = ipos ? d * wb : 0.f;
+    }
+}
+
+void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
+                        hipStream_t s) {
+    const int total = B * L.A;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos, w.sel,
+                       w.sample);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// optimizer
+// =================================================================================
+__global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ w, float* __restrict__ acc,
+                                                       const float* __restrict__ g, size_t n4, float lr, float mom,
+                                                       float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = mom * ld4(acc + i * 4) + gscale * ld4(g + i * 4);
+        st4(acc + i * 4, a);
+        st4(w + i * 4, ld4(w + i * 4) - lr * a);
+    }
+}
+
+void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, float momentum, float gscale,
+                     hipStream_t s) {
+    SSD_REQUIRE(n % 4 == 0, "momentum: arena size must be a multiple of 4");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n / 4, 256, 256 * 16)), dim3(256), 0, s, w, acc, g, n / 4, lr,
+                       momentum, gscale);
+    HIP_OK(hipGetLastError());
+}
+
+void fill_zero(void* p, size_t bytes, hipStream_t s) { HIP_OK(hipMemsetAsync(p, 0, bytes, s)); }
+
+}  // namespace ssd

@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's ssdutils.py: same names, arguments and error
+behaviour; the arithmetic runs in libssdvgg_hip.so (HIP kernels on the MI355X).
+
+  SSD_PRESETS / get_preset_by_name   ssdutils.py:32-73
+  get_anchors_for_preset             ssdutils.py:76-117
+  anchors2array                      ssdutils.py:120-130
+  decode_boxes                       ssdutils.py:192-229
+  suppress_overlaps                  ssdutils.py:310-318
+plus the batched entry points the drivers use (detect_batch, encode_labels_batch).
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, np_ptr
+from .utils import Size, Point, Box, abs2prop
+
+SSDMap = namedtuple('SSDMap', ['size', 'scale', 'aspect_ratios'])
+SSDPreset = namedtuple('SSDPreset', ['name', 'image_size', 'maps', 'extra_scale', 'num_anchors'])
+Anchor = namedtuple('Anchor', ['center', 'size', 'x', 'y', 'scale', 'map'])
+
+_AR2 = [2, 0.5]
+_AR4 = [2, 3, 0.5, 1. / 3.]
+SSD_PRESETS = {
+    'vgg300': SSDPreset('vgg300', Size(300, 300),
+                        [SSDMap(Size(38, 38), 0.1, _AR2), SSDMap(Size(19, 19), 0.2, _AR4),
+                         SSDMap(Size(10, 10), 0.375, _AR4), SSDMap(Size(5, 5), 0.55, _AR4),
+                         SSDMap(Size(3, 3), 0.725, _AR2), SSDMap(Size(1, 1), 0.9, _AR2)], 1.075, 8732),
+    'vgg512': SSDPreset('vgg512', Size(512, 512),
+                        [SSDMap(Size(64, 64), 0.07, _AR2), SSDMap(Size(32, 32), 0.15, _AR4),
+                         SSDMap(Size(16, 16), 0.3, _AR4), SSDMap(Size(8, 8), 0.45, _AR4),
+                         SSDMap(Size(4, 4), 0.6, _AR4), SSDMap(Size(2, 2), 0.75, _AR2),
+                         SSDMap(Size(1, 1), 0.9, _AR2)], 1.05, 24564),
+}
+IMG1000 = Size(1000, 1000)
+_DEVICE = 0
+
+
+def set_device(device):
+    """GPU ordinal the free functions of this module run on (a handle-owning SSDVGG has its own)."""
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+def get_preset_by_name(pname):
+    if pname not in SSD_PRESETS:
+        raise RuntimeError('No such preset: ' + pname)
+    return SSD_PRESETS[pname]
+
+
+def _pname(preset):
+    return (preset if isinstance(preset, str) else preset.name).encode()
+
+
+def anchors_array(preset):
+    """[A,4] float64 (cx, cy, w, h) from the HIP anchor kernel."""
+    p = get_preset_by_name(preset if isinstance(preset, str) else preset.name)
+    out = np.empty((p.num_anchors, 4), np.float64)
+    check(lib.ssd_anchors(_pname(p), _DEVICE, np_ptr(out)))
+    return out
+
+
+def get_anchors_for_preset(preset):
+    """List of Anchor records in the reference's order (map -> box type -> row -> col)."""
+    arr = anchors_array(preset)
+    out = []
+    k = 0
+    for m, mp in enumerate(preset.maps):
+        fk = mp.size[0]
+        for _t in range(2 + len(mp.aspect_ratios)):
+            for j in range(fk):
+                for i in range(fk):
+                    a = arr[k]
+                    out.append(Anchor(Point(float(a[0]), float(a[1])), Size(float(a[2]), float(a[3])), i, j, mp.scale, m))
+                    k += 1
+    return out
+
+
+def anchors2array(anchors, img_size):
+    """[A,4] float64 (xmin, xmax, ymin, ymax) truncated ints.  The HIP kernel serves the
+    reference's only call (img_size == Size(1000, 1000), a full preset); anything else is
+    converted with the scalar helper."""
+    from .utils import prop2abs
+    if tuple(img_size) == (1000, 1000):
+        for p in SSD_PRESETS.values():
+            if len(anchors) == p.num_anchors:
+                out = np.empty((p.num_anchors, 4), np.int32)
+                check(lib.ssd_anchors_abs(_pname(p), _DEVICE, np_ptr(out)))
+                return out.astype(np.float64)
+    return np.array([prop2abs(a.center, a.size, img_size) for a in anchors], np.float64).reshape(-1, 4)
+
+
+def _preset_for(num_anchors):
+    for p in SSD_PRESETS.values():
+        if p.num_anchors == num_anchors:
+            return p
+    raise ValueError(f'no preset with {num_anchors} anchors')
+
+
+def detect_batch(pred, preset, confidence_threshold=0.01, detections_cap=200, max_out=None, nms=True, out_cap=None):
+    """decode_boxes (+ suppress_overlaps)[:max_out] for pred [b, A, C+5] on the GPU.
+    Returns a list (one per image) of dicts: conf f32 [n], cls i32 [n], idx i32 [n], box i32 [n,4]."""
+    pred = np.ascontiguousarray(pred, np.float32)
+    if pred.ndim == 2:
+        pred = pred[None]
+    b, A, nv = pred.shape
+    p = _preset_for(A) if preset is None else preset
+    if p.num_anchors != A:
+        raise ValueError(f'pred has {A} anchors, preset {p.name} has {p.num_anchors}')
+    cap = -1 if detections_cap is None else int(detections_cap)
+    mo = -1 if max_out is None else int(max_out)
+    if out_cap is None:
+        out_cap = A if cap < 0 else max(cap, 1)
+        if mo >= 0:
+            out_cap = max(min(out_cap, mo), 1)
+    count = np.zeros(b, np.int32)
+    conf = np.zeros((b, out_cap), np.float32)
+    cls = np.zeros((b, out_cap), np.int32)
+    idx = np.zeros((b, out_cap), np.int32)
+    box = np.zeros((b, out_cap, 4), np.int32)
+    check(lib.ssd_decode_nms(_pname(p), nv - 5, _DEVICE, np_ptr(pred), b, float(confidence_threshold), cap, mo, out_cap,
+                             1 if nms else 0, np_ptr(count), np_ptr(conf), np_ptr(cls), np_ptr(idx), np_ptr(box)))
+    out = []
+    for i in range(b):
+        n = min(int(count[i]), out_cap)
+        out.append(dict(conf=conf[i, :n], cls=cls[i, :n], idx=idx[i, :n], box=box[i, :n]))
+    return out
+
+
+def boxes_from_detection(det, lid2name={}):
+    """dict from detect_batch -> the reference's list of (confidence, Box)."""
+    res = []
+    for c, k, b in zip(det['conf'], det['cls'], det['box']):
+        center, size = abs2prop(int(b[0]), int(b[1]), int(b[2]), int(b[3]), IMG1000)
+        k = int(k)
+        res.append((np.float32(c), Box(lid2name.get(k), k, center, size)))
+    return res
+
+
+class DecodedBoxes(list):
+    """decode_boxes' list of (confidence, Box); remembers the prediction it came from so that
+    suppress_overlaps can run decode + NMS as ONE fused GPU pass instead of a second upload."""
+    source = None
+
+
+def decode_boxes(pred, anchors, confidence_threshold=0.01, lid2name={}, detections_cap=200):
+    """ssdutils.py:192-229 for one image.  `anchors` only selects the preset (its length).
+    pred is not modified (the reference clamps offsets > 100 in place)."""
+    pred = np.asarray(pred, np.float32)
+    p = _preset_for(len(anchors))
+    det = detect_batch(pred, p, confidence_threshold, detections_cap, None, nms=False)[0]
+    out = DecodedBoxes(boxes_from_detection(det, lid2name))
+    out.source = (pred, p, confidence_threshold, detections_cap, lid2name)
+    return out
+
+
+def suppress_overlaps(boxes):
+    """ssdutils.py:310-318.  Boxes from decode_boxes go back through the fused GPU
+    decode+NMS; any other list of (confidence, Box) has no GPU-resident source and is refused."""
+    src = getattr(boxes, 'source', None)
+    if src is None:
+        if len(boxes) == 0:
+            return []
+        raise RuntimeError('suppress_overlaps needs the list returned by decode_boxes '
+                           '(use detect_batch for raw predictions); there is no CPU fallback')
+    pred, p, thr, cap, lid2name = src
+    det = detect_batch(pred, p, thr, cap, None, nms=True)[0]
+    return boxes_from_detection(det, lid2name)
+
+
+def encode_labels_batch(preset, num_classes, gt_boxes_list, gt_cls_list):
+    """LabelCreatorTransform for a batch on the GPU: lists (one per image) of [n,4] float64
+    proportional (cx, cy, w, h) and [n] class ids -> [b, A, num_classes+5] float32."""
+    b = len(gt_boxes_list)
+    offs = np.zeros(b + 1, np.int32)
+    for i, g in enumerate(gt_boxes_list):
+        offs[i + 1] = offs[i] + len(g)
+    gt = np.concatenate([np.asarray(g, np.float64).reshape(-1, 4) for g in gt_boxes_list] + [np.zeros((0, 4))], 0)
+    cls = np.concatenate([np.asarray(c, np.int32).reshape(-1) for c in gt_cls_list] + [np.zeros((0,), np.int32)], 0)
+    gt = np.ascontiguousarray(gt, np.float64); cls = np.ascontiguousarray(cls, np.int32)
+    vec = np.empty((b, preset.num_anchors, num_classes + 5), np.float32)
+    check(lib.ssd_encode_labels(_pname(preset), int(num_classes), _DEVICE, np_ptr(gt), np_ptr(cls), np_ptr(offs), b, np_ptr(vec)))
+    return vec
