@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the SSD-VGG hot path on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one forward + multibox loss + backward + momentum update of `--preset` at
+`--batch` images per GPU on synthetic data resident in HBM: the workload of
+BASELINE.json configs[1] (vgg300, batch 32, fp32, one MI355X).  N > 1: one process per GPU,
+the batch is sharded (weak scaling, 32 images per GPU), gradients are all-reduced over
+RCCL/xGMI between backward and the update.
+
+Rank 0 prints ONE JSON line: images/s over the whole job, the roofline block of the
+dominant kernel (per-launch HIP events, on the launching stream, over the timed region) and
+the CPU baseline (the fp32 torch-CPU oracle timed on this host; rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic conv FLOPs per image (SURVEY.md 8d / BASELINE.md 3)
+FLOPS_FWD_BWD = {'vgg300': 187.93e9, 'vgg512': 540.34e9}
+FLOPS_FWD = {'vgg300': 62.75e9, 'vgg512': 180.42e9}
+PEAK_FP32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0           # GB/s spec
+
+
+def synth_gt(rng, b):
+    """n ~ U{1..5} boxes per image, w,h ~ U(0.1,0.6), inside the image."""
+    boxes, cls, offs = [], [], [0]
+    for _ in range(b):
+        n = int(rng.integers(1, 6))
+        w = rng.uniform(0.1, 0.6, n); h = rng.uniform(0.1, 0.6, n)
+        boxes.append(np.stack([rng.uniform(w / 2, 1 - w / 2), rng.uniform(h / 2, 1 - h / 2), w, h], 1))
+        cls.append(rng.integers(0, 20, n))
+        offs.append(offs[-1] + n)
+    return np.concatenate(boxes), np.concatenate(cls).astype(np.int32), np.array(offs, np.int32)
+
+
+def cpu_baseline(preset, seconds_hint=20):
+    """The fp32 CPU restatement (oracle/ssdvgg_ref.py: torch-CPU ops, every host core) on a
+    bounded sample of the same workload: full steps (fwd + loss + bwd + update) at batch 2."""
+    import torch
+    from oracle import boxes as ob, ssdvgg_ref as ref
+    p = ob.get_preset(preset)
+    m = ref.RefModel(preset, params=ref.init_params(p, 20, seed=42))
+    rng = np.random.default_rng(1234)
+    b = 2
+    x, y, _ = ref.synth_batch(rng, b, p)
+    m.train_step(x, y)                     # warm
+    t0 = time.perf_counter(); n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_hint and n < 8):
+        m.train_step(x, y); n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(n * b / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} full training steps at batch {b} ({preset}, fp32 torch-CPU restatement oracle/ssdvgg_ref.py)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--preset', default='vgg300')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ssd_tensorflow_amd._lib import lib, check
+    from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    b = args.batch
+    sess = Session(local)
+    net = SSDVGG(sess, args.preset)
+    training = args.mode == 'train'
+    net.build_from_vgg(None, 20, max_batch=b, training=training, seed=42)
+    if world > 1:      # identical replicas
+        dist.broadcast(net.params_flat, 0)
+    if training:
+        net.build_optimizer(learning_rate=0.00075, weight_decay=0.0005, momentum=0.9)
+    net.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # synthetic shard, generated on this rank, resident in HBM before the timed region
+    rng = np.random.default_rng(1234 + rank)
+    H, W = net.preset.image_size.h, net.preset.image_size.w
+    x = torch.from_numpy(rng.integers(0, 256, (b, H, W, 3)).astype(np.float32)).cuda()
+    A, nv = net.preset.num_anchors, 25
+    y = torch.empty((b, A, nv), dtype=torch.float32, device='cuda')
+    gt, cls, offs = synth_gt(rng, b)
+    check(lib.ssd_encode_labels_dev(args.preset.encode(), 20, local, gt.ctypes.data, cls.ctypes.data, offs.ctypes.data, b,
+                                    y.data_ptr(), None))
+    torch.cuda.synchronize()
+
+    def step():
+        if args.mode == 'train':
+            net.forward_backward_dev(x, y)
+            if world > 1:
+                dist.all_reduce(net.grads_flat)            # sum over ranks, RCCL over xGMI
+            net.apply_gradients_dev(1.0 / world)
+        elif args.mode == 'infer':
+            net.infer_dev(x)
+        else:
+            net.infer_dev(x)
+            net.detect_last(b, 0.5, None, 200)
+
+    for _ in range(args.warmup):
+        step()
+    use_events = not args.no_kernel_events
+    if use_events:
+        check(lib.ssd_profile_enable(net._h, 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    kernels = {}
+    if use_events:
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.ssd_profile_report(net._h, buf, len(buf)))
+        for line in buf.value.decode().strip().split('\n'):
+            if not line:
+                continue
+            k, cnt, ms, fl, by = line.split('\t')
+            kernels[k] = dict(launches=int(cnt), ms=float(ms), flops=float(fl), bytes=float(by))
+        check(lib.ssd_profile_enable(net._h, 0))
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]['ms'])
+            d = kernels[dom]
+            if d['flops'] > 0:
+                ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+                roofline = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA, unit='TFLOP/s',
+                                frac=round(ach / PEAK_FP32_MFMA, 4), traffic=None,
+                                launches_per_step=d['launches'] // args.steps,
+                                avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
+                                flops_per_launch=d['flops'] / d['launches'])
+            else:
+                ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+                roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM, unit='GB/s',
+                                frac=round(ach / PEAK_HBM, 4), traffic=None,
+                                launches_per_step=d['launches'] // args.steps,
+                                avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
+                                bytes_per_launch=d['bytes'] / d['launches'])
+
+    if rank == 0:
+        imgs = b * world * args.steps
+        value = imgs / dt
+        flops_img = FLOPS_FWD_BWD[args.preset] if args.mode == 'train' else FLOPS_FWD[args.preset]
+        out = {
+            'metric': 'images/sec (fwd+bwd) %s batch%d' % (args.preset, b) if args.mode == 'train'
+                      else 'images/sec (%s) %s batch%d' % (args.mode, args.preset, b),
+            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.preset} {args.mode} step, {b} images/GPU x {world} GPU, synthetic '
+                                   f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[1])',
+                       'global_batch': b * world, 'parallelism': f'dp{world}'},
+            'model_tflops': round(value * flops_img / 1e12, 2),
+            'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4),
+            'roofline': roofline,
+        }
+        if use_events:
+            tot = sum(k['ms'] for k in kernels.values())
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / args.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}
+            out['kernel_ms_sum_per_step'] = round(tot / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline and args.mode == 'train':
+            out['cpu_baseline'] = cpu_baseline(args.preset)
+        else:
+            out['cpu_baseline'] = None
+        if args.mode == 'train':
+            out['losses_last_step'] = net.get_losses()
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

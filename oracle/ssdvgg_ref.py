@@ -79,22 +79,65 @@ def param_shapes(preset, num_classes=20):
     return P
 
 
-def init_params(preset, num_classes=20, seed=42, bias_scale=0.0):
+def init_params(preset, num_classes=20, seed=42, bias_scale=0.0, alive=False):
     """Synthetic weights (no vgg.zip offline): Xavier-uniform filters
     (ssdvgg.py:46), zero biases (:47), scale = 20 (:336).  bias_scale > 0 draws
-    small random biases instead (parity tests want every term exercised)."""
+    small random biases instead.
+    alive=True is the PARITY-TEST initialisation: with plain Xavier weights and a
+    0..255 input the relu stack dies beyond mod_conv7 (every gradient there is exactly
+    0 and would test nothing), so: He-uniform filters, conv1_1 scaled by 1/100 for the
+    0..255 input, head filters by 0.05, small positive biases.  Every layer then keeps
+    ~50 % of its units active at O(1) magnitude."""
     rng = np.random.default_rng(seed)
     out = {}
     for name, shp in param_shapes(preset, num_classes).items():
         if name.endswith('/filter'):
             kh, kw, ci, co = shp
-            lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
-            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
+            if alive:
+                w = rng.uniform(-1, 1, shp) * math.sqrt(6.0 / (kh * kw * ci))
+                if name.startswith('conv1_1'):
+                    w /= 100.0
+                if name.startswith('classifiers'):
+                    w *= 0.05
+                out[name] = w.astype(np.float32)
+            else:
+                lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+                out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
         elif name.endswith('/scale'):
             out[name] = np.full(shp, 20.0, np.float32)
+        elif alive:
+            out[name] = rng.normal(0.02, 0.02, shp).astype(np.float32)
         else:
             out[name] = (rng.normal(0, bias_scale, shp) if bias_scale > 0 else np.zeros(shp)).astype(np.float32)
     return out
+
+
+def graph(preset):
+    """The layer graph as data, for layer-local checks: list of ops
+    ('conv', name, input, k, stride, padding, dilation) | ('pool', name, input, k, stride) |
+    ('l2norm', name, input) | ('head', map_index, input); tensors are named by the op that
+    produces them ('image_input' is the network input, heads produce 'head<i>')."""
+    ops = []
+    cur = 'image_input'
+    pi = 0
+    for l in VGG:
+        if l == 'pool':
+            pi += 1
+            ops.append(('pool', f'pool{pi}', cur, 2, 2)); cur = f'pool{pi}'
+        else:
+            ops.append(('conv', l[0], cur, 3, 1, 'SAME', 1)); cur = l[0]
+    ops.append(('pool', 'mod_pool5', cur, 3, 1)); cur = 'mod_pool5'
+    ops.append(('conv', 'mod_conv6', cur, 3, 1, 'SAME', 6)); cur = 'mod_conv6'
+    ops.append(('conv', 'mod_conv7', cur, 1, 1, 'SAME', 1)); cur = 'mod_conv7'
+    fmaps = ['norm_conv4_3', 'mod_conv7']
+    for (n, k, ci, co, s, p) in extra_layers(preset):
+        ops.append(('conv', n, cur, k, s, 'BR1' if n == 'conv12_2' else p, 1)); cur = n
+        if n.endswith('_2'):
+            fmaps.append(n)
+    ops.append(('l2norm', 'norm_conv4_3', 'conv4_3'))
+    for i in range(len(preset['maps'])):
+        ops.append(('head', i, fmaps[i]))
+    return ops
 
 
 # ----------------------------------------------------------------------------
@@ -145,6 +188,9 @@ def forward(params, x_nhwc, preset, num_classes=20, keep=None):
         y = F.relu(y) if relu else y
         if keep is not None:
             keep[name] = y.permute(0, 2, 3, 1)
+            if y.requires_grad:
+                y.retain_grad()
+                keep['raw:' + name] = y
         return y
 
     pi = 0

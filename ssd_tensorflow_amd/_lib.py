@@ -14,6 +14,17 @@ if not os.path.exists(LIB_PATH):
         f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
         f'or `make -C {os.path.join(_HERE, "csrc")}` (hipcc, gfx950). There is no CPU fallback.')
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+# libamdhip64.so.7) + HSA runtime.  Loading it FIRST makes this library's DT_NEEDED
+# libamdhip64.so.7 resolve to the copy torch uses, so device pointers, streams and the
+# device itself are shared.  (Loaded the other way round the process ends up with two HSA
+# runtimes and the second one sees no device.)  A pure C consumer without torch simply
+# gets /opt/rocm's runtime.
+try:
+    import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+except ImportError:     # pragma: no cover
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 p_f32 = C.POINTER(C.c_float)
@@ -67,6 +78,8 @@ SIGNATURES = {
     'ssd_get_losses': (i32, [handle, vp]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'ssd_profile_enable': (i32, [handle, i32]),
+    'ssd_profile_report': (i32, [handle, C.c_char_p, sz]),
     'ssd_activation_shape': (i32, [handle, cstr, p_i32, p_i32, p_i32]),
     'ssd_activation': (i32, [handle, cstr, i32, vp, sz]),
     'ssd_op_conv2d_fwd': (i32, [vp, vp, vp, vp] + [i32] * 14 + [vp]),

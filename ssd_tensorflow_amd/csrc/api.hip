@@ -14,6 +14,31 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 const char* get_error() { return g_err.c_str(); }
+
+thread_local Profiler* g_prof = nullptr;
+hipEvent_t Profiler::get() {
+    if (used == pool.size()) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    return pool[used++];
+}
+Profiler::~Profiler() {
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+}
+ProfScope::ProfScope(const char* kernel, double flops, double bytes, hipStream_t stream) : s(stream), active(false), idx(0) {
+    Profiler* p = g_prof;
+    if (!p || !p->on) return;
+    Profiler::Rec r{kernel, flops, bytes, p->get(), p->get()};
+    idx = p->recs.size();
+    p->recs.push_back(r);
+    active = true;
+    (void)hipEventRecord(r.e0, s);
+}
+ProfScope::~ProfScope() {
+    if (active && g_prof) (void)hipEventRecord(g_prof->recs[idx].e1, s);
+}
 }  // namespace ssd
 
 using namespace ssd;
@@ -374,6 +399,39 @@ int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, i
                     int* cls, int* idx, int* box) {
     API_BEGIN
     N(h).detect_last(b, conf_thr, cap, max_out, out_cap, nms != 0, count, conf, cls, idx, box);
+    API_END
+}
+
+int ssd_profile_enable(ssd_handle h, int on) {
+    API_BEGIN
+    N(h).profiler().on = on != 0;
+    N(h).profiler().reset();
+    API_END
+}
+
+// one line per kernel label: "label\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n"
+int ssd_profile_report(ssd_handle h, char* buf, size_t cap) {
+    API_BEGIN
+    Net& n = N(h);
+    HIP_OK(hipStreamSynchronize(n.stream()));
+    struct Agg { long long cnt = 0; double ms = 0, fl = 0, by = 0; };
+    std::map<std::string, Agg> agg;
+    for (const auto& r : n.profiler().recs) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        Agg& a = agg[r.kernel];
+        a.cnt++; a.ms += ms; a.fl += r.flops; a.by += r.bytes;
+    }
+    std::string out;
+    char line[256];
+    for (const auto& kv : agg) {
+        snprintf(line, sizeof line, "%s\t%lld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.cnt, kv.second.ms, kv.second.fl,
+                 kv.second.by);
+        out += line;
+    }
+    SSD_REQUIRE(buf && cap > out.size(), "report needs %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    n.profiler().reset();
     API_END
 }
 

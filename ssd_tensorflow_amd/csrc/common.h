@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <stdexcept>
+#include <vector>
 
 namespace ssd {
 
@@ -39,6 +40,33 @@ inline void fail(const char* fmt, ...) {
     } while (0)
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Per-launch timing with HIP events on the launching stream (bench.py's roofline block).
+// Off by default; a Net turns it on for its steps.  One record per kernel launch.
+struct Profiler {
+    struct Rec {
+        const char* kernel;
+        double flops, bytes;
+        hipEvent_t e0, e1;
+    };
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get();
+    void reset() { recs.clear(); used = 0; }
+    ~Profiler();
+};
+extern thread_local Profiler* g_prof;
+
+// RAII: records an event before and after the launches issued inside the scope.
+struct ProfScope {
+    hipStream_t s;
+    bool active;
+    size_t idx;
+    ProfScope(const char* kernel, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+};
 
 // TF SAME padding: pad_total = max((ceil(in/s)-1)*s + k_eff - in, 0); before = total/2.
 inline void tf_same(int in, int k, int s, int d, int* before, int* out) {

@@ -471,7 +471,7 @@ static void set_lds(K kern, size_t bytes) {
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
-static void launch_gather(GatherArgs& a, hipStream_t s) {
+static void launch_gather(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM * LDA + (MODE == MODE_FWD ? BK * BN : BN * LDA)) * sizeof(float);
     auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED>;
@@ -479,8 +479,16 @@ static void launch_gather(GatherArgs& a, hipStream_t s) {
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
+    ProfScope prof(label, flops, bytes, s);
     hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
+}
+
+// algorithmic work of one conv pass (forward, dgrad or wgrad alike): 2*M*N*K, and the bytes a
+// pass must move at least once (activations in + out, the filter)
+static double conv_flops(const ConvDesc& d) { return 2.0 * d.B * d.Ho * d.Wo * (double)d.Co * d.Ci * d.KH * d.KW; }
+static double conv_bytes(const ConvDesc& d) {
+    return 4.0 * ((double)d.B * d.Hi * d.Wi * d.Ci + (double)d.B * d.Ho * d.Wo * d.Co + (double)d.KH * d.KW * d.Ci * d.Co);
 }
 
 static void check_desc(const ConvDesc& d) {
@@ -505,12 +513,13 @@ void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bi
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const bool smallc = d.Ci % 4 != 0;
+    const double fl = conv_flops(d), by = conv_bytes(d);
     if (smallc) {
-        launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, s);
+        launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
     } else if (d.Co <= 64) {
-        launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, s);
+        launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, "conv_fwd_128x64", fl, by, s);
     } else {
-        launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, s);
+        launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, "conv_fwd_128x128", fl, by, s);
     }
 }
 
@@ -529,12 +538,13 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
             a.tap_dh[kh * d.KW + kw] = d.pad_h - kh * d.dil;
             a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
         }
+    const double fl = conv_flops(d), by = conv_bytes(d) + (mask ? 4.0 * d.B * d.Hi * d.Wi * d.Ci : 0.0);
     if (d.stride > 1) {
-        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, true>(a, s);
-        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, s);
+        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, true>(a, "conv_dgrad_strided_128x64", fl, by, s);
+        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
     } else {
-        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, s);
-        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, s);
+        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, "conv_dgrad_128x64", fl, by, s);
+        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, "conv_dgrad_128x128", fl, by, s);
     }
 }
 
@@ -573,12 +583,13 @@ size_t conv_wgrad_ws_floats(const ConvDesc& d) {
 }
 
 template <int WM, int WN, int TM, int TN, bool SMALLC>
-static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
+static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(32 * BKT + 32 * BNT) * sizeof(float);
     auto kern = conv_wgrad_kernel<WM, WN, TM, TN, SMALLC>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
+    ProfScope prof(label, flops, bytes, s);
     hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.tiles), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
@@ -597,15 +608,17 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
             a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
-    if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, s);
-    else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, s);
-    else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, s);
-    else launch_wgrad<2, 2, 2, 2, false>(a, pl, s);
+    const double fl = conv_flops(d), by = conv_bytes(d);
+    if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
+    else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, "conv_wgrad_64x64", fl, by, s);
+    else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, "conv_wgrad_64x128", fl, by, s);
+    else launch_wgrad<2, 2, 2, 2, false>(a, pl, "conv_wgrad_128x128", fl, by, s);
 
     const size_t wcount = (size_t)a.ntaps * d.Ci * d.Co;
     const size_t total = wcount + d.Co;
     int blocks = cdiv((long long)total, 256 * 4);
     if (blocks > 2048) blocks = 2048;
+    ProfScope prof("wgrad_reduce", 0.0, 4.0 * (double)total * (pl.nsplit + 2), s);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, pl.nsplit, wcount, d.Co, dw, dbias, w,
                        weight_decay);
     HIP_OK(hipGetLastError());

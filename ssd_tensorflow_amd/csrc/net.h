@@ -94,6 +94,7 @@ public:
     size_t nfilters() const { return nfilters_; }
     float* result() { return result_; }
     long long global_step = 0;
+    Profiler& profiler() { return prof_; }
 
 private:
     int add_tensor(const std::string& name, int H, int W, int C, bool relu_out);
@@ -137,6 +138,7 @@ private:
     std::vector<float> lr_values_{0.001f};
     std::vector<long long> lr_bounds_;
     float momentum_ = 0.9f, wd_ = 0.0005f;
+    Profiler prof_;
 };
 
 }  // namespace ssd

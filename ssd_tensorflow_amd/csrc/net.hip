@@ -285,6 +285,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
 }
 
 Net::~Net() {
+    if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (void* p : allocs_) (void)hipFree(p);
@@ -296,6 +297,7 @@ Net::~Net() {
 // ---------------------------------------------------------------------------------
 void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
+    g_prof = &prof_;
     tensors_[input_t_].data = const_cast<float*>(x);
     for (const Op& op : ops_) {
         const Tensor& in = tensors_[op.in];
@@ -324,6 +326,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
 
 void Net::backward(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
+    g_prof = &prof_;
     multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
     for (Tensor& t : tensors_) t.done = 0;
     for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
@@ -364,6 +367,7 @@ float Net::current_lr() const {
 
 void Net::apply_gradients(float grad_scale) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
+    g_prof = &prof_;
     momentum_update(params_, mom_, grads_, nparams_, current_lr(), momentum_, grad_scale, stream_);
     ++global_step;
 }
@@ -428,6 +432,7 @@ void Net::save_variable(const char* name, float* host, size_t count, int which) 
 }
 
 void Net::activation_shape(const char* name, int* H, int* W, int* C) const {
+    if (name && !strncmp(name, "grad:", 5)) name += 5;
     for (const Tensor& t : tensors_)
         if (t.name == name) {
             *H = t.H; *W = t.W; *C = t.C;
@@ -437,8 +442,19 @@ void Net::activation_shape(const char* name, int* H, int* W, int* C) const {
 }
 
 void Net::activation(const char* name, int b, float* out, size_t count) {
+    // "grad:<scope>" returns d(loss)/d(pre-activation) of that layer from the last backward
+    const bool want_grad = name && !strncmp(name, "grad:", 5);
+    if (want_grad) name += 5;
     for (const Tensor& t : tensors_) {
         if (t.name != name || !t.data) continue;
+        if (want_grad) {
+            SSD_REQUIRE(t.grad != nullptr, "no gradient storage (training = 0?)");
+            SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name,
+                        t.per_image() * b, b, count);
+            HIP_OK(hipStreamSynchronize(stream_));
+            HIP_OK(hipMemcpy(out, t.grad, count * sizeof(float), hipMemcpyDeviceToHost));
+            return;
+        }
         SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name, t.per_image() * b, b,
                     count);
         HIP_OK(hipStreamSynchronize(stream_));

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const floa
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+    ProfScope prof("maxpool_fwd", 0.0, 4.0 * d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
     HIP_OK(hipGetLastError());
 }
@@ -123,6 +124,7 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
                  hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
+    ProfScope prof("maxpool_bwd", 0.0, 4.0 * d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
                        (int)accumulate, (int)relu_mask);
     HIP_OK(hipGetLastError());
@@ -225,6 +227,7 @@ void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, h
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
     int b = (npix + 3) / 4;
     if (b > 4096) b = 4096;
+    ProfScope prof("l2norm_fwd", 0.0, 8.0 * npix * C, s);
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(b), dim3(256), 0, s, npix, C, x, scale, y);
     HIP_OK(hipGetLastError());
 }
@@ -235,6 +238,7 @@ void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float
                 float* ws, hipStream_t s) {
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
     const int nb = l2_blocks(npix);
+    ProfScope prof("l2norm_bwd", 0.0, 12.0 * npix * C, s);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nb, C, dscale);
     HIP_OK(hipGetLastError());
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadLayout L, int B, float* 
 void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     const int total = B * L.A;
+    ProfScope prof("heads_result", 0.0, 8.0 * total * L.nvars, s);
     hipLaunchKernelGGL(heads_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, nullptr, nullptr,
                        nullptr, nullptr);
     HIP_OK(hipGetLastError());
@@ -499,6 +504,7 @@ void multibox_loss(const HeadLayout& L, int B, const float* result, const float*
                    const float* filters, size_t nfilters, float weight_decay, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     const int total = B * L.A;
+    ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars + 4.0 * nfilters, s);
     hipLaunchKernelGGL(heads_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, const_cast<float*>(result),
                        labels, w.ce, w.sl1, w.pos);
     hipLaunchKernelGGL(loss_sample_kernel, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, w.ce, w.sl1, w.pos, w.sel, w.sample);
@@ -536,6 +542,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(HeadLayout L, int B, con
 void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s) {
     const int total = B * L.A;
+    ProfScope prof("multibox_loss_grad", 0.0, 12.0 * total * L.nvars, s);
     hipLaunchKernelGGL(loss_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos, w.sel,
                        w.sample);
     HIP_OK(hipGetLastError());
@@ -557,6 +564,7 @@ __global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ w, fl
 void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, float momentum, float gscale,
                      hipStream_t s) {
     SSD_REQUIRE(n % 4 == 0, "momentum: arena size must be a multiple of 4");
+    ProfScope prof("momentum_update", 0.0, 20.0 * n, s);
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n / 4, 256, 256 * 16)), dim3(256), 0, s, w, acc, g, n / 4, lr,
                        momentum, gscale);
     HIP_OK(hipGetLastError());

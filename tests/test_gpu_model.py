@@ -1,8 +1,16 @@
 """-m gpu: the whole SSD-VGG step (forward, loss, backward, momentum update) through the C ABI
 against the CPU oracle (oracle/ssdvgg_ref.py, parity unpinned w.r.t. TensorFlow: see its
-header).  Tolerance 1e-3 relative (BASELINE.json north_star)."""
+header).  Tolerance 1e-3 relative (BASELINE.json north_star).
+
+Backward parity is checked LAYER-LOCALLY: every op's backward is recomputed by the oracle
+from the GPU's own input activation and output gradient.  End-to-end gradients of a 30-layer
+relu/max-pool network are chaotic at the 1e-3 level (a max-pool argmax or relu mask flips
+wherever two fp32 values agree to ~1e-6, which a different summation order decides
+differently); the end-to-end comparison is therefore reported with a looser bound."""
 import numpy as np
 import pytest
+import torch
+import torch.nn.functional as F
 
 from oracle import boxes as ob
 from oracle import ssdvgg_ref as ref
@@ -11,11 +19,12 @@ from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session, LearningRate
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+WD = 0.0005
 
 
 def make_pair(pname, b, seed=42, training=True):
     preset = ob.get_preset(pname)
-    w = ref.init_params(preset, 20, seed=seed, bias_scale=0.01)
+    w = ref.init_params(preset, 20, seed=seed, alive=True)
     m = ref.RefModel(pname, params=w)
     sess = Session(0)
     net = SSDVGG(sess, pname)
@@ -24,81 +33,189 @@ def make_pair(pname, b, seed=42, training=True):
 
 
 def report(tag, e):
-    print(f'    {tag:<40s} {e:.3e}')
+    print(f'    {tag:<44s} {e:.3e}')
     return e
 
 
-def test_forward_loss_backward_vgg300():
+def nchw(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2)
+
+
+def head_out_from_buffers(net, preset, b, prefix=''):
+    """[b, A, 25] in anchor order from the fused head buffers 'head<i>' ([b,H,W,ld], columns j*25..)."""
+    parts = []
+    for i, (fk, s, ars) in enumerate(preset['maps']):
+        buf = net.activation(prefix + f'head{i}', b)
+        for j in range(2 + len(ars)):
+            parts.append(buf[..., j * 25:(j + 1) * 25].reshape(b, fk * fk, 25))
+    return np.concatenate(parts, 1)
+
+
+def layer_local_backward_check(net, m, preset, b, x, y):
+    """Every op's backward, recomputed by the oracle from the GPU's own tensors."""
+    g_gpu = net.save_gradients()
+    act = {'image_input': x}
+
+    def A(name):
+        if name not in act:
+            act[name] = net.activation(name, b)
+        return act[name]
+
+    def G(name):
+        return net.activation('grad:' + name, b)
+
+    ops = ref.graph(preset)
+    consumers = {}
+    for op in ops:
+        consumers.setdefault(op[2], []).append(op)
+    relu_out = {op[1] for op in ops if op[0] == 'conv'}
+    worst_w, worst_x = 0.0, 0.0
+
+    # loss gradient w.r.t. the head outputs, from the GPU's own head outputs
+    out_gpu = head_out_from_buffers(net, preset, b)
+    conf, loc, d_out, _ = ref.loss_numpy(out_gpu, y)
+    got = head_out_from_buffers(net, preset, b, 'grad:')
+    assert report('d(loss)/d(head outputs)', max_rel(got, d_out)) < TOL
+    for i in range(len(preset['maps'])):      # fused-buffer padding columns never receive gradient
+        gbuf = G(f'head{i}')
+        nj = 2 + len(preset['maps'][i][2])
+        assert not gbuf[..., nj * 25:].any()
+
+    for tname, cons in consumers.items():
+        a = nchw(A(tname)).clone().requires_grad_(tname != 'image_input')
+        for op in cons:
+            if op[0] == 'conv':
+                _, name, _, k, stride, padding, dil = op
+                w = m.params[name + '/filter'].detach().clone().requires_grad_(True)
+                bias = m.params[name + '/biases'].detach().clone().requires_grad_(True)
+                xin = F.pad(a, (0, 1, 0, 1)) if padding == 'BR1' else a
+                pre = ref.conv2d_tf(xin, w, stride, 'SAME' if padding == 'SAME' else 'VALID', dil) + bias.view(1, -1, 1, 1)
+                pre.backward(nchw(G(name)))
+                worst_w = max(worst_w, report('wgrad ' + name, rel_err(g_gpu[name + '/filter'], w.grad.numpy() + WD * w.detach().numpy())))
+                worst_w = max(worst_w, rel_err(g_gpu[name + '/biases'], bias.grad.numpy()))
+            elif op[0] == 'pool':
+                _, name, _, k, s = op
+                ref.maxpool_tf(a, k, s).backward(nchw(G(name)))
+            elif op[0] == 'l2norm':
+                sc = m.params['l2_norm_conv4_3/scale'].detach().clone().requires_grad_(True)
+                ref.l2norm_tf(a, sc).backward(nchw(G('norm_conv4_3')))
+                worst_w = max(worst_w, report('dscale', rel_err(g_gpu['l2_norm_conv4_3/scale'], sc.grad.numpy())))
+            elif op[0] == 'head':
+                i = op[1]
+                gbuf = G(f'head{i}')
+                for j in range(2 + len(preset['maps'][i][2])):
+                    n = f'classifiers/classifier{i}_{j}'
+                    w = m.params[n + '/filter'].detach().clone().requires_grad_(True)
+                    bias = m.params[n + '/biases'].detach().clone().requires_grad_(True)
+                    pre = ref.conv2d_tf(a, w) + bias.view(1, -1, 1, 1)
+                    pre.backward(nchw(gbuf[..., j * 25:(j + 1) * 25]))
+                    worst_w = max(worst_w, rel_err(g_gpu[n + '/filter'], w.grad.numpy() + WD * w.detach().numpy()))
+                    worst_w = max(worst_w, rel_err(g_gpu[n + '/biases'], bias.grad.numpy()))
+        if tname == 'image_input':
+            continue
+        want = a.grad
+        if tname in relu_out:
+            want = want * (a > 0).float()
+        e = max_rel(G(tname), want.permute(0, 2, 3, 1).numpy())
+        worst_x = max(worst_x, report('dgrad into ' + tname, e))
+    return worst_w, worst_x
+
+
+def test_step_vgg300():
     b = 2
     preset, m, sess, net = make_pair('vgg300', b)
     rng = np.random.default_rng(1234)
     x, y, _ = ref.synth_batch(rng, b, preset)
-    m.set_optimizer([0.001], [], 0.9, 0.0005)
-    net.build_optimizer(learning_rate=0.001, weight_decay=0.0005, momentum=0.9)
+    y[1, :, :] = y[0, :, :]                # make the two samples' positive counts differ from B=1 tests
+    y[1, 4000:, :20] = 0; y[1, 4000:, 20] = 1; y[1, 4000:, 21:] = 0
+    m.set_optimizer([0.001], [], 0.9, WD)
+    net.build_optimizer(learning_rate=0.001, weight_decay=WD, momentum=0.9)
 
+    # ---- forward: every activation, result, the four losses ----------------------------------
     keep = {}
     r_ref, L_ref = m.eval_step(x, y, keep)
     r, L = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
     worst = 0
-    for name in ['conv1_1', 'conv1_2', 'pool1', 'conv2_2', 'conv3_3', 'pool3', 'conv4_3', 'norm_conv4_3', 'conv5_3',
-                 'mod_pool5', 'mod_conv6', 'mod_conv7', 'conv8_2', 'conv9_2', 'conv10_2', 'conv11_2']:
-        worst = max(worst, report('activation ' + name, max_rel(net.activation(name, b), keep[name].numpy())))
+    for name in [k for k in keep if not k.startswith('raw:')]:
+        got = net.activation(name, b)
+        assert np.count_nonzero(got) > 0.2 * got.size, f'{name} is (nearly) dead: the test would prove nothing'
+        worst = max(worst, report('activation ' + name, max_rel(got, keep[name].numpy())))
     assert worst < TOL
     assert report('result', max_rel(r, r_ref)) < TOL
     for k in ('total', 'localization', 'confidence', 'l2'):
         assert abs(L[k] - L_ref[k]) < TOL * abs(L_ref[k]), (k, L[k], L_ref[k])
 
-    # gradients of every variable
-    _, _, g_ref = m.grads(x, y)
-    import torch
+    # ---- backward, layer-local --------------------------------------------------------------
     xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
     net.forward_backward_dev(xt, yt)
     torch.cuda.synchronize()
+    worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y)
+    print('    worst layer-local weight-gradient error', worst_w, ' data-gradient error', worst_x)
+    assert worst_w < TOL and worst_x < TOL
+
+    # ---- backward, end to end (chaotic at 1e-3: see module docstring) -----------------------
+    _, _, g_ref = m.grads(x, y)
     g = net.save_gradients()
     assert set(g) == set(g_ref)
-    worst = 0
-    for k in g_ref:
-        e = rel_err(g[k], g_ref[k])
-        if e > 1e-4:
-            report('grad ' + k, e)
-        worst = max(worst, e)
-    print('    worst gradient rel-L2 error', worst)
-    assert worst < TOL
+    worst = max(rel_err(g[k], g_ref[k]) for k in g_ref)
+    report('end-to-end worst gradient rel-L2', worst)
+    assert worst < 3e-2
+    heads_and_extras = [k for k in g_ref if k.startswith(('classifiers', 'conv8', 'conv9', 'conv10', 'conv11', 'mod_conv'))]
+    assert max(rel_err(g[k], g_ref[k]) for k in heads_and_extras) < TOL      # nothing chaotic above mod_pool5
 
-    # two optimizer steps (momentum carries over); weights must track the oracle
-    for step in range(2):
-        m.train_step(x, y)
-        _, Ls = sess.run([net.result, net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})[:2]
+    # ---- two optimizer steps from identical gradients: momentum, lr, global_step ------------
+    w0 = net.save_variables()
+    net.apply_gradients_dev(1.0)
+    w1 = net.save_variables(); mom = net.save_momentum()
+    for k in w0:
+        assert np.allclose(mom[k], g[k], rtol=1e-6, atol=1e-12)
+        assert np.allclose(w1[k], w0[k] - np.float32(0.001) * g[k], rtol=1e-6, atol=1e-9)
+    net.apply_gradients_dev(1.0)           # same gradient arena again: acc = 0.9*g + g
+    w2 = net.save_variables()
+    for k in ('conv4_2/filter', 'classifiers/classifier1_3/biases', 'l2_norm_conv4_3/scale'):
+        assert np.allclose(w2[k], w1[k] - np.float32(0.001) * (np.float32(0.9) * g[k] + g[k]), rtol=1e-5, atol=1e-9)
     assert net.global_step == 2
-    w_ref = m.numpy_params(); w = net.save_variables()
-    worst = max(rel_err(w[k], w_ref[k]) for k in w_ref)
-    assert report('weights after 2 steps', worst) < 1e-5
-    # the update must have moved them by lr * accumulated gradient, not by nothing
-    k = 'conv4_2/filter'
-    w0 = ref.init_params(preset, 20, seed=42, bias_scale=0.01)[k]
-    assert np.abs(w[k] - w0).max() > 0
     sess.close()
 
 
-def test_forward_loss_vgg512_b1():
+def test_train_steps_track_oracle():
+    """sess.run([result, losses, optimizer]) twice; weights stay on the oracle's trajectory."""
+    b = 1
+    preset, m, sess, net = make_pair('vgg300', b, seed=7)
+    rng = np.random.default_rng(21)
+    x, y, _ = ref.synth_batch(rng, b, preset)
+    lr = LearningRate([0.001, 0.0001], [0])            # step 0 uses 0.001, step 1 uses 0.0001
+    m.set_optimizer(lr.values, lr.boundaries, 0.9, WD)
+    net.build_optimizer(learning_rate=lr, weight_decay=WD, momentum=0.9)
+    for step in range(2):
+        _, L_ref = m.train_step(x, y)
+        r, L, _ = sess.run([net.result, net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+        assert abs(L['total'] - L_ref['total']) < TOL * abs(L_ref['total'])
+    w_ref = m.numpy_params(); w = net.save_variables()
+    # weights move by lr*grad ~ 1e-3 * O(1e-2): a relative error of the UPDATE of a few 1e-2
+    # (chaotic end-to-end gradient) is ~1e-6 of the weight itself
+    assert report('weights after 2 steps', max(rel_err(w[k], w_ref[k]) for k in w_ref)) < 1e-4
+    assert net.global_step == 2
+    sess.close()
+
+
+def test_step_vgg512_b1():
     b = 1
     preset, m, sess, net = make_pair('vgg512', b)
     rng = np.random.default_rng(77)
     x, y, _ = ref.synth_batch(rng, b, preset)
     net.build_optimizer(learning_rate=0.001)
-    m.set_optimizer([0.001], [], 0.9, 0.0005)
-    r_ref, L_ref, g_ref = m.grads(x, y)
+    m.set_optimizer([0.001], [], 0.9, WD)
+    r_ref, L_ref = m.eval_step(x, y)
     r, L = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
     assert r.shape == (1, 24564, 25)
     assert report('vgg512 result', max_rel(r, r_ref)) < TOL
     for k in L_ref:
         assert abs(L[k] - L_ref[k]) < TOL * abs(L_ref[k]), (k, L[k], L_ref[k])
-    import torch
     net.forward_backward_dev(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
     torch.cuda.synchronize()
-    g = net.save_gradients()
-    worst = max(rel_err(g[k], g_ref[k]) for k in g_ref)
-    assert report('vgg512 worst gradient', worst) < TOL
+    worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y)
+    assert worst_w < TOL and worst_x < TOL
     sess.close()
 
 
@@ -109,11 +226,15 @@ def test_ragged_last_batch_and_no_positive_sample():
     x, y, _ = ref.synth_batch(rng, 3, preset)
     y[1] = 0; y[1, :, 20] = 1
     net.build_optimizer(learning_rate=0.001)
-    r_ref, L_ref, g_ref = m.grads(x, y)
+    r_ref, L_ref = m.eval_step(x, y)
     r, L = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
     assert r.shape[0] == 3 and max_rel(r, r_ref) < TOL
     for k in L_ref:
         assert abs(L[k] - L_ref[k]) < TOL * abs(L_ref[k]), (k, L[k], L_ref[k])
+    net.forward_backward_dev(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    got = head_out_from_buffers(net, preset, 3, 'grad:')
+    assert not got[1].any(), 'a sample without positives must contribute no gradient'
     sess.close()
 
 
@@ -129,8 +250,30 @@ def test_infer_and_detect_last_matches_oracle_boxes():
     oa = ob.anchors(preset)
     for i in range(2):
         want = ob.detect(r[i], oa, thr, None, 200)
+        assert len(want['idx']) > 0
         assert np.array_equal(dets[i]['idx'], want['idx']) and np.array_equal(dets[i]['box'], want['box'])
     sess.close()
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    preset, m, sess, net = make_pair('vgg300', 1)
+    net.build_optimizer(learning_rate=LearningRate([0.001, 0.0001], [5]), weight_decay=WD, momentum=0.9)
+    rng = np.random.default_rng(3)
+    x, y, _ = ref.synth_batch(rng, 1, preset)
+    sess.run([net.result, net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+    path = str(tmp_path / 'e1.npz')
+    net.save_checkpoint(path, LearningRate([0.001, 0.0001], [5]), 0.9, WD)
+    r1, L1, _ = sess.run([net.result, net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+    sess2 = Session(0)
+    net2 = SSDVGG(sess2, 'vgg300')
+    net2.build_from_metagraph(None, path, max_batch=1, training=True)
+    net2.build_optimizer_from_metagraph()
+    assert net2.global_step == 1
+    r2, L2, _ = sess2.run([net2.result, net2.losses, net2.optimizer], feed_dict={net2.image_input: x, net2.labels: y})
+    assert np.array_equal(r1, r2) and L1 == L2, 'a restored net must continue bit-identically'
+    w1 = net.save_variables(); w2 = net2.save_variables()
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    sess.close(); sess2.close()
 
 
 def test_shape_and_dtype_errors():
@@ -143,6 +286,8 @@ def test_shape_and_dtype_errors():
         net.infer(np.zeros((2, 300, 300, 3), np.float32))      # beyond max_batch
     with pytest.raises(RuntimeError):
         net.build_optimizer()                                    # inference-only handle
+    with pytest.raises(RuntimeError, match='no such variable'):
+        net.load_variables({'conv99/filter': np.zeros((3, 3, 3, 3), np.float32)})
     sess.close()
     with pytest.raises(RuntimeError, match='No such preset'):
         SSDVGG(None, 'vgg999')
