@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
     args = ap.parse_args()
 
@@ -130,7 +131,7 @@ def main():
         step()
     use_events = not args.no_kernel_events
     if use_events:
-        check(lib.ssd_profile_enable(net._h, 1))
+        check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -157,7 +158,14 @@ def main():
             if not line:
                 continue
             k, cnt, ms, fl, by = line.split('\t')
-            kernels[k] = dict(launches=int(cnt), ms=float(ms), flops=float(fl), bytes=float(by))
+            if args.per_layer:
+                if rank == 0:
+                    tf = float(fl) / (float(ms) * 1e-3) / 1e12 if float(ms) > 0 else 0
+                    print(f'{k:<48s} n={int(cnt) // args.steps:3d}  {float(ms) / args.steps:8.3f} ms/step  {tf:7.1f} TF/s  '
+                          f'{float(by) / (float(ms) * 1e-3) / 1e9 if float(ms) > 0 else 0:8.1f} GB/s', file=sys.stderr)
+                k = k.split(':')[0]
+            d0 = kernels.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d0['launches'] += int(cnt); d0['ms'] += float(ms); d0['flops'] += float(fl); d0['bytes'] += float(by)
         check(lib.ssd_profile_enable(net._h, 0))
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]['ms'])

@@ -30,7 +30,7 @@ Profiler::~Profiler() {
 ProfScope::ProfScope(const char* kernel, double flops, double bytes, hipStream_t stream) : s(stream), active(false), idx(0) {
     Profiler* p = g_prof;
     if (!p || !p->on) return;
-    Profiler::Rec r{kernel, flops, bytes, p->get(), p->get()};
+    Profiler::Rec r{p->detailed ? std::string(kernel) + ":" + p->layer : std::string(kernel), flops, bytes, p->get(), p->get()};
     idx = p->recs.size();
     p->recs.push_back(r);
     active = true;
@@ -405,6 +405,7 @@ int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, i
 int ssd_profile_enable(ssd_handle h, int on) {
     API_BEGIN
     N(h).profiler().on = on != 0;
+    N(h).profiler().detailed = on == 2;
     N(h).profiler().reset();
     API_END
 }
@@ -423,7 +424,7 @@ int ssd_profile_report(ssd_handle h, char* buf, size_t cap) {
         a.cnt++; a.ms += ms; a.fl += r.flops; a.by += r.bytes;
     }
     std::string out;
-    char line[256];
+    char line[384];
     for (const auto& kv : agg) {
         snprintf(line, sizeof line, "%s\t%lld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.cnt, kv.second.ms, kv.second.fl,
                  kv.second.by);

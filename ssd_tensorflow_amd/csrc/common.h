@@ -45,11 +45,13 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Off by default; a Net turns it on for its steps.  One record per kernel launch.
 struct Profiler {
     struct Rec {
-        const char* kernel;
+        std::string kernel;
         double flops, bytes;
         hipEvent_t e0, e1;
     };
     bool on = false;
+    bool detailed = false;          // label records "kernel:layer"
+    const char* layer = "";         // set by the executor around each op
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;

@@ -302,6 +302,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     for (const Op& op : ops_) {
         const Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
+        prof_.layer = op.name.c_str();
         switch (op.kind) {
         case OP_CONV:
             conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, stream_);
@@ -316,6 +317,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             break;
         }
     }
+    prof_.layer = "loss";
     if (train_mode) {
         multibox_loss(heads_, b, result_, y, lw_, params_, nfilters_, wd_, stream_);
         HIP_OK(hipMemcpyAsync(losses_host_, lw_.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -327,6 +329,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
 void Net::backward(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
+    prof_.layer = "loss";
     multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
     for (Tensor& t : tensors_) t.done = 0;
     for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
@@ -335,6 +338,7 @@ void Net::backward(int b, const float* y) {
         const Tensor& out = tensors_[op.out];
         const bool need_dx = op.in != input_t_;
         const bool last = in.done + 1 == in.consumers;
+        prof_.layer = op.name.c_str();
         switch (op.kind) {
         case OP_CONV: {
             const ConvDesc d = conv_desc(op, b);
@@ -368,6 +372,7 @@ float Net::current_lr() const {
 void Net::apply_gradients(float grad_scale) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
+    prof_.layer = "optimizer";
     momentum_update(params_, mom_, grads_, nparams_, current_lr(), momentum_, grad_scale, stream_);
     ++global_step;
 }
