@@ -1,0 +1,85 @@
+"""Data parallelism for the SSD-VGG step: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The reference trains on a single device (no collective anywhere).  Images are
+independent units, the loss is reduce_mean over the batch of per-sample normalised losses
+(ssdvgg.py:520,559), so with equal shards the global gradient is the MEAN of the per-rank
+gradients: all-reduce (sum) of the flat gradient arena, then 1/world folded into the update.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env():
+    """(rank, local_rank, world_size) from the launcher's environment."""
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+
+
+def init(backend=None):
+    rank, local, world = env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, **kw)
+    return rank, local, world
+
+
+class ShardSampler:
+    """The reference's single feeder shuffles the sample list and cuts it into batches
+    (training_data.py:137-139,176-178).  Here every rank draws the SAME permutation (same seed)
+    and takes a rank-strided slice of each global batch: shards are disjoint, their union is the
+    global batch, no exchange is needed.  The last global batch may be short; ranks whose slice
+    is empty skip it (the reference never pads a batch that reaches the net)."""
+
+    def __init__(self, num_samples, batch_per_rank, rank=0, world=1, seed=0):
+        self.n, self.b, self.rank, self.world, self.seed = int(num_samples), int(batch_per_rank), rank, world, seed
+
+    def num_batches(self):
+        g = self.b * self.world
+        return (self.n + g - 1) // g
+
+    def batches(self, epoch):
+        perm = np.random.default_rng(self.seed + epoch).permutation(self.n)
+        g = self.b * self.world
+        for k in range(self.num_batches()):
+            glob = perm[k * g:(k + 1) * g]
+            yield glob[self.rank * self.b:(self.rank + 1) * self.b]
+
+
+def allreduce_flat(flat, world, bucket_floats=0):
+    """Sum `flat` (the gradient arena, a 1-D tensor) over ranks, in place.  bucket_floats > 0
+    splits it into contiguous buckets issued back to back (async) so the first ones overlap the
+    tail of the producer stream; the arena is laid out filters-first in forward order."""
+    if world <= 1:
+        return
+    if bucket_floats <= 0 or bucket_floats >= flat.numel():
+        dist.all_reduce(flat)
+        return
+    works = [dist.all_reduce(flat[o:o + bucket_floats], async_op=True) for o in range(0, flat.numel(), bucket_floats)]
+    for w in works:
+        w.wait()
+
+
+def mean_scalars(values, world, device=None):
+    """Average a short list of floats over ranks (loss logging)."""
+    if world <= 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return (t / world).tolist()
+
+
+def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0):
+    """One data-parallel step on this rank's shard (device tensors)."""
+    net.forward_backward_dev(x_dev, y_dev)
+    allreduce_flat(net.grads_flat, world, bucket_floats)
+    net.apply_gradients_dev(1.0 / world)
