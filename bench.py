@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
     args = ap.parse_args()
@@ -108,6 +109,8 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     H, W = net.preset.image_size.h, net.preset.image_size.w
     x = torch.from_numpy(rng.integers(0, 256, (b, H, W, 3)).astype(np.float32)).cuda()
+    if args.zero_input:
+        x.zero_()
     A, nv = net.preset.num_anchors, 25
     y = torch.empty((b, A, nv), dtype=torch.float32, device='cuda')
     gt, cls, offs = synth_gt(rng, b)

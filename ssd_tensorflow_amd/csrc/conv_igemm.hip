@@ -23,11 +23,13 @@
 // Global->LDS goes through registers (the gather needs zero fill), issued one
 // k-iteration ahead of the MFMAs that consume it (two LDS buffers, one barrier / iter).
 #include "conv.h"
+#include <cstdlib>
 
 namespace ssd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDA = 36;
@@ -100,9 +102,69 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     f32x4 areg[A_ROWS];
     f32x4 breg[B_N];
 
+    // Fast path (every layer but conv1_1 and the strided data-gradients): the gather is a
+    // branch-free buffer load.  Per row: the byte offset of (pixel, channel a_c4) and a 9-bit
+    // mask of the taps that fall inside the image, both computed once; per iteration one add of
+    // the (wave-uniform) tap/chunk offset and one select to an out-of-range offset, for which the
+    // buffer unit returns zeros -- the zero padding costs no branch and no VALU select of data.
+    constexpr bool FAST = !SMALLC && !STRIDED;
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.src), 0, FAST ? (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.wci * p.wco * 4u), 0x00020000);
+    unsigned a_off[A_ROWS], a_msk[A_ROWS];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            a_off[i] = (unsigned)((rb[i] + rh[i] * p.SW + rw[i]) * p.SC + a_c4) * 4u;
+            unsigned mk = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int sh = rh[i] + p.tap_dh[t], sw = rw[i] + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+            }
+            a_msk[i] = mk;
+        }
+    }
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
     auto load_tiles = [&](int kiter) {
         const int cc = kiter / p.ntaps;
         const int tap = kiter - cc * p.ntaps;
+        if constexpr (FAST) {
+            const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * BK) * 4);   // wave-uniform
+            // validity as all-ones / all-zeros words, combined with bit ops: hipcc turns a
+            // `cond ? offset : OOB` feeding a load into divergent branches around two loads
+            const unsigned cmask = 0u - (unsigned)(cc * BK + a_c4 < p.SC);
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
+                const unsigned off = ((a_off[i] + toff) & m) | (OOB & ~m);
+                areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0));
+            }
+            if constexpr (MODE == MODE_FWD) {
+                const int col = (tid % B_CPR) * 4;
+                const unsigned nmask = 0u - (unsigned)(n0 + col < p.DN);
+#pragma unroll
+                for (int i = 0; i < B_FWD_N; ++i) {
+                    const int kr = tid / B_CPR + B_RPP * i;
+                    const int c = cc * BK + kr;
+                    const unsigned m = nmask & (0u - (unsigned)(c < p.SC && kr < BK));
+                    const unsigned off = (((unsigned)((tap * p.wci + c) * p.wco + n0 + col) * 4u) & m) | (OOB & ~m);
+                    breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wgt_rsrc, off, 0, 0));
+                }
+            } else {
+                const int c = cc * BK + a_c4;
+                const unsigned cmk = 0u - (unsigned)(c < p.SC);
+#pragma unroll
+                for (int i = 0; i < B_DG_N; ++i) {
+                    const int n = n0 + (tid >> 3) + 32 * i;
+                    const unsigned m = cmk & (0u - (unsigned)(n < p.DN));
+                    const unsigned off = (((unsigned)((tap * p.wci + n) * p.wco + c) * 4u) & m) | (OOB & ~m);
+                    breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wgt_rsrc, off, 0, 0));
+                }
+            }
+            return;
+        }
         if constexpr (SMALLC) {
             // K = ntaps*SC (27 for conv1_1) packed k = tap*SC + c; scalar gather.
 #pragma unroll
@@ -285,8 +347,10 @@ struct WgradArgs {
 template <int WM, int WN, int TM, int TN, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 32;
-    constexpr int X_CPR = BKT / 4, X_RPP = 256 / X_CPR, X_N = (BP + X_RPP - 1) / X_RPP;
-    constexpr int Y_CPR = BNT / 4, Y_RPP = 256 / Y_CPR, Y_N = (BP + Y_RPP - 1) / Y_RPP;
+    // staging map: thread -> ONE pixel row (tid >> 3) and the 16-byte chunks (tid & 7) + 8*j of it,
+    // so the per-pixel index math runs once per thread and every load instruction still covers
+    // whole 128-byte lines (8 lanes per row)
+    constexpr int X_N = BKT / 32, Y_N = BNT / 32;
     constexpr int X_LDS = BP * BKT, Y_LDS = BP * BNT;
     static_assert(WM * WN == 4, "4 waves per workgroup");
 
@@ -308,23 +372,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
     f32x4 xreg[X_N], yreg[Y_N];
 
-    auto load_tiles = [&](int it) {
-        const int mb = mbeg + it * BP;
+    // this thread's pixel row, advanced by BP pixels per iteration
+    const int row = tid >> 3, cb = (tid & 7) * 4;
+    int pw, ph, pb;
+    {
+        const int m = mbeg + row;
+        pw = m % p.Wo;
+        const int t2 = m / p.Wo;
+        ph = t2 % p.Ho;
+        pb = t2 / p.Ho;
+    }
+
+    // branch-free buffer loads: out-of-image pixels, rows past the split and channels past the
+    // tensor are steered to an out-of-range offset, for which the buffer unit returns zeros
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 4u), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned xcmask[X_N], ycmask[Y_N];
 #pragma unroll
-        for (int i = 0; i < X_N; ++i) {
-            const int r = tid / X_CPR + X_RPP * i;
-            const int col = (tid % X_CPR) * 4;
-            const int m = mb + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < BP && m < mend) {
-                const int ow = m % p.Wo;
-                const int t2 = m / p.Wo;
-                const int oh = t2 % p.Ho;
-                const int b = t2 / p.Ho;
-                if constexpr (SMALLC) {
+    for (int j = 0; j < X_N; ++j) xcmask[j] = 0u - (unsigned)(c0 + cb + 32 * j < p.Ci);
+#pragma unroll
+    for (int j = 0; j < Y_N; ++j) ycmask[j] = 0u - (unsigned)(n0 + cb + 32 * j < p.Co);
+
+    auto load_tiles = [&](int it) {
+        const int m = mbeg + it * BP + row;
+        const int ow = pw, oh = ph, b = pb;
+        if (p.Wo >= BP) {
+            pw += BP;
+            if (pw >= p.Wo) {
+                pw -= p.Wo;
+                if (++ph == p.Ho) { ph = 0; ++pb; }
+            }
+        } else {
+            const int m2 = m + BP;
+            pw = m2 % p.Wo;
+            const int t2 = m2 / p.Wo;
+            ph = t2 % p.Ho;
+            pb = t2 / p.Ho;
+        }
+        const unsigned rowok = 0u - (unsigned)(m < mend);
+        if constexpr (SMALLC) {
+#pragma unroll
+            for (int j = 0; j < X_N; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < mend) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int k = col + e;
+                        const int k = cb + 32 * j + e;
                         if (k < p.ntaps * p.Ci) {
                             const int tp = k / p.Ci, c = k - tp * p.Ci;
                             const int sh = oh * p.stride + p.tap_dh[tp], sw = ow * p.stride + p.tap_dw[tp];
@@ -332,38 +428,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                                 v[e] = p.x[((size_t)(b * p.Hi + sh) * p.Wi + sw) * p.Ci + c];
                         }
                     }
-                } else {
-                    const int sh = oh * p.stride + dh, sw = ow * p.stride + dw;
-                    const int c = c0 + col;
-                    if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi && c < p.Ci)
-                        v = ld4(p.x + ((size_t)(b * p.Hi + sh) * p.Wi + sw) * p.Ci + c);
                 }
+                xreg[j] = v;
             }
-            xreg[i] = v;
-        }
+        } else {
+            const int sh = oh * p.stride + dh, sw = ow * p.stride + dw;
+            const unsigned inb = 0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi));
+            const unsigned base = (unsigned)(((b * p.Hi + sh) * p.Wi + sw) * p.Ci + c0 + cb) * 4u;
 #pragma unroll
-        for (int i = 0; i < Y_N; ++i) {
-            const int r = tid / Y_CPR + Y_RPP * i;
-            const int col = (tid % Y_CPR) * 4;
-            const int m = mb + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < BP && m < mend && n0 + col < p.Co) v = ld4(p.dy + (size_t)m * p.Co + n0 + col);
-            yreg[i] = v;
+            for (int j = 0; j < X_N; ++j) {
+                const unsigned mk = rowok & inb & xcmask[j];
+                xreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ((base + 128u * j) & mk) | (OOB & ~mk), 0, 0));
+            }
+        }
+        const unsigned ybase = (unsigned)(m * p.Co + n0 + cb) * 4u;
+#pragma unroll
+        for (int j = 0; j < Y_N; ++j) {
+            const unsigned mk = rowok & ycmask[j];
+            yreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ((ybase + 128u * j) & mk) | (OOB & ~mk), 0, 0));
         }
     };
     auto store_tiles = [&](int buf) {
         float* Xs = smem + buf * (X_LDS + Y_LDS);
         float* Ys = Xs + X_LDS;
 #pragma unroll
-        for (int i = 0; i < X_N; ++i) {
-            const int r = tid / X_CPR + X_RPP * i;
-            if (r < BP) *reinterpret_cast<f32x4*>(Xs + r * BKT + (tid % X_CPR) * 4) = xreg[i];
-        }
+        for (int j = 0; j < X_N; ++j) *reinterpret_cast<f32x4*>(Xs + row * BKT + cb + 32 * j) = xreg[j];
 #pragma unroll
-        for (int i = 0; i < Y_N; ++i) {
-            const int r = tid / Y_CPR + Y_RPP * i;
-            if (r < BP) *reinterpret_cast<f32x4*>(Ys + r * BNT + (tid % Y_CPR) * 4) = yreg[i];
-        }
+        for (int j = 0; j < Y_N; ++j) *reinterpret_cast<f32x4*>(Ys + row * BNT + cb + 32 * j) = yreg[j];
     };
 
     f32x16 acc[TM][TN];
@@ -465,6 +556,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // =================================================================================
 // host launchers
 // =================================================================================
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <typename K>
 static void set_lds(K kern, size_t bytes) {
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -499,6 +595,27 @@ static void check_desc(const ConvDesc& d) {
                 "conv: tensor too large for 32-bit pixel indexing");
 }
 
+// Tile choice: all co-resident workgroups of a CU share its matrix pipes, so a launch costs
+// about ceil(workgroups / 256 CUs) * BM * BN (tile work incl. padded rows/columns) divided by a
+// per-tile efficiency (bigger tiles re-use LDS fragments better).  0:128x128 1:128x64 2:64x128 3:64x64
+static int pick_tile(long long M, int N, int mode) {
+    static const int forced = env_int("SSD_TILE", -1);      // tuning override
+    if (forced >= 0 && forced < 4) return forced;
+    static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
+    // relative per-tile efficiency measured on vgg300 layers at batch 32 (tools/bench_conv.py):
+    // forward runs 116-125 TF/s on every tile; the data-gradient is fastest on 64x64
+    static const double eff_fwd[4] = {0.98, 1.0, 1.0, 0.95}, eff_dg[4] = {0.93, 0.92, 0.93, 1.0};
+    const double* eff = mode == MODE_FWD ? eff_fwd : eff_dg;
+    int best = 0;
+    double bc = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const long long wgs = (long long)cdiv(M, bm[c]) * cdiv(N, bn[c]);
+        const double cost = (double)((wgs + 255) / 256) * bm[c] * bn[c] / eff[c];
+        if (cost < bc * 0.999) { bc = cost; best = c; }
+    }
+    return best;
+}
+
 void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s) {
     check_desc(d);
     GatherArgs a{};
@@ -516,10 +633,13 @@ void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bi
     const double fl = conv_flops(d), by = conv_bytes(d);
     if (smallc) {
         launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
-    } else if (d.Co <= 64) {
-        launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, "conv_fwd_128x64", fl, by, s);
-    } else {
-        launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, "conv_fwd_128x128", fl, by, s);
+        return;
+    }
+    switch (pick_tile(a.M, a.DN, MODE_FWD)) {
+    case 0: launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, "conv_fwd_128x128", fl, by, s); break;
+    case 1: launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, "conv_fwd_128x64", fl, by, s); break;
+    case 2: launch_gather<MODE_FWD, 2, 2, 1, 2, false, false>(a, "conv_fwd_64x128", fl, by, s); break;
+    default: launch_gather<MODE_FWD, 2, 2, 1, 1, false, false>(a, "conv_fwd_64x64", fl, by, s); break;
     }
 }
 
@@ -539,12 +659,17 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
             a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
         }
     const double fl = conv_flops(d), by = conv_bytes(d) + (mask ? 4.0 * d.B * d.Hi * d.Wi * d.Ci : 0.0);
-    if (d.stride > 1) {
-        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, true>(a, "conv_dgrad_strided_128x64", fl, by, s);
-        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
+    const int cfg = pick_tile(a.M, a.DN, MODE_DGRAD);
+    if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
+        if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
+        else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
     } else {
-        if (d.Ci <= 64) launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, "conv_dgrad_128x64", fl, by, s);
-        else launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, "conv_dgrad_128x128", fl, by, s);
+        switch (cfg) {
+        case 0: launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, "conv_dgrad_128x128", fl, by, s); break;
+        case 1: launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, "conv_dgrad_128x64", fl, by, s); break;
+        case 2: launch_gather<MODE_DGRAD, 2, 2, 1, 2, false, false>(a, "conv_dgrad_64x128", fl, by, s); break;
+        default: launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, false>(a, "conv_dgrad_64x64", fl, by, s); break;
+        }
     }
 }
 
@@ -569,6 +694,7 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     const int taps = p.smallc ? 1 : d.KH * d.KW;
     p.tiles = taps * p.CT * p.NT;
     int want = cdiv(1536, p.tiles);
+    if (want > 256) want = 256;          // the reduce pass reads every slab: keep it short
     int maxs = cdiv(M, 256);
     p.nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);
     if (p.nsplit < 1) p.nsplit = 1;

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const floa
         const int b = (int)(pix / d.Hi);
         const f32x4 self = ld4(x + idx * 4);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (relu_mask && !(self[0] > 0.f) && !(self[1] > 0.f) && !(self[2] > 0.f) && !(self[3] > 0.f)) {
+            st4(dx + idx * 4, g);                    // every component is masked whatever arrives
+            continue;
+        }
         int n = h + d.pad_h - d.k + 1;
         const int oh_lo = n <= 0 ? 0 : (n + d.stride - 1) / d.stride;
         const int oh_hi = min(d.Ho - 1, (h + d.pad_h) / d.stride);
@@ -112,6 +116,58 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const floa
     }
 }
 
+// 2x2 stride-2 SAME pooling never overlaps and never pads before the image: one thread owns one
+// window (x 4 channels), finds its first maximum and writes all (<= 4) input gradients.
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const float* __restrict__ x,
+                                                             const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int accumulate, int relu_mask) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * 2, w0 = ow * 2;
+        f32x4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            ok[q] = h < d.Hi && w < d.Wi;
+            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok[q]) v[q] = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+        }
+        const f32x4 gy = ld4(dy + idx * 4);
+        int arg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int a = 0;
+            float m = v[0][e];                       // cell 0 is always inside the image
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (ok[q] && v[q][e] > m) { m = v[q][e]; a = q; }   // strict: the first maximum wins
+            arg[e] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            float* o = dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (accumulate) g = ld4(o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (arg[e] == q) g[e] += gy[e];
+                if (relu_mask && !(v[q][e] > 0.f)) g[e] = 0.f;
+            }
+            st4(o, g);
+        }
+    }
+}
+
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
@@ -125,6 +181,13 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
     ProfScope prof("maxpool_bwd", 0.0, 4.0 * d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
+    if (d.k == 2 && d.stride == 2 && d.pad_h == 0 && d.pad_w == 0) {
+        const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+        hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
+                           (int)accumulate, (int)relu_mask);
+        HIP_OK(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
                        (int)accumulate, (int)relu_mask);
     HIP_OK(hipGetLastError());
@@ -210,12 +273,17 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
         ws[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-__global__ void colsum_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// column sums of ws[nrows][C]: one wave per 64 columns x row-slices, fixed-order tree in LDS
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += ws[(size_t)r * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int r = wv; r < nrows; r += 4) s += ws[(size_t)r * C + c];
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 static int l2_blocks(int npix) {
@@ -240,7 +308,7 @@ void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float
     const int nb = l2_blocks(npix);
     ProfScope prof("l2norm_bwd", 0.0, 12.0 * npix * C, s);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nb, C, dscale);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nb, C, dscale);
     HIP_OK(hipGetLastError());
 }
 
@@ -460,7 +528,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 __global__ void loss_final_kernel(int B, const float* __restrict__ sample, const float* __restrict__ partial, int npartial,
                                   float wd, float* __restrict__ losses) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave; lane-strided partial sums then a fixed-order shuffle tree
+    const int lane = threadIdx.x;
+    double ss = 0.0;
+    for (int i = lane; i < npartial; i += 64) ss += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane != 0) return;
     float conf = 0.f, loc = 0.f;
     for (int b = 0; b < B; ++b) {
         conf += sample[b * 4 + 0];
@@ -468,8 +542,6 @@ __global__ void loss_final_kernel(int B, const float* __restrict__ sample, const
     }
     conf /= (float)B;
     loc /= (float)B;
-    double ss = 0.0;
-    for (int i = 0; i < npartial; ++i) ss += (double)partial[i];
     const float l2 = wd * (float)(0.5 * ss);
     losses[0] = conf + loc + l2;
     losses[1] = loc;
