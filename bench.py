@@ -71,9 +71,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--preset', default='vgg300')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
+    ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
+    ap.add_argument('--bucket-mb', type=float, default=0, help='all-reduce the gradient arena in buckets of this many MB (0 = one buffer)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
     args = ap.parse_args()
@@ -82,6 +85,7 @@ def main():
     import torch.distributed as dist
     from ssd_tensorflow_amd._lib import lib, check
     from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+    from ssd_tensorflow_amd import parallel
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -89,12 +93,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend)
 
     b = args.batch
+    bucket = int(args.bucket_mb * 1e6 / 4)
     sess = Session(local)
     net = SSDVGG(sess, args.preset)
     training = args.mode == 'train'
@@ -118,11 +128,26 @@ def main():
                                     y.data_ptr(), None))
     torch.cuda.synchronize()
 
+    if args.mode == 'decode':
+        # BASELINE config 5 / SURVEY 8d: softmax of N(0,1) logits, +4 on background, +8 on 300 random
+        # (anchor, class) pairs per image; loc ~ N(0, 0.5): ~300 detections per image at thr 0.5
+        g = torch.Generator(device='cuda'); g.manual_seed(1234 + rank)
+        logits = torch.randn((b, A, 21), generator=g, device='cuda')
+        logits[:, :, 20] += 4
+        hot_a = torch.randint(0, A, (b, 300), generator=g, device='cuda'); hot_c = torch.randint(0, 20, (b, 300), generator=g, device='cuda')
+        logits[torch.arange(b, device='cuda')[:, None], hot_a, hot_c] += 8
+        pred = torch.cat([torch.softmax(logits, -1), torch.randn((b, A, 4), generator=g, device='cuda') * 0.5], -1).contiguous()
+        check(lib.ssd_set_result_dev(net._h, pred.data_ptr(), b))
+        torch.cuda.synchronize()
+
     def step():
+        if args.mode == 'decode':
+            dets = net.detect_last(b, 0.5, None, 200)
+            return
         if args.mode == 'train':
             net.forward_backward_dev(x, y)
             if world > 1:
-                dist.all_reduce(net.grads_flat)            # sum over ranks, RCCL over xGMI
+                parallel.allreduce_flat(net.grads_flat, world, bucket)     # sum over ranks, RCCL over xGMI
             net.apply_gradients_dev(1.0 / world)
         elif args.mode == 'infer':
             net.infer_dev(x)
@@ -150,6 +175,11 @@ def main():
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # replicas must still agree after K data-parallel steps
+        chk = net.params_flat[::4099].double().sum().reshape(1)
+        lo = chk.clone(); hi = chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(hi - lo) == 0.0, 'replicas diverged'
         dt = float(t.item())
 
     roofline = None
@@ -172,6 +202,8 @@ def main():
         check(lib.ssd_profile_enable(net._h, 0))
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]['ms'])
+            if args.mode == 'decode' and 'detect_scan' in kernels:
+                dom = 'detect_scan'       # the HBM-bound pass (every [A,25] row read once); detect_image works on candidates only
             d = kernels[dom]
             if d['flops'] > 0:
                 ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
@@ -194,6 +226,7 @@ def main():
         flops_img = FLOPS_FWD_BWD[args.preset] if args.mode == 'train' else FLOPS_FWD[args.preset]
         out = {
             'metric': 'images/sec (fwd+bwd) %s batch%d' % (args.preset, b) if args.mode == 'train'
+                      else 'images/sec (decode + per-class NMS of [b,A,25] predictions) %s batch%d' % (args.preset, b) if args.mode == 'decode'
                       else 'images/sec (%s) %s batch%d' % (args.mode, args.preset, b),
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',

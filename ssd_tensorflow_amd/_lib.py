@@ -76,6 +76,7 @@ SIGNATURES = {
     'ssd_infer_dev': (i32, [handle, vp, i32]),
     'ssd_result_dev': (i32, [handle, C.POINTER(vp)]),
     'ssd_get_losses': (i32, [handle, vp]),
+    'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'ssd_profile_enable': (i32, [handle, i32]),

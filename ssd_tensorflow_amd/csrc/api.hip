@@ -346,6 +346,11 @@ int ssd_result_dev(ssd_handle h, const float** result_dev) {
     *result_dev = N(h).result();
     API_END
 }
+int ssd_set_result_dev(ssd_handle h, const float* pred_dev, int b) {
+    API_BEGIN
+    N(h).set_result(pred_dev, b);
+    API_END
+}
 int ssd_get_losses(ssd_handle h, float losses_out[4]) {
     API_BEGIN
     N(h).get_losses(losses_out);

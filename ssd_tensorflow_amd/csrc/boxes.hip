@@ -232,33 +232,57 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // confidence >= thr are appended to the image's list as one 64-bit sort key:
 //   conf bits << 32 | (32767 - anchor) << 8 | class      (descending sort == conf desc, anchor asc)
 constexpr int SCAN_ROWS = 256;
+constexpr int SCAN_MAXV = 32;                       // nv <= 32
+constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
 
 __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
                                                           int A2, int* __restrict__ counts, u64* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
+    __shared__ int s_cnt[2], s_base[2];
     const size_t total_rows = (size_t)B * A;
     const size_t r0 = (size_t)blockIdx.x * SCAN_ROWS;
-    const size_t nrows = min((size_t)SCAN_ROWS, total_rows - r0);
-    const size_t nfl = nrows * nv;
+    const int nrows = (int)min((size_t)SCAN_ROWS, total_rows - r0);
+    const int nfl = nrows * nv;
     const float* src = pred + r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
-    const size_t n4 = nfl >> 2;
-    for (size_t i = threadIdx.x; i < n4; i += 256)
-        *reinterpret_cast<float4*>(rows + i * 4) = *reinterpret_cast<const float4*>(src + i * 4);
-    for (size_t i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
-    __syncthreads();
-    if (threadIdx.x >= nrows) return;
-    const float* r = rows + (size_t)threadIdx.x * nv;
-    const int nfg = nv - 5;                      // argmax excludes the background class
-    int best = 0;
-    float conf = r[0];
-    for (int c = 1; c < nfg; ++c)
-        if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-    if (!(conf < thr)) {                         // the reference breaks at the first conf < thr
-        const size_t row = r0 + threadIdx.x;
-        const int b = (int)(row / A), a = (int)(row - (size_t)b * A);
-        const int slot = atomicAdd(&counts[b], 1);
-        keys[(size_t)b * A2 + slot] = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best;
+    const int n4 = nfl >> 2;
+    // all of this thread's loads are issued before the first one is consumed
+    float4 v[SCAN_LOADS];
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
     }
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    __syncthreads();
+    // a block of 256 rows touches at most two images: slot 0 = the image of its first row
+    const int b0 = (int)(r0 / A);
+    const int a0 = (int)(r0 - (size_t)b0 * A);
+    bool cand = false;
+    int best = 0, which = 0, a = 0, slot = 0;
+    float conf = 0.f;
+    if ((int)threadIdx.x < nrows) {
+        const float* r = rows + (size_t)threadIdx.x * nv;
+        const int nfg = nv - 5;                  // argmax excludes the background class
+        conf = r[0];
+        for (int c = 1; c < nfg; ++c)
+            if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
+        cand = !(conf < thr);                    // the reference breaks at the first conf < thr
+        a = a0 + (int)threadIdx.x;
+        if (a >= A) { a -= A; which = 1; }
+        if (cand) slot = atomicAdd(&s_cnt[which], 1);       // LDS: order inside the list is irrelevant (sorted later)
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[b0 + threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (cand)
+        keys[(size_t)(b0 + which) * A2 + s_base[which] + slot] =
+            ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best;
 }
 
 // descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
@@ -501,6 +525,7 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
             int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s) {
     SSD_REQUIRE(A <= 32767 && A <= DET_MAX_ALIVE, "detect: at most 32767 anchors (got %d)", A);
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
+    SSD_REQUIRE(A >= SCAN_ROWS, "detect: at least %d anchors", SCAN_ROWS);
     SSD_REQUIRE(out_cap >= 1, "detect: out_cap must be >= 1");
     const int nv = num_classes + 5;
     const int A2 = pow2_ge(A);
@@ -514,12 +539,16 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     HIP_OK(hipMemsetAsync(counts, 0, (size_t)B * 4, s));
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
-    hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                       conf_thr, A2, counts, keys1);
+    {
+        ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
+        hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
+                           conf_thr, A2, counts, keys1);
+    }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
     a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.counts = counts;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
+    ProfScope prof("detect_image", 0.0, 0.0, s);
     hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
     HIP_OK(hipGetLastError());
 }

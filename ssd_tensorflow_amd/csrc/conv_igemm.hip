@@ -59,7 +59,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED, bool PF>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_ROWS = BM / 32;                   // rows staged per thread
@@ -260,22 +260,31 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     auto compute = [&](int buf) {
         const float* As = smem + buf * (A_LDS + B_LDS);
         const float* Bs = As + A_LDS;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        f32x4 a[2][TM], b[2][TN];
+        auto load_frags = [&](int g, int slot) {
             const int kb = g * 8 + lh * 4;
-            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
-                a[mi] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * TM + mi * 32 + li) * LDA + kb);
+                a[slot][mi] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * TM + mi * 32 + li) * LDA + kb);
             if constexpr (MODE == MODE_FWD) {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[ni][t] = Bs[(kb + t) * BN + wn * 32 * TN + ni * 32 + li];
+                    for (int t = 0; t < 4; ++t) b[slot][ni][t] = Bs[(kb + t) * BN + wn * 32 * TN + ni * 32 + li];
             } else {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    b[ni] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 * TN + ni * 32 + li) * LDA + kb);
+                    b[slot][ni] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 * TN + ni * 32 + li) * LDA + kb);
+            }
+        };
+        if constexpr (PF) load_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const int cur = PF ? (g & 1) : 0;
+            if constexpr (PF) {
+                if (g + 1 < BK / 8) load_frags(g + 1, (g + 1) & 1);
+            } else {
+                load_frags(g, 0);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -283,7 +292,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi][t], b[cur][ni][t], acc[mi][ni], 0, 0, 0);
+            if constexpr (PF) {
+                // pin the order: the next group's LDS reads first, then this group's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+            }
         }
     };
 
@@ -570,8 +584,11 @@ template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
 static void launch_gather(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM * LDA + (MODE == MODE_FWD ? BK * BN : BN * LDA)) * sizeof(float);
-    auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED>;
-    static bool once = (set_lds(kern, lds), true);
+    static const int pf = env_int("SSD_PREFETCH", 0);
+    auto kern = pf ? conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, true>
+                   : conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, false>;
+    static bool once = (set_lds(conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, true>, lds),
+                        set_lds(conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, false>, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);

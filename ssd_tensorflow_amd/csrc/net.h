@@ -72,6 +72,7 @@ public:
 
     void get_losses(float out[4]);
     void copy_result(float* out, int b);
+    void set_result(const float* pred_dev, int b);
 
     const std::vector<Variable>& variables() const { return vars_; }
     void load_variable(const char* name, const float* host, size_t count, int which);   // 0 params, 2 momentum

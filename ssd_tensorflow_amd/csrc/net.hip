@@ -400,6 +400,11 @@ void Net::get_losses(float out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = losses_host_[i];
 }
 
+void Net::set_result(const float* pred_dev, int b) {
+    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
+    HIP_OK(hipMemcpyAsync(result_, pred_dev, (size_t)b * preset_->num_anchors * (C_ + 5) * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+}
+
 void Net::copy_result(float* out, int b) {
     const size_t n = (size_t)b * preset_->num_anchors * (C_ + 5);
     HIP_OK(hipMemcpyAsync(out, result_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -481,6 +486,8 @@ void Net::detect_last(int b, float thr, int cap, int max_out, int out_cap, bool 
         detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
         detect_ws_b_ = Bmax_;
     }
+    g_prof = &prof_;
+    prof_.layer = "detect";
     const size_t n = (size_t)b * out_cap;
     char* o = (char*)dalloc(n * 4 * 7 + (size_t)b * 4 + 256);     // small, freed with the handle
     DetectOut d;
