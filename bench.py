@@ -76,7 +76,7 @@ def main():
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
-    ap.add_argument('--bucket-mb', type=float, default=0, help='all-reduce the gradient arena in buckets of this many MB (0 = one buffer)')
+    ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
     args = ap.parse_args()
@@ -145,10 +145,8 @@ def main():
             dets = net.detect_last(b, 0.5, None, 200)
             return
         if args.mode == 'train':
-            net.forward_backward_dev(x, y)
-            if world > 1:
-                parallel.allreduce_flat(net.grads_flat, world, bucket)     # sum over ranks, RCCL over xGMI
-            net.apply_gradients_dev(1.0 / world)
+            # N > 1: bucketed all-reduce (sum over ranks, RCCL over xGMI) overlapped with backward
+            parallel.train_step_dp(net, x, y, world, bucket)
         elif args.mode == 'infer':
             net.infer_dev(x)
         else:

@@ -71,6 +71,9 @@ SIGNATURES = {
     'ssd_infer': (i32, [handle, vp, i32, vp]),
     'ssd_forward_backward_dev': (i32, [handle, vp, vp, i32]),
     'ssd_apply_gradients_dev': (i32, [handle, f32]),
+    'ssd_forward_dev': (i32, [handle, vp, vp, i32]),
+    'ssd_backward_begin_dev': (i32, [handle, vp, i32]),
+    'ssd_backward_next_dev': (i32, [handle, sz, C.POINTER(sz), C.POINTER(sz), p_i32]),
     'ssd_train_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_eval_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_infer_dev': (i32, [handle, vp, i32]),

@@ -318,6 +318,22 @@ int ssd_forward_backward_dev(ssd_handle h, const float* x_dev, const float* y_de
     n.backward(b, y_dev);
     API_END
 }
+int ssd_forward_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
+    API_BEGIN
+    N(h).forward(x_dev, b, true, y_dev);
+    API_END
+}
+int ssd_backward_begin_dev(ssd_handle h, const float* y_dev, int b) {
+    API_BEGIN
+    N(h).backward_begin(b, y_dev);
+    API_END
+}
+int ssd_backward_next_dev(ssd_handle h, size_t min_floats, size_t* offset, size_t* count, int* more) {
+    API_BEGIN
+    SSD_REQUIRE(offset && count && more, "null output pointer");
+    *more = N(h).backward_step(min_floats, offset, count) ? 1 : 0;
+    API_END
+}
 int ssd_apply_gradients_dev(ssd_handle h, float grad_scale) {
     API_BEGIN
     N(h).apply_gradients(grad_scale);

@@ -354,6 +354,7 @@ struct WgradArgs {
     int M, Hi, Wi, Ci, Ho, Wo, Co;
     int ntaps, stride;
     int CT, NT;             // channel tiles, n tiles
+    int ntaps_grid;         // taps enumerated by the grid (1 for the packed small-C case)
     int mchunk, nsplit;
     int tap_dh[9], tap_dw[9];
 };
@@ -371,8 +372,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
-    const int split = blockIdx.x;
-    int tile = blockIdx.y;
+    // 1-D grid: consecutive ids (after the XCD remap) = all (tap, channel, n) tiles of ONE pixel split,
+    // so the workgroups that re-read the same x / dy rows run together on one XCD and share its L2
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = p.ntaps_grid * p.CT * p.NT;
+    const int split = wgid / ntiles;
+    int tile = wgid - split * ntiles;
     const int nt = tile % p.NT;
     tile /= p.NT;
     const int ct = tile % p.CT;
@@ -692,7 +697,7 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
 
 // ---- wgrad planning ---------------------------------------------------------------
 struct WgradPlan {
-    int cfg;        // 0: 128x128, 1: 64x64, 2: 64x128
+    int cfg;        // (channels x n) 0: 128x128, 1: 64x64, 2: 64x128, 3: 128x64
     int bkt, bnt, CT, NT, tiles, nsplit, mchunk;
     bool smallc;
 };
@@ -701,11 +706,13 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     WgradPlan p{};
     const int M = d.B * d.Ho * d.Wo;
     p.smallc = d.Ci % 4 != 0;
+    const int waste128 = cdiv(d.Co, 128) * 128 - d.Co, waste64 = cdiv(d.Co, 64) * 64 - d.Co;
     if (p.smallc || (d.Ci <= 64 && d.Co <= 64)) p.cfg = 1;
     else if (d.Ci <= 64) p.cfg = 2;
+    else if (waste64 < waste128) p.cfg = 3;      // fused heads: Co = 100 / 152
     else p.cfg = 0;
-    p.bkt = p.cfg == 0 ? 128 : 64;
-    p.bnt = p.cfg == 1 ? 64 : 128;
+    p.bkt = (p.cfg == 0 || p.cfg == 3) ? 128 : 64;
+    p.bnt = (p.cfg == 1 || p.cfg == 3) ? 64 : 128;
     p.CT = p.smallc ? 1 : cdiv(d.Ci, p.bkt);
     p.NT = cdiv(d.Co, p.bnt);
     const int taps = p.smallc ? 1 : d.KH * d.KW;
@@ -733,7 +740,7 @@ static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, const char* label, d
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit * pl.tiles), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -746,6 +753,7 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
     a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
     a.ntaps = d.KH * d.KW; a.stride = d.stride; a.CT = pl.CT; a.NT = pl.NT;
     a.mchunk = pl.mchunk; a.nsplit = pl.nsplit;
+    a.ntaps_grid = pl.smallc ? 1 : a.ntaps;
     for (int kh = 0; kh < d.KH; ++kh)
         for (int kw = 0; kw < d.KW; ++kw) {
             a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
@@ -755,6 +763,7 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
     if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
     else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, "conv_wgrad_64x64", fl, by, s);
     else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, "conv_wgrad_64x128", fl, by, s);
+    else if (pl.cfg == 3) launch_wgrad<2, 2, 2, 1, false>(a, pl, "conv_wgrad_128x64", fl, by, s);
     else launch_wgrad<2, 2, 2, 2, false>(a, pl, "conv_wgrad_128x128", fl, by, s);
 
     const size_t wcount = (size_t)a.ntaps * d.Ci * d.Co;

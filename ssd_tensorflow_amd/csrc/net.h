@@ -62,6 +62,9 @@ public:
     // steps; x/y device pointers
     void forward(const float* x, int b, bool train_mode, const float* y);
     void backward(int b, const float* y);
+    void backward_begin(int b, const float* y);
+    // runs reverse ops until >= min_floats of filter gradients are newly final; [off, off+count) is that range
+    bool backward_step(size_t min_floats, size_t* off, size_t* count);
     void apply_gradients(float grad_scale);
     void set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd);
 
@@ -140,6 +143,8 @@ private:
     std::vector<long long> lr_bounds_;
     float momentum_ = 0.9f, wd_ = 0.0005f;
     Profiler prof_;
+    int bw_next_ = -1, bw_b_ = 0;
+    size_t bw_done_off_ = 0;
 };
 
 }  // namespace ssd

@@ -326,14 +326,27 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
 }
 
-void Net::backward(int b, const float* y) {
+// Backward runs the op list in reverse.  It can be driven in stages so a data-parallel caller can
+// start all-reducing finished gradient ranges while the rest of backward still runs: filters sit
+// in the arena in forward order, so reverse execution completes them from the END of the filter
+// region towards its beginning, always as one contiguous, growing suffix.
+void Net::backward_begin(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
     prof_.layer = "loss";
     multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
     for (Tensor& t : tensors_) t.done = 0;
-    for (int oi = (int)ops_.size() - 1; oi >= 0; --oi) {
-        const Op& op = ops_[oi];
+    bw_next_ = (int)ops_.size() - 1;
+    bw_b_ = b;
+    bw_done_off_ = nfilters_;
+}
+
+bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
+    const int b = bw_b_;
+    const size_t hi = bw_done_off_;
+    size_t lo = hi;
+    while (bw_next_ >= 0 && hi - lo < min_floats) {
+        const Op& op = ops_[bw_next_--];
         Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
         const bool need_dx = op.in != input_t_;
@@ -346,6 +359,7 @@ void Net::backward(int b, const float* y) {
             if (need_dx)
                 conv_dgrad(d, out.grad, params_ + op.w_off, in.grad, (last && in.relu_out) ? in.data : nullptr, in.done > 0,
                            stream_);
+            lo = op.w_off;          // conv ops own descending, adjacent filter ranges
             break;
         }
         case OP_POOL: {
@@ -361,6 +375,16 @@ void Net::backward(int b, const float* y) {
         }
         in.done++;
     }
+    bw_done_off_ = lo;
+    *off = lo;
+    *count = hi - lo;
+    return bw_next_ >= 0;
+}
+
+void Net::backward(int b, const float* y) {
+    backward_begin(b, y);
+    size_t off, count;
+    while (backward_step(nparams_, &off, &count)) {}
 }
 
 float Net::current_lr() const {

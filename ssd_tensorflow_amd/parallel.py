@@ -79,7 +79,25 @@ def mean_scalars(values, world, device=None):
 
 
 def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0):
-    """One data-parallel step on this rank's shard (device tensors)."""
-    net.forward_backward_dev(x_dev, y_dev)
-    allreduce_flat(net.grads_flat, world, bucket_floats)
+    """One data-parallel step on this rank's shard (device tensors).
+
+    bucket_floats > 0: backward is driven in stages and every finished range of the filter
+    gradients (>= bucket_floats, completed from the end of the arena: heads, conv11 ... conv1) is
+    all-reduced asynchronously while the remaining backward kernels run; the tiny bias / scale
+    tail goes last.  bucket_floats == 0: one all-reduce after backward."""
+    if world <= 1:
+        net.forward_backward_dev(x_dev, y_dev)
+        net.apply_gradients_dev(1.0)
+        return
+    if bucket_floats <= 0:
+        net.forward_backward_dev(x_dev, y_dev)
+        dist.all_reduce(net.grads_flat)
+    else:
+        net.forward_dev(x_dev, y_dev)
+        works = []
+        for off, cnt in net.backward_staged(y_dev, x_dev.shape[0], bucket_floats):
+            works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
+        works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True))
+        for w in works:
+            w.wait()
     net.apply_gradients_dev(1.0 / world)

@@ -298,6 +298,18 @@ class SSDVGG:
     def forward_backward_dev(self, x_t, y_t):
         check(lib.ssd_forward_backward_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))
 
+    def forward_dev(self, x_t, y_t):
+        check(lib.ssd_forward_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))
+
+    def backward_staged(self, y_t, b, min_floats):
+        """Generator over (offset, count) ranges of the gradient arena as backward finishes them."""
+        check(lib.ssd_backward_begin_dev(self._h, y_t.data_ptr(), b))
+        off = C.c_size_t(); cnt = C.c_size_t(); more = C.c_int(1)
+        while more.value:
+            check(lib.ssd_backward_next_dev(self._h, int(min_floats), C.byref(off), C.byref(cnt), C.byref(more)))
+            if cnt.value:
+                yield off.value, cnt.value
+
     def apply_gradients_dev(self, grad_scale=1.0):
         check(lib.ssd_apply_gradients_dev(self._h, float(grad_scale)))
 

@@ -294,3 +294,29 @@ def test_shape_and_dtype_errors():
     sess.close()
     with pytest.raises(RuntimeError, match='No such preset'):
         SSDVGG(None, 'vgg999')
+
+
+def test_staged_backward_equals_plain_and_ranges_tile_the_filters():
+    """ssd_backward_next_dev (used to overlap the all-reduce with backward): same gradients, and the
+    finished ranges are adjacent, descending and cover exactly the filter region."""
+    preset, m, sess, net = make_pair('vgg300', 1)
+    net.build_optimizer(learning_rate=0.001)
+    rng = np.random.default_rng(4)
+    x, y, _ = ref.synth_batch(rng, 1, preset)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    net.forward_backward_dev(xt, yt)
+    torch.cuda.synchronize()
+    g_plain = net.grads_flat.clone()
+    net.grads_flat.zero_()
+    net.forward_dev(xt, yt)
+    ranges = list(net.backward_staged(yt, 1, 4_000_000))
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_flat, g_plain)
+    assert len(ranges) >= 4
+    hi = net.filter_floats
+    for off, cnt in ranges:
+        assert off + cnt == hi and cnt > 0
+        hi = off
+    assert hi == 0
+    assert all(cnt >= 4_000_000 for _, cnt in ranges[:-1])
+    sess.close()
