@@ -33,6 +33,40 @@ PEAK_FP32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0           # GB/s spec
 
 
+# kernel label (event profiler) -> substring of the kernel symbol in rocprofv3 output
+KERNEL_SYMBOLS = {
+    'conv_fwd_128x128': 'conv_gather_kernel<0, 2, 2, 2, 2, false, false', 'conv_fwd_128x64': 'conv_gather_kernel<0, 4, 1, 1, 2, false, false',
+    'conv_fwd_64x128': 'conv_gather_kernel<0, 2, 2, 1, 2, false, false', 'conv_fwd_64x64': 'conv_gather_kernel<0, 2, 2, 1, 1, false, false',
+    'conv_dgrad_128x128': 'conv_gather_kernel<1, 2, 2, 2, 2, false, false', 'conv_dgrad_128x64': 'conv_gather_kernel<1, 4, 1, 1, 2, false, false',
+    'conv_dgrad_64x128': 'conv_gather_kernel<1, 2, 2, 1, 2, false, false', 'conv_dgrad_64x64': 'conv_gather_kernel<1, 2, 2, 1, 1, false, false',
+    'conv_wgrad_128x128': 'conv_wgrad_kernel<2, 2, 2, 2, false>', 'conv_wgrad_64x64': 'conv_wgrad_kernel<2, 2, 1, 1, false>',
+    'conv_wgrad_64x128': 'conv_wgrad_kernel<2, 2, 1, 2, false>', 'conv_wgrad_128x64': 'conv_wgrad_kernel<2, 2, 2, 1, false>',
+    'detect_scan': 'detect_scan_kernel',
+}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of `label`'s kernel from the newest committed rocprofv3 --pmc passes
+    (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt; separate passes, KB units, FETCH_SIZE
+    doubled on gfx950 as MI355X_MICROARCH.md prescribes).  None when no pass is committed."""
+    import glob
+    sym = KERNEL_SYMBOLS.get(label)
+    f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_FETCH_SIZE.txt')))
+    w = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_WRITE_SIZE.txt')))
+    if not sym or not f or not w:
+        return None, None
+
+    def avg(path):
+        for line in open(path):
+            if sym in line:
+                return float(line.split('avg=')[1].split()[0])
+        return None
+    fa, wa = avg(f[-1]), avg(w[-1])
+    if fa is None or wa is None:
+        return None, None
+    return (2.0 * fa + wa) * 1024.0, os.path.basename(f[-1]) + ' + ' + os.path.basename(w[-1])
+
+
 def synth_gt(rng, b):
     """n ~ U{1..5} boxes per image, w,h ~ U(0.1,0.6), inside the image."""
     boxes, cls, offs = [], [], [0]
@@ -236,6 +270,11 @@ def main():
             'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4),
             'roofline': roofline,
         }
+        if roofline is not None and world == 1:
+            tr, src = pmc_traffic(roofline['kernel'])
+            if tr is not None:
+                roofline['traffic'] = tr
+                roofline['traffic_source'] = src
         if use_events:
             tot = sum(k['ms'] for k in kernels.values())
             out['kernel_ms_per_step'] = {k: round(v['ms'] / args.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}

@@ -398,3 +398,19 @@ def synth_batch(rng, b, preset, num_classes=20, anch=None, anch_abs=None):
                 break
         ys.append(vec); gts.append((g, c))
     return x, np.stack(ys), gts
+
+
+def decimate_fc_loops(fc6_w, fc6_b, fc7_w, fc7_b):
+    """The weight decimation of ssdvgg.py:245-253 and :273-280, restated with the reference's own loop
+    structure (float64 zeros, element-wise copies).  Used to check ssd_tensorflow_amd/weights.py."""
+    mod_w6 = np.zeros((3, 3, 512, 1024)); mod_b6 = np.zeros(1024)
+    for i in range(1024):
+        mod_b6[i] = fc6_b[4 * i]
+        for h in range(3):
+            for w in range(3):
+                mod_w6[h, w, :, i] = fc6_w[3 * h, 3 * w, :, 4 * i]
+    mod_w7 = np.zeros((1, 1, 1024, 1024)); mod_b7 = np.zeros(1024)
+    for i in range(1024):
+        mod_b7[i] = fc7_b[4 * i]
+        mod_w7[:, :, :, i] = fc7_w[:, :, 0:4096:4, 4 * i]      # for j: mod_w[:, :, j, i] = orig_w[:, :, 4j, 4i]
+    return mod_w6, mod_b6, mod_w7, mod_b7

@@ -46,6 +46,7 @@ SIGNATURES = {
     'ssd_preset_map': (i32, [cstr, i32, p_i32, p_f64, p_i32]),
     'ssd_anchors': (i32, [cstr, i32, vp]),
     'ssd_anchors_abs': (i32, [cstr, i32, vp]),
+    'ssd_jaccard_overlap': (i32, [i32, vp, vp, i32, vp]),
     'ssd_encode_labels': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp]),
     'ssd_encode_labels_dev': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp, vp]),
     'ssd_decode_nms': (i32, [cstr, i32, i32, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -127,6 +127,20 @@ int ssd_anchors_abs(const char* preset, int device, int* out) {
     API_END
 }
 
+int ssd_jaccard_overlap(int device, const double* box, const double* boxes, int n, double* iou_out) {
+    API_BEGIN
+    SSD_REQUIRE(n >= 0, "n must be >= 0");
+    if (n > 0) {
+        HIP_OK(hipSetDevice(device));
+        DevBuf db(4 * sizeof(double)), da((size_t)n * 4 * sizeof(double)), di((size_t)n * sizeof(double));
+        HIP_OK(hipMemcpy(db.p, box, 4 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(da.p, boxes, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice));
+        jaccard_device(db.as<double>(), da.as<double>(), n, di.as<double>(), nullptr);
+        HIP_OK(hipMemcpy(iou_out, di.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    API_END
+}
+
 static void encode_labels_impl(const char* preset, int num_classes, int device, const double* gt, const int* cls,
                                const int* offsets, int b, float* vec_dev, float* vec_host, hipStream_t s) {
     const Preset& p = get_preset(preset);

@@ -31,6 +31,9 @@ const Preset& get_preset(const char* name);
 // [A][4] f64 (cx, cy, w, h) and [A][4] i32 (xmin, xmax, ymin, ymax on the 1000 grid), device.
 void anchors_device(const Preset& p, double* anchors, int* anchors_abs, hipStream_t s);
 
+// jaccard_overlap of one box vs n boxes (f64, +1 pixel convention); device pointers
+void jaccard_device(const double* box, const double* arr, int n, double* iou, hipStream_t s);
+
 // LabelCreatorTransform for a batch.  gt [ntot][4] f64 (cx,cy,w,h), cls [ntot], offsets [B+1]
 // (CSR) all device; anchors/anchors_abs from anchors_device.  vec [B][A][C+5] f32 device.
 size_t encode_labels_ws_bytes(int ntot);

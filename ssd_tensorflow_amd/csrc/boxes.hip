@@ -208,6 +208,26 @@ __global__ __launch_bounds__(256) void label_rows_kernel(int A, int C, int B, co
     row[C + 4] = (float)__dmul_rn(log(__ddiv_rn(bh, ah)), 5.0);
 }
 
+// jaccard_overlap (ssdutils.py:138-152) of one box against n boxes, all (xmin, xmax, ymin, ymax) f64
+__global__ void jaccard_kernel(const double* __restrict__ box, const double* __restrict__ arr, int n, double* __restrict__ iou) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double b0 = box[0], b1 = box[1], b2 = box[2], b3 = box[3];
+    const double a0 = arr[i * 4], a1 = arr[i * 4 + 1], a2 = arr[i * 4 + 2], a3 = arr[i * 4 + 3];
+    const double areaa = __dmul_rn(__dadd_rn(__dsub_rn(a1, a0), 1.0), __dadd_rn(__dsub_rn(a3, a2), 1.0));
+    const double areab = __dmul_rn(__dadd_rn(__dsub_rn(b1, b0), 1.0), __dadd_rn(__dsub_rn(b3, b2), 1.0));
+    const double w = fmax(0.0, __dadd_rn(__dsub_rn(fmin(b1, a1), fmax(b0, a0)), 1.0));
+    const double h = fmax(0.0, __dadd_rn(__dsub_rn(fmin(b3, a3), fmax(b2, a2)), 1.0));
+    const double inter = __dmul_rn(w, h);
+    iou[i] = __ddiv_rn(inter, __dsub_rn(__dadd_rn(areab, areaa), inter));
+}
+
+void jaccard_device(const double* box, const double* arr, int n, double* iou, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(jaccard_kernel, dim3((n + 255) / 256), dim3(256), 0, s, box, arr, n, iou);
+    HIP_OK(hipGetLastError());
+}
+
 size_t encode_labels_ws_bytes(int ntot) { return (size_t)(ntot > 0 ? ntot : 1) * 7 * sizeof(int) + 64; }
 
 void encode_labels(const Preset& p, int num_classes, const double* anchors, const int* anchors_abs, const double* gt,

@@ -38,6 +38,15 @@ def main(argv=None):
     parser.add_argument('--dump-predictions', type=lambda v: v.lower() in ('1', 'true', 'yes', 'y', 't'), default=False)
     parser.add_argument('--batch-size', type=int, default=32, help='batch size')
     parser.add_argument('--threshold', type=float, default=0.5, help='confidence threshold')
+    # accepted for command-line compatibility with the reference (infer.py:62-89); the features behind
+    # them (cv2 annotation, AP statistics, VOC dataset / summary) are out of scope
+    parser.add_argument('--training-data', default='', help='unused: class names are the VOC defaults')
+    parser.add_argument('--annotate', default='False', help='out of scope (cv2 drawing)')
+    parser.add_argument('--compute-stats', default='True', help='out of scope (AP statistics)')
+    parser.add_argument('--data-source', default=None, help='out of scope (dataset readers)')
+    parser.add_argument('--data-dir', default='pascal-voc', help='out of scope (dataset readers)')
+    parser.add_argument('--sample', default='test', choices=['test', 'trainval'], help='out of scope')
+    parser.add_argument('--pascal-summary', default='False', help='out of scope (VOC submission files)')
     parser.add_argument('--synthetic', type=int, default=0, help='run on N synthetic images instead of files')
     parser.add_argument('--preset', default=None, help='preset when no checkpoint is given')
     args = parser.parse_args(argv)
@@ -55,6 +64,8 @@ def main(argv=None):
         if args.preset is None:
             print('[!] Cannot find checkpoint in ' + args.name); return 1                    # infer.py:113-126
         ckpt = None
+    if args.data_source:
+        print('[!] --data-source is not built (dataset readers are out of scope); use files or --synthetic'); return 1
     print('[i] Project name:      ', args.name)
     print('[i] Checkpoint:        ', ckpt or '(random weights, --preset ' + str(args.preset) + ')')
     print('[i] Batch size:        ', args.batch_size)

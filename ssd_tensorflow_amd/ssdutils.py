@@ -170,6 +170,59 @@ def suppress_overlaps(boxes):
     return boxes_from_detection(det, lid2name)
 
 
+# ---- scalar / per-box helpers of the reference kept under their names (ssdutils.py:133-189) ----
+def box2array(box, img_size):
+    """ssdutils.py:133-135"""
+    from .utils import prop2abs
+    return np.array(prop2abs(box.center, box.size, img_size))
+
+
+def jaccard_overlap(box_arr, anchors_arr):
+    """ssdutils.py:138-152 (+1 pixel convention) on the GPU (ssd_jaccard_overlap)."""
+    a = np.ascontiguousarray(anchors_arr, np.float64).reshape(-1, 4)
+    box = np.ascontiguousarray(box_arr, np.float64).reshape(4)
+    iou = np.empty(a.shape[0], np.float64)
+    check(lib.ssd_jaccard_overlap(_DEVICE, np_ptr(box), np_ptr(a), a.shape[0], np_ptr(iou)))
+    return iou
+
+
+def compute_overlap(box_arr, anchors_arr, threshold):
+    """ssdutils.py:155-170: Overlap(best, good) with Score(idx, score) records."""
+    from .utils import Score, Overlap
+    iou = jaccard_overlap(box_arr, anchors_arr)
+    best_idx = int(np.argmax(iou))
+    best = Score(best_idx, iou[best_idx]) if iou[best_idx] > threshold else None
+    return Overlap(best, [Score(int(i), iou[i]) for i in np.nonzero(iou > threshold)[0]])
+
+
+def compute_location(box, anchor):
+    """ssdutils.py:173-179"""
+    from math import log
+    arr = np.zeros((4))
+    arr[0] = (box.center.x - anchor.center.x) / anchor.size.w * 10
+    arr[1] = (box.center.y - anchor.center.y) / anchor.size.h * 10
+    arr[2] = log(box.size.w / anchor.size.w) * 5
+    arr[3] = log(box.size.h / anchor.size.h) * 5
+    return arr
+
+
+def decode_location(box, anchor):
+    """ssdutils.py:182-189, without the in-place clamp of the caller's array."""
+    from math import exp
+    box = np.where(box > 100, 100, box).astype(box.dtype)
+    x = box[0] / 10 * anchor.size.w + anchor.center.x
+    y = box[1] / 10 * anchor.size.h + anchor.center.y
+    return Point(x, y), Size(exp(box[2] / 5) * anchor.size.w, exp(box[3] / 5) * anchor.size.h)
+
+
+def non_maximum_suppression(boxes, overlap_threshold):
+    """ssdutils.py:232-307 for one class.  Only the reference's own call (threshold 0.45 from
+    suppress_overlaps) is built: it maps to the fused GPU decode + NMS."""
+    if abs(overlap_threshold - 0.45) > 1e-12:
+        raise NotImplementedError('the HIP kernel implements the reference\'s 0.45 threshold (20*inter > 9*union)')
+    return suppress_overlaps(boxes)
+
+
 def encode_labels_batch(preset, num_classes, gt_boxes_list, gt_cls_list):
     """LabelCreatorTransform for a batch on the GPU: lists (one per image) of [n,4] float64
     proportional (cx, cy, w, h) and [n] class ids -> [b, A, num_classes+5] float32."""

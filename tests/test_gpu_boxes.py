@@ -173,3 +173,26 @@ def test_detect_empty_and_tiny_out_cap():
     pred[1, 100, 3] = 0.9; pred[1, 100, 20] = 0.1
     d = su.detect_batch(pred, preset, 0.5, 200, None)
     assert len(d[0]['conf']) == 0 and len(d[1]['conf']) == 1 and d[1]['idx'][0] == 100 and d[1]['cls'][0] == 3
+
+
+@pytest.mark.parametrize('pname', PRESETS)
+def test_overlap_mirrors_golden(pname):
+    """jaccard_overlap / compute_overlap / box2array / compute_location under their reference names."""
+    g = load(f'g23_labels_{pname}.npz')
+    g1 = load(f'g1_anchors_{pname}.npz')
+    aabs = g1['anchors_abs'].astype(np.float64)
+    for ci in range(int(g['ncases'][0])):
+        b = g[f'gt_{ci}'][0]
+        box = Box('x', 0, Point(float(b[0]), float(b[1])), Size(float(b[2]), float(b[3])))
+        arr = su.box2array(box, Size(1000, 1000))
+        ov = su.compute_overlap(arr, aabs, 0.5)
+        assert [s.idx for s in ov.good] == list(g[f'good_{ci}'])
+        assert np.array_equal(np.array([s.score for s in ov.good]), g[f'goodiou_{ci}'])      # IEEE f64 division: bit-exact
+        assert (-1 if ov.best is None else ov.best.idx) == int(g[f'best_{ci}'][0])
+    g7 = load('g7_location.npz')
+    for i in range(16):
+        bx = Box('x', 0, Point(*map(float, g7['box'][i, :2])), Size(*map(float, g7['box'][i, 2:])))
+        an = su.Anchor(Point(*map(float, g7['anchor'][i, :2])), Size(*map(float, g7['anchor'][i, 2:])), 0, 0, 0, 0)
+        assert np.array_equal(su.compute_location(bx, an), g7['enc'][i])
+        c, s = su.decode_location(g7['loc'][i].copy(), an)
+        assert [float(c.x), float(c.y), s.w, s.h] == list(g7['dec'][i])
