@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
     ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
     args = ap.parse_args()
@@ -190,7 +191,14 @@ def main():
     for _ in range(args.warmup):
         step()
     use_events = not args.no_kernel_events
-    if use_events:
+    # In training the weight gradients run on a side stream next to the data gradients, so kernels of
+    # the timed region overlap and a per-launch event interval is not one kernel's own duration.  The
+    # timed region therefore runs WITHOUT per-launch events; the roofline block comes from an equal
+    # number of serialized steps (one kernel at a time, events on the launching stream) right after it.
+    serialize_for_events = use_events and args.mode == 'train' and not args.no_overlap
+    if args.no_overlap and args.mode == 'train':
+        check(lib.ssd_set_overlap(net._h, 0))
+    if use_events and not serialize_for_events:
         check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
     torch.cuda.synchronize()
     if world > 1:
@@ -216,6 +224,13 @@ def main():
 
     roofline = None
     kernels = {}
+    if serialize_for_events:
+        check(lib.ssd_set_overlap(net._h, 0))
+        check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
     if use_events:
         buf = C.create_string_buffer(1 << 16)
         check(lib.ssd_profile_report(net._h, buf, len(buf)))
@@ -243,7 +258,9 @@ def main():
                                 frac=round(ach / PEAK_FP32_MFMA, 4), traffic=None,
                                 launches_per_step=d['launches'] // args.steps,
                                 avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
-                                flops_per_launch=d['flops'] / d['launches'])
+                                flops_per_launch=d['flops'] / d['launches'],
+                                measured='HIP events per launch, %d serialized steps after the timed region' % args.steps
+                                if serialize_for_events else 'HIP events per launch over the timed region')
             else:
                 ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
                 roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM, unit='GB/s',

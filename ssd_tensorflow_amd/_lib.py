@@ -83,6 +83,7 @@ SIGNATURES = {
     'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'ssd_set_overlap': (i32, [handle, i32]),
     'ssd_profile_enable': (i32, [handle, i32]),
     'ssd_profile_report': (i32, [handle, C.c_char_p, sz]),
     'ssd_activation_shape': (i32, [handle, cstr, p_i32, p_i32, p_i32]),

@@ -437,6 +437,12 @@ int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, i
     API_END
 }
 
+int ssd_set_overlap(ssd_handle h, int on) {
+    API_BEGIN
+    N(h).set_overlap(on != 0);
+    API_END
+}
+
 int ssd_profile_enable(ssd_handle h, int on) {
     API_BEGIN
     N(h).profiler().on = on != 0;

@@ -99,6 +99,7 @@ public:
     float* result() { return result_; }
     long long global_step = 0;
     Profiler& profiler() { return prof_; }
+    void set_overlap(bool on) { overlap_ = on; }
 
 private:
     int add_tensor(const std::string& name, int H, int W, int C, bool relu_out);
@@ -114,6 +115,9 @@ private:
     int C_, Bmax_, device_;
     bool training_;
     hipStream_t stream_ = nullptr;
+    hipStream_t wstream_ = nullptr;        // side stream of the weight gradients (SSD_OVERLAP_WGRAD=0 disables)
+    hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
+    bool overlap_ = true;
 
     std::vector<Tensor> tensors_;
     std::vector<Op> ops_;

@@ -2,6 +2,7 @@
 #include "net.h"
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 namespace ssd {
 
@@ -282,12 +283,24 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     build_graph();
     alloc();
     init_weights(seed);
+    const char* ov = getenv("SSD_OVERLAP_WGRAD");
+    overlap_ = !(ov && ov[0] == '0');
+    if (training_) {
+        HIP_OK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_dy_, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev_w_, hipEventDisableTiming));
+    }
 }
 
 Net::~Net() {
     if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    if (wstream_) {
+        (void)hipStreamDestroy(wstream_);
+        (void)hipEventDestroy(ev_dy_);
+        (void)hipEventDestroy(ev_w_);
+    }
     for (void* p : allocs_) (void)hipFree(p);
     if (losses_host_) (void)hipHostFree(losses_host_);
 }
@@ -345,6 +358,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
     const int b = bw_b_;
     const size_t hi = bw_done_off_;
     size_t lo = hi;
+    bool side_used = false;
     while (bw_next_ >= 0 && hi - lo < min_floats) {
         const Op& op = ops_[bw_next_--];
         Tensor& in = tensors_[op.in];
@@ -355,7 +369,18 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
         switch (op.kind) {
         case OP_CONV: {
             const ConvDesc d = conv_desc(op, b);
-            conv_wgrad(d, in.data, out.grad, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, stream_);
+            // The weight gradient only feeds the optimizer; the data gradient is on the critical
+            // path.  They read the same dy and write disjoint buffers, so the weight gradient goes
+            // to a side stream: its workgroups fill the CUs the data-gradient's last partial wave
+            // of workgroups leaves idle (and vice versa).
+            const bool side = wstream_ && overlap_;
+            hipStream_t ws = side ? wstream_ : stream_;
+            if (side) {
+                HIP_OK(hipEventRecord(ev_dy_, stream_));
+                HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+                side_used = true;
+            }
+            conv_wgrad(d, in.data, out.grad, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
             if (need_dx)
                 conv_dgrad(d, out.grad, params_ + op.w_off, in.grad, (last && in.relu_out) ? in.data : nullptr, in.done > 0,
                            stream_);
@@ -374,6 +399,10 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
             break;
         }
         in.done++;
+    }
+    if (side_used) {        // the returned range is final in main-stream order
+        HIP_OK(hipEventRecord(ev_w_, wstream_));
+        HIP_OK(hipStreamWaitEvent(stream_, ev_w_, 0));
     }
     bw_done_off_ = lo;
     *off = lo;
