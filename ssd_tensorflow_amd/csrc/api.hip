@@ -535,7 +535,9 @@ int ssd_op_maxpool_bwd(const float* x, const float* dy, float* dx, int accumulat
                        int ho, int wo, int k, int stride, int pad_h, int pad_w, void* stream) {
     API_BEGIN
     PoolDesc d{b, hi, wi, c, ho, wo, k, stride, pad_h, pad_w};
-    maxpool_bwd(d, x, dy, dx, accumulate != 0, relu_mask != 0, (hipStream_t)stream);
+    DevBuf ws(maxpool_bwd_ws_bytes(d));
+    maxpool_bwd(d, x, dy, dx, accumulate != 0, relu_mask != 0, maxpool_bwd_ws_bytes(d) ? ws.p : nullptr, (hipStream_t)stream);
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));     // the scratch dies here
     API_END
 }
 int ssd_op_l2norm_fwd(const float* x, const float* scale, float* y, int npix, int c, void* stream) {

@@ -572,6 +572,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Many slabs, few elements (early layers: 9 tiles x ~170 pixel splits): 16 threads share one float4
+// element and each sums every 16th slab; the 16 partials are added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, int nsplit, size_t wcount,
+                                                                int Co, float* __restrict__ dw, float* __restrict__ db,
+                                                                const float* __restrict__ w, float wd) {
+    __shared__ f32x4 part[16][16];
+    const size_t total = wcount + Co;
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t i = ((size_t)blockIdx.x * 16 + e) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < total)
+        for (int k = sl; k < nsplit; k += 16) s += ld4(ws + (size_t)k * total + i);
+    part[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        f32x4 t = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += part[q][e];
+        if (i < wcount) {
+            if (wd != 0.f) t += wd * ld4(w + i);
+            *reinterpret_cast<f32x4*>(dw + i) = t;
+        } else if (db) {
+            *reinterpret_cast<f32x4*>(db + (i - wcount)) = t;
+        }
+    }
+}
+
 // =================================================================================
 // host launchers
 // =================================================================================
@@ -771,8 +798,12 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
     int blocks = cdiv((long long)total, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     ProfScope prof("wgrad_reduce", 0.0, 4.0 * (double)total * (pl.nsplit + 2), s);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, pl.nsplit, wcount, d.Co, dw, dbias, w,
-                       weight_decay);
+    if (pl.nsplit >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(cdiv((long long)total, 64)), dim3(256), 0, s, ws, pl.nsplit, wcount,
+                           d.Co, dw, dbias, w, weight_decay);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, pl.nsplit, wcount, d.Co, dw, dbias, w,
+                           weight_decay);
     HIP_OK(hipGetLastError());
 }
 

@@ -117,6 +117,8 @@ private:
     hipStream_t stream_ = nullptr;
     hipStream_t wstream_ = nullptr;        // side stream of the weight gradients (SSD_OVERLAP_WGRAD=0 disables)
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
+    hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
+    hipEvent_t ev_h_ = nullptr, ev_fmap_[MAX_MAPS] = {};
     bool overlap_ = true;
 
     std::vector<Tensor> tensors_;
@@ -134,6 +136,7 @@ private:
     float *x_stage_ = nullptr, *y_stage_ = nullptr;
     float* wgrad_ws_ = nullptr;
     float* l2_ws_ = nullptr;
+    void* pool_ws_ = nullptr;
     void* loss_ws_ = nullptr;
     LossWork lw_{};
     float* losses_host_ = nullptr;        // pinned

@@ -232,6 +232,15 @@ void Net::alloc() {
                 for (int b : {1, B}) ws = std::max(ws, conv_wgrad_ws_floats(conv_desc(op, b)));
         wgrad_ws_ = (float*)dalloc(ws * sizeof(float));
         l2_ws_ = (float*)dalloc(l2norm_bwd_ws_floats(B * 64 * 64, 512) * sizeof(float));
+        size_t pws = 0;
+        for (auto& op : ops_)
+            if (op.kind == OP_POOL) {
+                const Tensor& in = tensors_[op.in];
+                const Tensor& out = tensors_[op.out];
+                PoolDesc d{B, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+                pws = std::max(pws, maxpool_bwd_ws_bytes(d));
+            }
+        pool_ws_ = dalloc(pws);
     }
     result_ = (float*)dalloc((size_t)B * A * nv * sizeof(float));
     x_stage_ = (float*)dalloc((size_t)B * preset_->image_h * preset_->image_w * 3 * sizeof(float));
@@ -285,6 +294,9 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     init_weights(seed);
     const char* ov = getenv("SSD_OVERLAP_WGRAD");
     overlap_ = !(ov && ov[0] == '0');
+    HIP_OK(hipStreamCreateWithFlags(&hstream_, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_h_, hipEventDisableTiming));
+    for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev_fmap_[i], hipEventDisableTiming));
     if (training_) {
         HIP_OK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&ev_dy_, hipEventDisableTiming));
@@ -296,6 +308,11 @@ Net::~Net() {
     if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    if (hstream_) {
+        (void)hipStreamDestroy(hstream_);
+        (void)hipEventDestroy(ev_h_);
+        for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev_fmap_[i]);
+    }
     if (wstream_) {
         (void)hipStreamDestroy(wstream_);
         (void)hipEventDestroy(ev_dy_);
@@ -311,6 +328,7 @@ Net::~Net() {
 void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
     g_prof = &prof_;
+    bool heads_on_side = false;
     tensors_[input_t_].data = const_cast<float*>(x);
     for (const Op& op : ops_) {
         const Tensor& in = tensors_[op.in];
@@ -318,7 +336,16 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         prof_.layer = op.name.c_str();
         switch (op.kind) {
         case OP_CONV:
-            conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, stream_);
+            if (op.head >= 0 && hstream_ && overlap_) {
+                // the multibox heads hang off the trunk: they run on a side stream behind their feature
+                // map and fill the CUs the trunk's kernels leave idle between waves of workgroups
+                HIP_OK(hipEventRecord(ev_fmap_[op.head], stream_));
+                HIP_OK(hipStreamWaitEvent(hstream_, ev_fmap_[op.head], 0));
+                conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, hstream_);
+                heads_on_side = true;
+            } else {
+                conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, stream_);
+            }
             break;
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
@@ -329,6 +356,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             l2norm_fwd(b * in.H * in.W, in.C, in.data, params_ + scale_off_, out.data, stream_);
             break;
         }
+    }
+    if (heads_on_side) {
+        HIP_OK(hipEventRecord(ev_h_, hstream_));
+        HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
     }
     prof_.layer = "loss";
     if (train_mode) {
@@ -389,7 +420,8 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
         }
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-            maxpool_bwd(d, in.data, out.grad, in.grad, in.done > 0, last && in.relu_out, stream_);
+            maxpool_bwd(d, in.data, out.grad, in.grad, in.done > 0, last && in.relu_out,
+                        maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr, stream_);
             break;
         }
         case OP_L2NORM:

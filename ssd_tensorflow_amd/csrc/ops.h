@@ -13,8 +13,11 @@ struct PoolDesc {
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s);
 // dx[cell] = sum of dy over the windows whose FIRST maximum (scan order) is this cell.
 // accumulate: += existing dx first; relu_mask: zero where x <= 0 (x is a relu output).
+// ws: optional scratch of maxpool_bwd_ws_bytes() for overlapping windows (per-window argmax bytes);
+// nullptr = recompute every window's maximum per cell.
+size_t maxpool_bwd_ws_bytes(const PoolDesc& d);
 void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
-                 hipStream_t s);
+                 void* ws, hipStream_t s);
 
 // ---- l2_normalization (ssdvgg.py:80-84): y = scale * x * rsqrt(max(sum_c x^2, 1e-12))
 void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s);

@@ -168,6 +168,78 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const f
     }
 }
 
+// Overlapping pooling (3x3 stride 1, mod_pool5): pass A finds every window's first maximum once
+// (its scan-order cell index, one byte per channel); pass B lets every input cell collect dy from
+// the <= 9 windows whose recorded maximum it is.  27 loads per cell instead of 81.
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const float* __restrict__ x, unsigned* __restrict__ arg) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * d.stride - d.pad_h, w0 = ow * d.stride - d.pad_w;
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+        unsigned a[4] = {255u, 255u, 255u, 255u};
+        for (int kh = 0; kh < d.k; ++kh) {
+            const int h = h0 + kh;
+            if ((unsigned)h >= (unsigned)d.Hi) continue;
+            for (int kw = 0; kw < d.k; ++kw) {
+                const int w = w0 + kw;
+                if ((unsigned)w >= (unsigned)d.Wi) continue;
+                const f32x4 v = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > m[e] || a[e] == 255u) { m[e] = v[e]; a[e] = (unsigned)(kh * d.k + kw); }   // strict: first maximum
+            }
+        }
+        arg[idx] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(PoolDesc d, const float* __restrict__ x, const unsigned* __restrict__ arg,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              int accumulate, int relu_mask) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Hi * d.Wi * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int w = (int)(pix % d.Wi);
+        pix /= d.Wi;
+        const int h = (int)(pix % d.Hi);
+        const int b = (int)(pix / d.Hi);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        int n = h + d.pad_h - d.k + 1;
+        const int oh_lo = n <= 0 ? 0 : (n + d.stride - 1) / d.stride;
+        const int oh_hi = min(d.Ho - 1, (h + d.pad_h) / d.stride);
+        n = w + d.pad_w - d.k + 1;
+        const int ow_lo = n <= 0 ? 0 : (n + d.stride - 1) / d.stride;
+        const int ow_hi = min(d.Wo - 1, (w + d.pad_w) / d.stride);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const size_t o = (((size_t)b * d.Ho + oh) * d.Wo + ow) * C4 + c4;
+                const unsigned me = (unsigned)((h - (oh * d.stride - d.pad_h)) * d.k + (w - (ow * d.stride - d.pad_w)));
+                const unsigned a = arg[o];
+                const f32x4 gy = ld4(dy + o * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((a >> (8 * e)) & 255u) == me) g[e] += gy[e];
+            }
+        if (accumulate) g += ld4(dx + idx * 4);
+        if (relu_mask) {
+            const f32x4 self = ld4(x + idx * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = self[e] > 0.f ? g[e] : 0.f;
+        }
+        st4(dx + idx * 4, g);
+    }
+}
+
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
@@ -176,8 +248,12 @@ void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
     HIP_OK(hipGetLastError());
 }
 
+size_t maxpool_bwd_ws_bytes(const PoolDesc& d) {
+    return (d.k == 2 && d.stride == 2) ? 0 : (size_t)d.B * d.Ho * d.Wo * (d.C / 4) * sizeof(unsigned);
+}
+
 void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
-                 hipStream_t s) {
+                 void* ws, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
     ProfScope prof("maxpool_bwd", 0.0, 4.0 * d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
@@ -185,6 +261,14 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
         const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
         hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
                            (int)accumulate, (int)relu_mask);
+        HIP_OK(hipGetLastError());
+        return;
+    }
+    if (ws) {
+        const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+        hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (unsigned*)ws);
+        hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
+                           (const unsigned*)ws, dy, dx, (int)accumulate, (int)relu_mask);
         HIP_OK(hipGetLastError());
         return;
     }
