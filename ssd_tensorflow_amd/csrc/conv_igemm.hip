@@ -737,7 +737,11 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     if (p.smallc || (d.Ci <= 64 && d.Co <= 64)) p.cfg = 1;
     else if (d.Ci <= 64) p.cfg = 2;
     else if (waste64 < waste128) p.cfg = 3;      // fused heads: Co = 100 / 152
+    else if (M < 100000) p.cfg = 3;              // conv4 and deeper: 128x64 tiles (3 workgroups / CU) measured
+                                                 // 116 vs 107 TFLOP/s; conv2/conv3 are as fast on 128x128
     else p.cfg = 0;
+    static const int forced = env_int("SSD_WGRAD_CFG", -1);      // tuning override
+    if (forced >= 0 && forced < 4 && !p.smallc) p.cfg = forced;
     p.bkt = (p.cfg == 0 || p.cfg == 3) ? 128 : 64;
     p.bnt = (p.cfg == 1 || p.cfg == 3) ? 64 : 128;
     p.CT = p.smallc ? 1 : cdiv(d.Ci, p.bkt);
