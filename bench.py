@@ -188,6 +188,8 @@ def main():
             net.infer_dev(x)
             net.detect_last(b, 0.5, None, 200)
 
+    if args.no_overlap and args.mode == 'train':
+        check(lib.ssd_set_overlap(net._h, 0))
     for _ in range(args.warmup):
         step()
     use_events = not args.no_kernel_events
@@ -196,8 +198,6 @@ def main():
     # timed region therefore runs WITHOUT per-launch events; the roofline block comes from an equal
     # number of serialized steps (one kernel at a time, events on the launching stream) right after it.
     serialize_for_events = use_events and args.mode == 'train' and not args.no_overlap
-    if args.no_overlap and args.mode == 'train':
-        check(lib.ssd_set_overlap(net._h, 0))
     if use_events and not serialize_for_events:
         check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
     torch.cuda.synchronize()
@@ -283,8 +283,8 @@ def main():
             'config': {'workload': f'{args.preset} {args.mode} step, {b} images/GPU x {world} GPU, synthetic '
                                    f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[1])',
                        'global_batch': b * world, 'parallelism': f'dp{world}'},
-            'model_tflops': round(value * flops_img / 1e12, 2),
-            'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4),
+            'model_tflops': round(value * flops_img / 1e12, 2) if args.mode != 'decode' else None,
+            'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4) if args.mode != 'decode' else None,
             'roofline': roofline,
         }
         if roofline is not None and world == 1:
