@@ -258,7 +258,6 @@ constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thre
 __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
                                                           int A2, int* __restrict__ counts, u64* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
-    __shared__ int s_cnt[2], s_base[2];
     const size_t total_rows = (size_t)B * A;
     const size_t r0 = (size_t)blockIdx.x * SCAN_ROWS;
     const int nrows = (int)min((size_t)SCAN_ROWS, total_rows - r0);
@@ -270,9 +269,9 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, 
 #pragma unroll
     for (int j = 0; j < SCAN_LOADS; ++j) {
         const int i = threadIdx.x + 256 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
     }
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_LOADS; ++j) {
         const int i = threadIdx.x + 256 * j;
@@ -280,29 +279,19 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, 
     }
     for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
     __syncthreads();
-    // a block of 256 rows touches at most two images: slot 0 = the image of its first row
-    const int b0 = (int)(r0 / A);
-    const int a0 = (int)(r0 - (size_t)b0 * A);
-    bool cand = false;
-    int best = 0, which = 0, a = 0, slot = 0;
-    float conf = 0.f;
+    // one 64-bit key per anchor, 0 = not a candidate: no atomics, the per-image kernel compacts
     if ((int)threadIdx.x < nrows) {
         const float* r = rows + (size_t)threadIdx.x * nv;
         const int nfg = nv - 5;                  // argmax excludes the background class
-        conf = r[0];
+        int best = 0;
+        float conf = r[0];
         for (int c = 1; c < nfg; ++c)
             if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-        cand = !(conf < thr);                    // the reference breaks at the first conf < thr
-        a = a0 + (int)threadIdx.x;
-        if (a >= A) { a -= A; which = 1; }
-        if (cand) slot = atomicAdd(&s_cnt[which], 1);       // LDS: order inside the list is irrelevant (sorted later)
+        const size_t row = r0 + threadIdx.x;
+        const int a = (int)(row % A);
+        const bool cand = !(conf < thr);         // the reference breaks at the first conf < thr
+        keys[row] = cand ? (((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7)) : 0ull;
     }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[b0 + threadIdx.x], s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (cand)
-        keys[(size_t)(b0 + which) * A2 + s_base[which] + slot] =
-            ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best;
 }
 
 // descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
@@ -378,7 +367,7 @@ struct DetectArgs {
     const double* anchors;
     const float* pred;
     int cap, max_out, out_cap, do_nms;
-    const int* counts;
+    const u64* dense;   // [B][A] one key per anchor, 0 = below the threshold
     u64* keys1;
     u64* keys2;
     int* box;       // [B][A][4]
@@ -392,8 +381,29 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
     __shared__ int s_npresent, s_wtot[DET_THREADS / 64], s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = min(p.counts[b], p.A);
     u64* g1 = p.keys1 + (size_t)b * p.A2;
+    // ---- compact the image's candidates (non-zero keys of the dense per-anchor array) ---------
+    int n = 0;
+    {
+        const u64* dense = p.dense + (size_t)b * p.A;
+        const int lane0 = tid & 63, wv0 = tid >> 6;
+        for (int a0 = 0; a0 < p.A; a0 += DET_THREADS) {
+            const int a = a0 + tid;
+            const u64 key = a < p.A ? dense[a] : 0ull;
+            const u64 bal = __ballot(key != 0ull);
+            if (lane0 == 0) s_wtot[wv0] = __popcll(bal);
+            __syncthreads();
+            int base = n, tot = 0;
+#pragma unroll
+            for (int i = 0; i < DET_THREADS / 64; ++i) {
+                if (i < wv0) base += s_wtot[i];
+                tot += s_wtot[i];
+            }
+            if (key != 0ull) g1[base + __popcll(bal & ((1ull << lane0) - 1ull))] = key;
+            n += tot;
+            __syncthreads();
+        }
+    }
     u64* g2 = p.keys2 + (size_t)b * p.A2;
     int* box = p.box + (size_t)b * p.A * 4;
     int* nbox = p.nbox + (size_t)b * p.A * 4;
@@ -538,7 +548,7 @@ static int pow2_ge(int n) {
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
-    return 256 + ((size_t)B * 4 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
+    return 512 + (size_t)B * A * 8 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
@@ -550,23 +560,21 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     const int nv = num_classes + 5;
     const int A2 = pow2_ge(A);
     char* base = (char*)ws;
-    int* counts = (int*)base;
-    base += ((size_t)B * 4 + 255) / 256 * 256;
+    u64* dense = (u64*)base; base += ((size_t)B * A * 8 + 255) / 256 * 256;
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
     int* box = (int*)base; base += (size_t)B * A * 16;
     int* nbox = (int*)base;
-    HIP_OK(hipMemsetAsync(counts, 0, (size_t)B * 4, s));
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                           conf_thr, A2, counts, keys1);
+                           conf_thr, A2, nullptr, dense);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
-    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.counts = counts;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.dense = dense;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
     ProfScope prof("detect_image", 0.0, 0.0, s);
     hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
