@@ -53,6 +53,7 @@ SIGNATURES = {
     'ssd_decode_nms_ws_bytes': (sz, [cstr, i32]),
     'ssd_decode_nms_dev': (i32, [cstr, i32, vp, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     'ssd_anchors_dev': (i32, [cstr, vp, vp, vp]),
+    'ssd_average_precision': (i32, [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_double, vp, vp]),
     'ssd_arena_floats': (sz, [cstr, i32]),
     'ssd_create': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, C.POINTER(handle)]),
     'ssd_destroy': (i32, [handle]),

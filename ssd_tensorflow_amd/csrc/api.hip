@@ -1,6 +1,7 @@
 // extern "C" boundary of libssdvgg_hip.so (include/ssdvgg_hip.h).
 #include "../../include/ssdvgg_hip.h"
 #include "net.h"
+#include "metrics.h"
 #include <vector>
 
 namespace ssd {
@@ -222,6 +223,37 @@ int ssd_decode_nms(const char* preset, int num_classes, int device, const float*
     HIP_OK(hipMemcpy(cls, dcls.p, n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(idx, didx.p, n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(box, dbox.p, n * 16, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int ssd_average_precision(int device, int n_det, const float* det_box, const float* det_conf, const int* det_cls,
+                          const int* det_sample, int n_gt, const double* gt_box, const int* gt_cls, const int* gt_sample,
+                          int num_classes, double minoverlap, double* ap_out, int* present_out) {
+    API_BEGIN
+    SSD_REQUIRE(num_classes >= 1 && n_det >= 0 && n_gt >= 0, "bad sizes");
+    for (int g = 1; g < n_gt; ++g) SSD_REQUIRE(gt_sample[g] >= gt_sample[g - 1], "ground truth must be grouped by ascending sample id");
+    HIP_OK(hipSetDevice(device));
+    int n2 = 1;
+    while (n2 < n_det) n2 <<= 1;
+    const size_t nd = n_det ? n_det : 1, ng = n_gt ? n_gt : 1;
+    DevBuf dbox(nd * 16), dconf(nd * 4), dcls(nd * 4), dsmp(nd * 4), gbox(ng * 32), gcls(ng * 4), gsmp(ng * 4);
+    DevBuf keys((size_t)num_classes * n2 * 8), matched(ng), ap((size_t)num_classes * 8), present((size_t)num_classes * 4);
+    if (n_det) {
+        HIP_OK(hipMemcpy(dbox.p, det_box, nd * 16, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dconf.p, det_conf, nd * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dcls.p, det_cls, nd * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dsmp.p, det_sample, nd * 4, hipMemcpyHostToDevice));
+    }
+    if (n_gt) {
+        HIP_OK(hipMemcpy(gbox.p, gt_box, ng * 32, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(gcls.p, gt_cls, ng * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(gsmp.p, gt_sample, ng * 4, hipMemcpyHostToDevice));
+    }
+    average_precision_device(n_det, n_gt, num_classes, dbox.as<float>(), dconf.as<float>(), dcls.as<int>(), dsmp.as<int>(),
+                             gbox.as<double>(), gcls.as<int>(), gsmp.as<int>(), minoverlap, keys.as<unsigned long long>(), n2,
+                             matched.as<unsigned char>(), ap.as<double>(), present.as<int>(), nullptr);
+    HIP_OK(hipMemcpy(ap_out, ap.p, (size_t)num_classes * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(present_out, present.p, (size_t)num_classes * 4, hipMemcpyDeviceToHost));
     API_END
 }
 

@@ -14,6 +14,8 @@ import sys
 import numpy as np
 
 from . import parallel
+from .average_precision import APCalculator, APs2mAP
+from .ssdutils import boxes_from_detection
 from .ssdvgg import SSDVGG, Session, LearningRate
 from .training_data import TrainingData
 from .utils import str2bool
@@ -96,6 +98,8 @@ def main(argv=None):
             torch.distributed.broadcast(net.params_flat, 0)
         net.set_stream(torch.cuda.current_stream().cuda_stream)
 
+        training_ap_calc = APCalculator()
+        validation_ap_calc = APCalculator()
         say('[i] Training...')
         for e in range(start_epoch, args.epochs):
             td.epoch = e
@@ -115,8 +119,10 @@ def main(argv=None):
                 seen += x.shape[0]
                 if e == 0:
                     continue
-                # decode + NMS of the batch just computed, on the GPU (train.py:275-277)
+                # decode + NMS of the batch just computed, on the GPU (train.py:275-277), then AP bookkeeping
                 dets = net.detect_last(x.shape[0], 0.5, 200, None)
+                for i in range(x.shape[0]):
+                    training_ap_calc.add_detections(gt_boxes[i], boxes_from_detection(dets[i], td.lid2name))
             tot = np.array(parallel.mean_scalars(tot / max(seen, 1), world, 'cuda' if world > 1 else None))
             say('[i] Train {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(e + 1, args.epochs, *tot))
             # ---- validate (train.py:286-306) ---------------------------------------------------
@@ -125,8 +131,18 @@ def main(argv=None):
                 result, loss_batch = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
                 vt += np.array([loss_batch[k] for k in ('total', 'localization', 'confidence', 'l2')]) * x.shape[0]
                 vs += x.shape[0]
+                if e == 0:
+                    continue
+                dets = net.detect_last(x.shape[0], 0.5, 200, None)
+                for i in range(x.shape[0]):
+                    validation_ap_calc.add_detections(gt_boxes[i], boxes_from_detection(dets[i], td.lid2name))
             vt = np.array(parallel.mean_scalars(vt / max(vs, 1), world, 'cuda' if world > 1 else None))
             say('[i] Valid {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(e + 1, args.epochs, *vt))
+            # ---- mAP of this rank's shard (train.py:317-323, VOC07 11-point, on the GPU) ---------------------
+            if e > 0:
+                say('[i] mAP  {:>2}/{}  training {:.4f}  validation {:.4f}'.format(
+                    e + 1, args.epochs, APs2mAP(training_ap_calc.compute_aps()), APs2mAP(validation_ap_calc.compute_aps())))
+            training_ap_calc.clear(); validation_ap_calc.clear()
             # ---- checkpoint (train.py:336-343) -------------------------------------------------
             if (e + 1) % args.checkpoint_interval == 0 and rank == 0:
                 path = '{}/e{}.npz'.format(args.name, e + 1)

@@ -222,6 +222,54 @@ def main():
         assert type(c.x) is np.float32 and type(s.w) is float
         dec[i] = [c.x, c.y, s.w, s.h]
     np.savez_compressed(os.path.join(OUT, 'g7_location.npz'), box=bx, anchor=ax, enc=enc, loc=loc_in, dec=dec)
+    # ---- G8 VOC07 11-point AP (average_precision.py; np.bool / np.int aliased for numpy >= 1.24) ----
+    if not hasattr(np, 'bool'):
+        np.bool = bool
+    if not hasattr(np, 'int'):
+        np.int = int
+    import average_precision as apm
+    from oracle import average_precision as oap
+    rng = np.random.default_rng(21)
+    g8 = {}
+    for case in range(3):
+        nimg = [6, 40, 15][case]
+        calc = apm.APCalculator()
+        db, dc, dk, ds, gb, gk, gs = [], [], [], [], [], [], []
+        for img in range(nimg):
+            ng = int(rng.integers(0, 5))
+            gts = []
+            for _ in range(ng):
+                w, h = rng.uniform(0.1, 0.5, 2); cx = rng.uniform(w / 2, 1 - w / 2); cy = rng.uniform(h / 2, 1 - h / 2)
+                k = int(rng.integers(0, 6 if case < 2 else 20))
+                gts.append(ut.Box('c%d' % k, k, ut.Point(float(cx), float(cy)), ut.Size(float(w), float(h))))
+                gb.append(ut.prop2abs(gts[-1].center, gts[-1].size, ut.Size(1000, 1000))); gk.append(k); gs.append(img)
+            dets = []
+            for g in gts:                       # jittered copies of the ground truth (some duplicated) + clutter
+                for rep in range(int(rng.integers(0, 3))):
+                    j = rng.normal(0, 0.03 if rep == 0 else 0.12, 4)
+                    c = ut.Point(float(g.center.x + j[0]), float(g.center.y + j[1])); z = ut.Size(float(abs(g.size.w + j[2]) + 0.01), float(abs(g.size.h + j[3]) + 0.01))
+                    dets.append((np.float32(rng.uniform(0.3, 1.0)), ut.normalize_box(ut.Box(g.label, g.labelid, c, z))))
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.integers(0, 8 if case < 2 else 20))
+                w, h = rng.uniform(0.05, 0.5, 2)
+                dets.append((np.float32(rng.uniform(0.05, 0.9)), ut.normalize_box(ut.Box('c%d' % k, k, ut.Point(float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.2, 0.8))), ut.Size(float(w), float(h))))))
+            calc.add_detections(gts, dets)
+            for conf, b in dets:
+                db.append(ut.prop2abs(b.center, b.size, ut.Size(1000, 1000))); dc.append(conf); dk.append(b.labelid); ds.append(img)
+        assert len(set(np.float32(dc).tolist())) == len(dc), 'fixture must avoid exact confidence ties'
+        aps = calc.compute_aps()
+        ref_aps = {int(k[1:]): float(v) for k, v in aps.items()}
+        mine = oap.compute_aps(np.array(db, np.float32).reshape(-1, 4), np.array(dc, np.float32), dk, ds, np.array(gb, np.float64).reshape(-1, 4), gk, gs)
+        assert set(mine) == set(ref_aps) and all(mine[k] == ref_aps[k] for k in ref_aps), ('G8', case, mine, ref_aps)
+        assert oap.aps2map(mine) == apm.APs2mAP(aps)
+        g8[f'det_box_{case}'] = np.array(db, np.float32).reshape(-1, 4); g8[f'det_conf_{case}'] = np.array(dc, np.float32)
+        g8[f'det_cls_{case}'] = np.array(dk, np.int32); g8[f'det_sample_{case}'] = np.array(ds, np.int32)
+        g8[f'gt_box_{case}'] = np.array(gb, np.float64).reshape(-1, 4); g8[f'gt_cls_{case}'] = np.array(gk, np.int32); g8[f'gt_sample_{case}'] = np.array(gs, np.int32)
+        g8[f'ap_cls_{case}'] = np.array(list(mine), np.int32); g8[f'ap_{case}'] = np.array([ref_aps[k] for k in mine], np.float64)
+        g8[f'map_{case}'] = np.array([apm.APs2mAP(aps)], np.float64)
+        print('G8 case', case, 'detections', len(dc), 'gt', len(gk), 'mAP', oap.aps2map(mine))
+    g8['ncases'] = np.array([3])
+    np.savez_compressed(os.path.join(OUT, 'g8_average_precision.npz'), **g8)
     print('all golden fixtures written and oracle agrees bit-exactly')
 
 
