@@ -140,6 +140,7 @@ def main():
 
     b = args.batch
     bucket = int(args.bucket_mb * 1e6 / 4)
+    state = {'bucket': bucket}
     sess = Session(local)
     net = SSDVGG(sess, args.preset)
     training = args.mode == 'train'
@@ -181,7 +182,7 @@ def main():
             return
         if args.mode == 'train':
             # N > 1: bucketed all-reduce (sum over ranks, RCCL over xGMI) overlapped with backward
-            parallel.train_step_dp(net, x, y, world, bucket)
+            parallel.train_step_dp(net, x, y, world, state['bucket'])
         elif args.mode == 'infer':
             net.infer_dev(x)
         else:
@@ -190,6 +191,18 @@ def main():
 
     if args.no_overlap and args.mode == 'train':
         check(lib.ssd_set_overlap(net._h, 0))
+    allreduce_mode = 'none' if world == 1 else ('bucketed, overlapped with backward' if bucket > 0 else 'single, after backward')
+    if world > 1 and args.mode == 'train' and bucket > 0:
+        # the overlapped path is exercised once up front; if the collective library rejects it on every
+        # rank alike, fall back to ONE all-reduce after backward rather than losing the run
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                print(f'[bench] bucketed all-reduce failed ({type(e).__name__}: {e}); falling back to a single all-reduce', file=sys.stderr)
+            state['bucket'] = 0
+            allreduce_mode = 'single, after backward (fallback)'
     for _ in range(args.warmup):
         step()
     use_events = not args.no_kernel_events
@@ -282,7 +295,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.preset} {args.mode} step, {b} images/GPU x {world} GPU, synthetic '
                                    f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[1])',
-                       'global_batch': b * world, 'parallelism': f'dp{world}'},
+                       'global_batch': b * world, 'parallelism': f'dp{world}', 'allreduce': allreduce_mode},
             'model_tflops': round(value * flops_img / 1e12, 2) if args.mode != 'decode' else None,
             'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4) if args.mode != 'decode' else None,
             'roofline': roofline,

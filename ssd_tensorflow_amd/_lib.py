@@ -75,7 +75,8 @@ SIGNATURES = {
     'ssd_apply_gradients_dev': (i32, [handle, f32]),
     'ssd_forward_dev': (i32, [handle, vp, vp, i32]),
     'ssd_backward_begin_dev': (i32, [handle, vp, i32]),
-    'ssd_backward_next_dev': (i32, [handle, sz, C.POINTER(sz), C.POINTER(sz), p_i32]),
+    'ssd_backward_next_dev': (i32, [handle, sz, i32, C.POINTER(sz), C.POINTER(sz), p_i32]),
+    'ssd_set_wgrad_stream': (i32, [handle, vp]),
     'ssd_train_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_eval_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_infer_dev': (i32, [handle, vp, i32]),

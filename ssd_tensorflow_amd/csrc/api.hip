@@ -374,10 +374,15 @@ int ssd_backward_begin_dev(ssd_handle h, const float* y_dev, int b) {
     N(h).backward_begin(b, y_dev);
     API_END
 }
-int ssd_backward_next_dev(ssd_handle h, size_t min_floats, size_t* offset, size_t* count, int* more) {
+int ssd_backward_next_dev(ssd_handle h, size_t min_floats, int sync_main, size_t* offset, size_t* count, int* more) {
     API_BEGIN
     SSD_REQUIRE(offset && count && more, "null output pointer");
-    *more = N(h).backward_step(min_floats, offset, count) ? 1 : 0;
+    *more = N(h).backward_step(min_floats, offset, count, sync_main != 0) ? 1 : 0;
+    API_END
+}
+int ssd_set_wgrad_stream(ssd_handle h, void* stream) {
+    API_BEGIN
+    N(h).set_wgrad_stream((hipStream_t)stream);
     API_END
 }
 int ssd_apply_gradients_dev(ssd_handle h, float grad_scale) {

@@ -64,7 +64,8 @@ public:
     void backward(int b, const float* y);
     void backward_begin(int b, const float* y);
     // runs reverse ops until >= min_floats of filter gradients are newly final; [off, off+count) is that range
-    bool backward_step(size_t min_floats, size_t* off, size_t* count);
+    bool backward_step(size_t min_floats, size_t* off, size_t* count, bool sync_main);
+    void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
     void set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd);
 
@@ -120,6 +121,7 @@ private:
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
     hipEvent_t ev_h_ = nullptr, ev_fmap_[MAX_MAPS] = {};
     bool overlap_ = true;
+    bool own_wstream_ = true;
 
     std::vector<Tensor> tensors_;
     std::vector<Op> ops_;

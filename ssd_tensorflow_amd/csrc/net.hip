@@ -314,7 +314,7 @@ Net::~Net() {
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev_fmap_[i]);
     }
     if (wstream_) {
-        (void)hipStreamDestroy(wstream_);
+        if (own_wstream_) (void)hipStreamDestroy(wstream_);
         (void)hipEventDestroy(ev_dy_);
         (void)hipEventDestroy(ev_w_);
     }
@@ -385,7 +385,7 @@ void Net::backward_begin(int b, const float* y) {
     bw_done_off_ = nfilters_;
 }
 
-bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
+bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync_main) {
     const int b = bw_b_;
     const size_t hi = bw_done_off_;
     size_t lo = hi;
@@ -432,7 +432,10 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
         }
         in.done++;
     }
-    if (side_used) {        // the returned range is final in main-stream order
+    // The returned range is final in the weight-gradient stream's order.  Make it final in
+    // main-stream order too unless the caller consumes it on the weight-gradient stream itself
+    // (sync_main = false keeps the data gradients running ahead); the last stage always joins.
+    if (wstream_ && overlap_ && (side_used || bw_next_ < 0) && (sync_main || bw_next_ < 0)) {
         HIP_OK(hipEventRecord(ev_w_, wstream_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_w_, 0));
     }
@@ -442,10 +445,17 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count) {
     return bw_next_ >= 0;
 }
 
+void Net::set_wgrad_stream(hipStream_t s) {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    if (own_wstream_ && wstream_) (void)hipStreamDestroy(wstream_);
+    wstream_ = s;
+    own_wstream_ = false;
+}
+
 void Net::backward(int b, const float* y) {
     backward_begin(b, y);
     size_t off, count;
-    while (backward_step(nparams_, &off, &count)) {}
+    while (backward_step(nparams_, &off, &count, true)) {}
 }
 
 float Net::current_lr() const {

@@ -93,10 +93,15 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0):
         net.forward_backward_dev(x_dev, y_dev)
         dist.all_reduce(net.grads_flat)
     else:
+        # Collectives are enqueued behind the weight-gradient stream only: the data gradients on the
+        # current stream keep running ahead of them.  The last stage joins the two streams, after which
+        # the bias / scale tail is reduced and the current stream waits for everything.
+        side = net.use_torch_wgrad_stream()
         net.forward_dev(x_dev, y_dev)
         works = []
-        for off, cnt in net.backward_staged(y_dev, x_dev.shape[0], bucket_floats):
-            works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
+        for off, cnt in net.backward_staged(y_dev, x_dev.shape[0], bucket_floats, sync_main=False):
+            with torch.cuda.stream(side):
+                works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
         works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True))
         for w in works:
             w.wait()

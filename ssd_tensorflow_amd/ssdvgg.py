@@ -301,12 +301,21 @@ class SSDVGG:
     def forward_dev(self, x_t, y_t):
         check(lib.ssd_forward_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))
 
-    def backward_staged(self, y_t, b, min_floats):
+    def use_torch_wgrad_stream(self):
+        """Run the weight gradients on a torch-owned side stream (returned) so collectives can be enqueued
+        behind exactly that stream while the data gradients keep running on the current stream."""
+        import torch
+        if getattr(self, 'wgrad_stream', None) is None:
+            self.wgrad_stream = torch.cuda.Stream(device=self.device)
+            check(lib.ssd_set_wgrad_stream(self._h, self.wgrad_stream.cuda_stream))
+        return self.wgrad_stream
+
+    def backward_staged(self, y_t, b, min_floats, sync_main=True):
         """Generator over (offset, count) ranges of the gradient arena as backward finishes them."""
         check(lib.ssd_backward_begin_dev(self._h, y_t.data_ptr(), b))
         off = C.c_size_t(); cnt = C.c_size_t(); more = C.c_int(1)
         while more.value:
-            check(lib.ssd_backward_next_dev(self._h, int(min_floats), C.byref(off), C.byref(cnt), C.byref(more)))
+            check(lib.ssd_backward_next_dev(self._h, int(min_floats), int(sync_main), C.byref(off), C.byref(cnt), C.byref(more)))
             if cnt.value:
                 yield off.value, cnt.value
 
