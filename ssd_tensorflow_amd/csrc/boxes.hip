@@ -248,15 +248,16 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // decode (ssdutils.py:192-229) + per-class greedy NMS (ssdutils.py:232-318)
 // =================================================================================
 // Pass 1, HBM-bound: every anchor row [C+5] f32 is read exactly once through LDS (coalesced
-// float4 loads; rows are then read at an odd stride: conflict-free).  Candidates with
-// confidence >= thr are appended to the image's list as one 64-bit sort key:
-//   conf bits << 32 | (32767 - anchor) << 8 | class      (descending sort == conf desc, anchor asc)
+// float4 loads, all issued before the first is consumed; rows are then read at an odd stride:
+// conflict-free).  Every anchor gets one 64-bit sort key, 0 when its confidence is below thr:
+//   conf bits << 32 | (32767 - anchor) << 8 | 0x80 | class   (descending sort == conf desc, anchor asc)
+// No atomics: the per-image kernel compacts the non-zero keys.
 constexpr int SCAN_ROWS = 256;
 constexpr int SCAN_MAXV = 32;                       // nv <= 32
 constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
 
 __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          int A2, int* __restrict__ counts, u64* __restrict__ keys) {
+                                                          u64* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
     const size_t total_rows = (size_t)B * A;
     const size_t r0 = (size_t)blockIdx.x * SCAN_ROWS;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     __shared__ u64 lkeys[DET_LDS_KEYS];
     __shared__ unsigned char alive[DET_MAX_ALIVE];
     __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
-    __shared__ int s_npresent, s_wtot[DET_THREADS / 64], s_base;
+    __shared__ int s_npresent, s_wtot[DET_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     u64* g1 = p.keys1 + (size_t)b * p.A2;
     // ---- compact the image's candidates (non-zero keys of the dense per-anchor array) ---------
@@ -506,8 +507,6 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     // ---- compact survivors in order; the caller's [:max_out] -------------------------------
     int limit = p.out_cap;
     if (p.max_out >= 0 && p.max_out < limit) limit = p.max_out;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     int total = 0;
     for (int q0 = 0; q0 < m; q0 += DET_THREADS) {
@@ -570,7 +569,7 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                           conf_thr, A2, nullptr, dense);
+                           conf_thr, dense);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;

@@ -59,7 +59,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED, bool PF>
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_ROWS = BM / 32;                   // rows staged per thread
@@ -109,14 +109,29 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     // buffer unit returns zeros -- the zero padding costs no branch and no VALU select of data.
     constexpr bool FAST = !SMALLC && !STRIDED;
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.src), 0, FAST ? (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u) : 0u, 0x00020000);
+        const_cast<float*>(p.src), 0, (FAST || SMALLC) ? (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.wci * p.wco * 4u), 0x00020000);
     unsigned a_off[A_ROWS], a_msk[A_ROWS];
-    if constexpr (FAST) {
+    // conv1_1 (Ci = 3): k = tap*Ci + c packed into ONE k-iteration.  This thread's four k's are the
+    // same for all of its rows: their element offset from the row's pixel, tap index and validity
+    // are constants; the per-row part is the same (offset, tap mask) pair as on the fast path.
+    int sk_off[4];
+    unsigned sk_bit[4];
+    if constexpr (SMALLC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = a_c4 + e;
+            const bool kv = k < p.ntaps * p.SC;
+            const int tp = kv ? k / p.SC : 0, c = kv ? k - tp * p.SC : 0;
+            sk_off[e] = ((p.tap_dh[tp] * p.SW + p.tap_dw[tp]) * p.SC + c) * 4;
+            sk_bit[e] = kv ? (1u << tp) : 0u;
+        }
+    }
+    if constexpr (FAST || SMALLC) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            a_off[i] = (unsigned)((rb[i] + rh[i] * p.SW + rw[i]) * p.SC + a_c4) * 4u;
+            a_off[i] = (unsigned)((rb[i] + rh[i] * p.SW + rw[i]) * p.SC + (SMALLC ? 0 : a_c4)) * 4u;
             unsigned mk = 0;
             for (int t = 0; t < p.ntaps; ++t) {
                 const int sh = rh[i] + p.tap_dh[t], sw = rw[i] + p.tap_dw[t];
@@ -166,19 +181,14 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
             return;
         }
         if constexpr (SMALLC) {
-            // K = ntaps*SC (27 for conv1_1) packed k = tap*SC + c; scalar gather.
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = a_c4 + e;
-                    if (k < p.ntaps * p.SC) {
-                        const int tp = k / p.SC, c = k - tp * p.SC;
-                        const int sh = rh[i] + p.tap_dh[tp], sw = rw[i] + p.tap_dw[tp];
-                        if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW)
-                            v[e] = p.src[(size_t)(rb[i] + sh * p.SW + sw) * p.SC + c];
-                    }
+                    const unsigned m = 0u - (unsigned)((a_msk[i] & sk_bit[e]) != 0u);
+                    const unsigned off = ((a_off[i] + (unsigned)sk_off[e]) & m) | (OOB & ~m);
+                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, off, 0, 0));
                 }
                 areg[i] = v;
             }
@@ -260,31 +270,22 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     auto compute = [&](int buf) {
         const float* As = smem + buf * (A_LDS + B_LDS);
         const float* Bs = As + A_LDS;
-        f32x4 a[2][TM], b[2][TN];
-        auto load_frags = [&](int g, int slot) {
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
             const int kb = g * 8 + lh * 4;
+            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
-                a[slot][mi] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * TM + mi * 32 + li) * LDA + kb);
+                a[mi] = *reinterpret_cast<const f32x4*>(As + (wm * 32 * TM + mi * 32 + li) * LDA + kb);
             if constexpr (MODE == MODE_FWD) {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[slot][ni][t] = Bs[(kb + t) * BN + wn * 32 * TN + ni * 32 + li];
+                    for (int t = 0; t < 4; ++t) b[ni][t] = Bs[(kb + t) * BN + wn * 32 * TN + ni * 32 + li];
             } else {
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    b[slot][ni] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 * TN + ni * 32 + li) * LDA + kb);
-            }
-        };
-        if constexpr (PF) load_frags(0, 0);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            const int cur = PF ? (g & 1) : 0;
-            if constexpr (PF) {
-                if (g + 1 < BK / 8) load_frags(g + 1, (g + 1) & 1);
-            } else {
-                load_frags(g, 0);
+                    b[ni] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 * TN + ni * 32 + li) * LDA + kb);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -292,12 +293,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi][t], b[cur][ni][t], acc[mi][ni], 0, 0, 0);
-            if constexpr (PF) {
-                // pin the order: the next group's LDS reads first, then this group's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
-            }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
         }
     };
 
@@ -415,6 +411,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < Y_N; ++j) ycmask[j] = 0u - (unsigned)(n0 + cb + 32 * j < p.Co);
 
+    int wk_dh[4], wk_dw[4], wk_c[4];
+    unsigned wk_valid[4];
+    if constexpr (SMALLC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = cb + e;
+            const bool kv = k < p.ntaps * p.Ci;
+            const int tp = kv ? k / p.Ci : 0;
+            wk_dh[e] = p.tap_dh[tp]; wk_dw[e] = p.tap_dw[tp]; wk_c[e] = kv ? k - tp * p.Ci : 0;
+            wk_valid[e] = 0u - (unsigned)kv;
+        }
+    }
+
     auto load_tiles = [&](int it) {
         const int m = mbeg + it * BP + row;
         const int ow = pw, oh = ph, b = pb;
@@ -433,23 +442,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
         const unsigned rowok = 0u - (unsigned)(m < mend);
         if constexpr (SMALLC) {
+            // packed k = tap*Ci + c < 32: only chunk 0 holds data; (tap, channel) of this thread's four
+            // k's are constants (wk_*), only the pixel moves
+            f32x4 v;
 #pragma unroll
-            for (int j = 0; j < X_N; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < mend) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = cb + 32 * j + e;
-                        if (k < p.ntaps * p.Ci) {
-                            const int tp = k / p.Ci, c = k - tp * p.Ci;
-                            const int sh = oh * p.stride + p.tap_dh[tp], sw = ow * p.stride + p.tap_dw[tp];
-                            if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi)
-                                v[e] = p.x[((size_t)(b * p.Hi + sh) * p.Wi + sw) * p.Ci + c];
-                        }
-                    }
-                }
-                xreg[j] = v;
+            for (int e = 0; e < 4; ++e) {
+                const int sh = oh * p.stride + wk_dh[e], sw = ow * p.stride + wk_dw[e];
+                const unsigned m = rowok & wk_valid[e] &
+                                   (0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi)));
+                const unsigned off = (unsigned)(((b * p.Hi + sh) * p.Wi + sw) * p.Ci + wk_c[e]) * 4u;
+                v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (off & m) | (OOB & ~m), 0, 0));
             }
+            xreg[0] = v;
+#pragma unroll
+            for (int j = 1; j < X_N; ++j) xreg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const int sh = oh * p.stride + dh, sw = ow * p.stride + dw;
             const unsigned inb = 0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi));
@@ -616,11 +622,8 @@ template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
 static void launch_gather(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM * LDA + (MODE == MODE_FWD ? BK * BN : BN * LDA)) * sizeof(float);
-    static const int pf = env_int("SSD_PREFETCH", 0);
-    auto kern = pf ? conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, true>
-                   : conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, false>;
-    static bool once = (set_lds(conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, true>, lds),
-                        set_lds(conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, false>, lds), true);
+    auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED>;
+    static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
