@@ -56,6 +56,8 @@ SIGNATURES = {
     'ssd_average_precision': (i32, [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_double, vp, vp]),
     'ssd_arena_floats': (sz, [cstr, i32]),
     'ssd_create': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, C.POINTER(handle)]),
+    'ssd_create_dtype': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, i32, C.POINTER(handle)]),
+    'ssd_get_dtype': (i32, [handle, p_i32]),
     'ssd_destroy': (i32, [handle]),
     'ssd_set_stream': (i32, [handle, vp]),
     'ssd_num_variables': (i32, [handle]),
@@ -94,6 +96,11 @@ SIGNATURES = {
     'ssd_op_conv2d_dgrad': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_wgrad_ws_floats': (sz, [i32] * 13),
     'ssd_op_conv2d_wgrad': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
+    'ssd_op_cast_filter': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'ssd_op_conv2d_fwd_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),
+    'ssd_op_conv2d_dgrad_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_wgrad_bf16_ws_floats': (sz, [i32] * 13),
+    'ssd_op_conv2d_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
     'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),
     'ssd_op_maxpool_bwd': (i32, [vp, vp, vp, i32, i32] + [i32] * 10 + [vp]),
     'ssd_op_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, vp]),

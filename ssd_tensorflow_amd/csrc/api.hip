@@ -78,7 +78,7 @@ struct DevBuf {
 extern "C" {
 
 const char* ssd_last_error(void) { return ssd::get_error(); }
-const char* ssd_version(void) { return "ssdvgg_hip 0.1 gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32)"; }
+const char* ssd_version(void) { return "ssdvgg_hip 0.1 gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) bf16-mfma(v_mfma_f32_32x32x16_bf16)"; }
 
 int ssd_preset_info(const char* preset, int* image_w, int* image_h, int* num_anchors, int* num_maps) {
     API_BEGIN
@@ -276,6 +276,25 @@ int ssd_create(const char* preset, int num_classes, int max_batch, int device, i
                      ext_momentum_dev);
     SSD_REQUIRE(n->nparams() == Net::arena_floats(preset, num_classes), "arena size mismatch");
     *out = new ssd_net{n};
+    API_END
+}
+
+int ssd_create_dtype(const char* preset, int num_classes, int max_batch, int device, int training, unsigned long long seed,
+                     float* ext_params_dev, float* ext_grads_dev, float* ext_momentum_dev, int dtype, ssd_handle* out) {
+    API_BEGIN
+    SSD_REQUIRE(out != nullptr, "out handle pointer is null");
+    *out = nullptr;
+    Net* n = new Net(preset, num_classes, max_batch, device, training != 0, seed, ext_params_dev, ext_grads_dev,
+                     ext_momentum_dev, dtype);
+    SSD_REQUIRE(n->nparams() == Net::arena_floats(preset, num_classes), "arena size mismatch");
+    *out = new ssd_net{n};
+    API_END
+}
+
+int ssd_get_dtype(ssd_handle h, int* dtype) {
+    API_BEGIN
+    SSD_REQUIRE(h != nullptr && dtype != nullptr, "null argument");
+    *dtype = h->net->dtype();
     API_END
 }
 
@@ -547,6 +566,41 @@ int ssd_op_conv2d_dgrad(const float* dy, const float* w, float* dx, const float*
     API_BEGIN
     conv_dgrad(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), dy, w, dx, mask, accumulate != 0,
                (hipStream_t)stream);
+    API_END
+}
+int ssd_op_cast_filter(const float* w, void* w_io_bf16, void* w_oi_bf16, int taps, int ci, int co, void* stream) {
+    API_BEGIN
+    FilterCastPlan plan;
+    plan.add(0, taps, ci, co);
+    cast_filters(plan, w, (bf16_t*)w_io_bf16, (bf16_t*)w_oi_bf16, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_fwd_bf16(const void* x, const void* w_oi, const float* bias, void* y, int y_f32, int b, int hi, int wi, int ci,
+                           int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, int relu,
+                           void* stream) {
+    API_BEGIN
+    conv_fwd_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), (const bf16_t*)x, (const bf16_t*)w_oi, bias, y,
+                  y_f32 != 0, relu != 0, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_dgrad_bf16(const void* dy, const void* w_io, void* dx, const void* mask, int accumulate, int b, int hi, int wi,
+                             int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w,
+                             void* stream) {
+    API_BEGIN
+    conv_dgrad_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), (const bf16_t*)dy, (const bf16_t*)w_io,
+                    (bf16_t*)dx, (const bf16_t*)mask, accumulate != 0, (hipStream_t)stream);
+    API_END
+}
+size_t ssd_op_conv2d_wgrad_bf16_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                                          int dil, int pad_h, int pad_w) {
+    return conv_wgrad_bf16_ws_floats(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w));
+}
+int ssd_op_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, const float* w, float weight_decay,
+                             float* ws, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                             int dil, int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    conv_wgrad_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), (const bf16_t*)x, (const bf16_t*)dy, dw,
+                    dbias, w, weight_decay, ws, (hipStream_t)stream);
     API_END
 }
 size_t ssd_op_conv2d_wgrad_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,

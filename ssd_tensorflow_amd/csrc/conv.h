@@ -29,4 +29,35 @@ size_t conv_wgrad_ws_floats(const ConvDesc& d);
 void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias,
                 const float* w, float weight_decay, float* ws, hipStream_t s);
 
+// ---- bf16 configuration (conv_bf16.hip): bf16 activations / gradients / filter mirrors, fp32 accumulate ----
+struct bf16_t;
+
+// conv1_1 (Ci = 3) stays on the fp32 kernels: fp32 image and master filter in, bf16 out / bf16 dy in
+void conv_fwd_smallc_bf16out(const ConvDesc& d, const float* x, const float* w, const float* bias, bf16_t* y, bool relu,
+                             hipStream_t s);
+void conv_wgrad_smallc_bf16dy(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                              float weight_decay, float* ws, hipStream_t s);
+
+// One launch mirrors every layer's fp32 filter [tap][Ci][Co] as bf16 in the same order (io, the data
+// gradient's operand) and transposed [tap][Co][Ci] (oi, the forward operand), at the same offsets.
+struct FilterCastPlan {
+    static constexpr int MAX_LAYERS = 48;
+    struct Layer {
+        size_t off;
+        int taps, ci, co;
+    } L[MAX_LAYERS];
+    int n = 0;
+    void add(size_t off, int taps, int ci, int co);
+};
+void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t* oi, hipStream_t s);
+
+// y: bf16 [B,Ho,Wo,Co], or fp32 when y_f32 (the multibox heads feed the fp32 loss)
+void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
+                   hipStream_t s);
+void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
+                     hipStream_t s);
+size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d);
+void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                     float weight_decay, float* ws, hipStream_t s);
+
 }  // namespace ssd

@@ -1,0 +1,697 @@
+// im2col-free direct convolution for gfx950 (MI355X), bf16 in / fp32 accumulate on the matrix
+// cores (v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[2] ("bf16 MFMA").  Same gather-GEMM
+// formulation as conv_igemm.hip (forward and data gradient are one kernel, the weight gradient a
+// second one); what changes is how tiles reach the LDS: a bf16 MFMA retires 8x the k of the fp32
+// one per cycle, so staging through registers (address VALU + ds_write per 16 bytes) would bound the
+// kernel.  Every tile is therefore filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging
+// registers, no ds_write, zero fill of the padding by steering a lane's offset out of the buffer's
+// range (tools/probes/bf16_probe.hip pins all three behaviours on the hardware).
+//
+// LDS-DMA writes lane-linear (base + lane*16), so a tile row is exactly its bytes, unpadded; bank
+// conflicts are removed by choosing WHICH 16-byte chunk of the global row a lane fetches:
+//   gather tiles  [rows][64 k] (128-byte rows): LDS slot p of row r holds chunk p ^ ((r>>1)&7);
+//                 a ds_read_b128 lane group (16 rows, MI355X_MICROARCH.md) then covers 16 distinct slots;
+//   wgrad tiles   [64 pixels][channels] (natural NHWC rows): slot p of pixel row r holds chunk
+//                 p ^ 4*(r&3) (256-byte rows) or p ^ 4*((r>>1)&1) (128-byte rows), read by
+//                 ds_read_b64_tr_b16, which hands every lane 4 consecutive PIXELS of its channel:
+//                 the k-major MFMA operand straight from the pixel-major image, no transpose pass.
+//
+// Filters: fp32 masters live in the parameter arena; cast_filters() mirrors them per step as bf16
+// in both orientations a k-contiguous B operand needs: [tap][Co][Ci] (forward) and [tap][Ci][Co]
+// (data gradient; the arena's own HWIO order).
+#include "conv.h"
+#include "conv_detail.h"
+#include "bf16.h"
+
+namespace ssd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int HBK = 64;                 // k elements per iteration: one 128-byte line per tile row
+constexpr unsigned OOBH = 0xFFFFFFF0u;  // offset no buffer covers: the load returns / the DMA writes zeros
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct GatherArgsH {
+    const bf16_t* src;
+    const bf16_t* wgt;      // [tap][DN rows][SC k] bf16, k contiguous
+    const float* bias;
+    const bf16_t* mask;
+    void* dst;              // bf16 [M][DN], or fp32 when out_f32
+    int M, DH, DW, DN;
+    int SH, SW, SC;
+    int ntaps, mul, div;
+    int relu, accum, out_f32;
+    int NT;
+    int tap_dh[9], tap_dw[9];
+};
+
+__device__ __forceinline__ void wait_dma_and_sync() {
+    // every lane's LDS-DMA has landed (vmcnt), then the workgroup barrier publishes them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED>
+__global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_N = BM / 32, B_N = BN / 32;       // DMA instructions per thread and tile
+    constexpr int STAGE = (BM + BN) * 128;            // bytes per pipeline stage
+    constexpr int LDC = BN + 4;                       // fp32 epilogue tile pitch
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / p.NT, nt = wg - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- staging: thread -> rows (tid>>3) + 32 i, LDS slot tid&7, global chunk slot ^ swizzle(row)
+    const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;      // k element offset inside the 64-wide block
+    int rb[A_N], rh[A_N], rw[A_N];
+    unsigned a_off[A_N], a_msk[A_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.DW;
+        const int t2 = mm / p.DW;
+        const int oh = t2 % p.DH;
+        const int b = t2 / p.DH;
+        rb[i] = b * p.SH * p.SW;
+        rh[i] = m < p.M ? oh * p.mul : -(1 << 20);
+        rw[i] = ow * p.mul;
+        a_off[i] = (unsigned)((rb[i] + rh[i] * p.SW + rw[i]) * p.SC + a_ck) * 2u;
+        unsigned mk = 0;
+        if constexpr (!STRIDED) {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int sh = rh[i] + p.tap_dh[t], sw = rw[i] + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+            }
+        }
+        a_msk[i] = mk;
+    }
+    unsigned b_off[B_N], b_ok[B_N];      // byte offset of (row n, chunk) inside one tap's filter image; row inside the filter
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        b_ok[i] = 0u - (unsigned)(n < p.DN);
+        b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.SC + a_ck) * 2u;
+    }
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.DN * p.SC * 2u), 0x00020000);
+
+    const int nchunks = (p.SC + HBK - 1) / HBK;
+    const int nk = nchunks * p.ntaps;
+
+    auto issue = [&](int kiter, int stage) {
+        const int cc = kiter / p.ntaps;
+        const int tap = kiter - cc * p.ntaps;
+        unsigned char* As = smem + stage * STAGE + wave * 1024;       // wave-uniform: 8 rows x 128 B per DMA
+        unsigned char* Bs = As + BM * 128;
+        const unsigned cmask = 0u - (unsigned)(cc * HBK + a_ck < p.SC);
+        if constexpr (!STRIDED) {
+            const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * HBK) * 2);
+#pragma unroll
+            for (int i = 0; i < A_N; ++i) {
+                const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
+                const unsigned off = ((a_off[i] + toff) & m) | (OOBH & ~m);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, off, 0, 0, 0);
+            }
+        } else {
+            const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+#pragma unroll
+            for (int i = 0; i < A_N; ++i) {
+                int sh = rh[i] + dh, sw = rw[i] + dw;
+                bool ok = (sh % p.div == 0) && (sw % p.div == 0);
+                sh /= p.div;
+                sw /= p.div;
+                ok = ok && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
+                const unsigned m = (0u - (unsigned)ok) & cmask;
+                const unsigned off = ((unsigned)(((rb[i] + sh * p.SW + sw) * p.SC + cc * HBK + a_ck) * 2) & m) | (OOBH & ~m);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, off, 0, 0, 0);
+            }
+        }
+        const unsigned woff = (unsigned)((tap * p.DN * p.SC + cc * HBK) * 2);
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) {
+            const unsigned m = cmask & b_ok[i];
+            const unsigned off = ((b_off[i] + woff) & m) | (OOBH & ~m);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- accumulators: D rows = output channels (filter operand first), D cols = pixels, so a lane
+    // ends up with 4 consecutive channels of one pixel per register quad
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    // fragment address inside a stage: row*128 + ((2s + lh) ^ swz(row))*16 = (row*128 + q) ^ (s*32)
+    const int q0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int a_row = (wm * 32 * TM + li) * 128 + q0;
+    const int b_row = BM * 128 + (wn * 32 * TN + li) * 128 + q0;
+
+    auto compute = [&](int stage) {
+        const unsigned char* S = smem + stage * STAGE;
+#pragma unroll
+        for (int st = 0; st < HBK / 16; ++st) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                a[mi] = *reinterpret_cast<const bf16x8*>(S + ((a_row + mi * 4096) ^ (st * 32)));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                b[ni] = *reinterpret_cast<const bf16x8*>(S + ((b_row + ni * 4096) ^ (st * 32)));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: two stages; tile k+1 streams in while tile k is multiplied --------------
+    issue(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        wait_dma_and_sync();              // tile k visible; everyone is done reading the other stage
+        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
+        compute(k & 1);
+    }
+    __syncthreads();
+
+    // ---- epilogue through an fp32 LDS tile [BM][LDC]: full-line loads / stores, fused bias+relu
+    // (forward) or accumulate + relu mask (data gradient), one rounding to bf16
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ml = wm * 32 * TM + mi * 32 + li;
+                const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
+                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) =
+                    f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            }
+    __syncthreads();
+    constexpr int TPR = BN / 8;               // threads per row, 8 channels each
+    constexpr int RPP = 256 / TPR;            // rows per pass
+    const int cg = tid % TPR, r0 = tid / TPR;
+    const int n = n0 + cg * 8;
+    if (n >= p.DN) return;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias) ? p.bias[n + e] : 0.f;
+#pragma unroll 2
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int ml = r0 + ps * RPP;
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const size_t o = (size_t)m * p.DN + n;
+        if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += bv[e];
+                if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+        } else {
+            if (p.accum) {
+                const u32x4 old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += lo2f(old[e]);
+                    v[2 * e + 1] += hi2f(old[e]);
+                }
+            }
+            if (p.mask) {
+                const u32x4 y = *reinterpret_cast<const u32x4*>(p.mask + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = lo2f(y[e]) > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = hi2f(y[e]) > 0.f ? v[2 * e + 1] : 0.f;
+                }
+            }
+        }
+        if (p.out_f32) {
+            float* d = reinterpret_cast<float*>(p.dst) + o;
+            *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + o) =
+                u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
+    }
+}
+
+// =================================================================================
+// weight gradient:  dW[(tap, c)][n] = sum_m x[pix(m, tap)][c] * dy[m][n]      (fp32 slabs, split-M)
+// One workgroup owns (tap, channel tile, n tile, pixel split); 64 pixels per iteration.  Both
+// tiles keep their global pixel-major rows in LDS; ds_read_b64_tr_b16 transposes on the way out.
+// =================================================================================
+struct WgradArgsH {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* ws;              // [nsplit][ntaps*Ci*Co + Co]
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int ntaps, stride;
+    int CT, NT;
+    int mchunk, nsplit;
+    int tap_dh[9], tap_dw[9];
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 64;
+    constexpr int XCPR = BKT / 8, YCPR = BNT / 8;               // 16-byte chunks per pixel row
+    constexpr int XRPP = 256 / XCPR, YRPP = 256 / YCPR;         // pixel rows per DMA pass of the workgroup
+    constexpr int X_N = BP / XRPP, Y_N = BP / YRPP;             // DMA instructions per thread and tile
+    constexpr int XROWB = BKT * 2, YROWB = BNT * 2;
+    constexpr int X_LDS = BP * XROWB, STAGE = BP * (XROWB + YROWB);
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(XCPR == 8 || XCPR == 16, "channel tile 64 or 128");
+    static_assert(YCPR == 8 || YCPR == 16, "n tile 64 or 128");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = p.ntaps * p.CT * p.NT;
+    const int split = wgid / ntiles;
+    int tile = wgid - split * ntiles;
+    const int nt = tile % p.NT;
+    tile /= p.NT;
+    const int ct = tile % p.CT;
+    const int tap = tile / p.CT;
+    const int c0 = ct * BKT, n0 = nt * BNT;
+    const int mbeg = split * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int niter = (mend - mbeg + BP - 1) / BP;
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const bool do_bias = (tap == 0 && ct == 0);
+
+    // chunk swizzle of a pixel row r: 256-byte rows p ^ 4*(r&3); 128-byte rows p ^ 4*((r>>1)&1)
+    auto swz = [](int r, int cpr) { return cpr == 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
+
+    // ---- staging map -----------------------------------------------------------------------
+    const int xr = tid / XCPR, xs = tid % XCPR;          // pixel row within a pass, LDS slot
+    const int yr = tid / YCPR, ys = tid % YCPR;
+    const int xchunk = xs ^ swz(xr, XCPR);               // XRPP, YRPP are multiples of 4: the swizzle is per-thread constant
+    const int ychunk = ys ^ swz(yr, YCPR);
+    const unsigned xcm = 0u - (unsigned)(c0 + xchunk * 8 < p.Ci);
+    const unsigned ycm = 0u - (unsigned)(n0 + ychunk * 8 < p.Co);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 2u), 0x00020000);
+
+    // this thread's X_N pixel rows, advanced by BP pixels per iteration (issue() runs for it = 0, 1, 2, ...)
+    int pw[X_N], ph[X_N], pb[X_N];
+#pragma unroll
+    for (int j = 0; j < X_N; ++j) {
+        const int m = mbeg + xr + j * XRPP;
+        pw[j] = m % p.Wo;
+        const int t2 = m / p.Wo;
+        ph[j] = t2 % p.Ho;
+        pb[j] = t2 / p.Ho;
+    }
+
+    auto issue = [&](int it, int stage) {
+        unsigned char* Xs = smem + stage * STAGE + wave * 1024;
+        unsigned char* Ys = smem + stage * STAGE + X_LDS + wave * 1024;
+        const int mb = mbeg + it * BP;
+#pragma unroll
+        for (int j = 0; j < X_N; ++j) {
+            const int m = mb + xr + j * XRPP;
+            const int sh = ph[j] * p.stride + dh, sw = pw[j] * p.stride + dw;
+            const unsigned mk = xcm & (0u - (unsigned)(m < mend)) &
+                                (0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi)));
+            const unsigned off = (unsigned)((((pb[j] * p.Hi + sh) * p.Wi + sw) * p.Ci + c0 + xchunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (off & mk) | (OOBH & ~mk), 0, 0, 0);
+            if (p.Wo >= BP) {
+                pw[j] += BP;
+                if (pw[j] >= p.Wo) {
+                    pw[j] -= p.Wo;
+                    if (++ph[j] == p.Ho) { ph[j] = 0; ++pb[j]; }
+                }
+            } else {
+                const int m2 = m + BP;
+                pw[j] = m2 % p.Wo;
+                const int t2 = m2 / p.Wo;
+                ph[j] = t2 % p.Ho;
+                pb[j] = t2 / p.Ho;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < Y_N; ++j) {
+            const int m = mb + yr + j * YRPP;
+            const unsigned mk = ycm & (0u - (unsigned)(m < mend));
+            const unsigned off = (unsigned)((m * p.Co + n0 + ychunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (off & mk) | (OOBH & ~mk), 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    // transpose-read addressing (bf16_probe.hip): inside a 16-lane group lane q supplies the 8 bytes at
+    // (pixel row q>>2, channel quad q&3); lane l receives, for j = 0..3, pixel row j of channel l&15.
+    // Two reads (pixel rows +0..3, +4..7) give the lane k = 8*lh .. 8*lh+7 of channel tile row lane&31.
+    const int q = lane & 15, cb = (lane >> 4) & 1;
+    const int prow = lh * 8 + (q >> 2);                   // pixel row of this lane's address (first read)
+    int xa[TM], ya[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int ch = (wm * 32 * TM + mi * 32) / 8 + cb * 2 + ((q >> 1) & 1);
+        xa[mi] = prow * XROWB + ((ch ^ swz(prow, XCPR)) * 16) + (q & 1) * 8;
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int ch = (wn * 32 * TN + ni * 32) / 8 + cb * 2 + ((q >> 1) & 1);
+        ya[ni] = X_LDS + prow * YROWB + ((ch ^ swz(prow, YCPR)) * 16) + (q & 1) * 8;
+    }
+
+    auto compute = [&](int stage) {
+        const unsigned char* S = smem + stage * STAGE;
+#pragma unroll
+        for (int st = 0; st < BP / 16; ++st) {
+            s16x8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                // rows +4: (r&3) and ((r>>1)&1 for +4 -> flips) -- the 128-byte-row swizzle depends on bit 1 of the
+                // row only, and +4 leaves bit 1 unchanged; the 256-byte-row swizzle depends on r&3, unchanged too
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + xa[mi] + (st * 16) * XROWB));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + xa[mi] + (st * 16 + 4) * XROWB));
+                a[mi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + ya[ni] + (st * 16) * YROWB));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + ya[ni] + (st * 16 + 4) * YROWB));
+                b[ni] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
+                                                                         __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
+        if (do_bias && tid < BNT) {
+            // column sums of dy for the bias gradient, from the same LDS tile (channel tid of every pixel row)
+            const unsigned char* Ys = S + X_LDS;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BP; ++r) {
+                const int slot = (tid >> 3) ^ swz(r, YCPR);
+                s += bf2f(*reinterpret_cast<const unsigned short*>(Ys + r * YROWB + slot * 16 + (tid & 7) * 2));
+            }
+            bsum += s;
+        }
+    };
+
+    if (niter > 0) issue(0, 0);
+    for (int it = 0; it < niter; ++it) {
+        wait_dma_and_sync();
+        if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+        compute(it & 1);
+    }
+
+    const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c0 + kl >= p.Ci) continue;
+                slab[((size_t)tap * p.Ci + c0 + kl) * p.Co + n] = acc[mi][ni][r];
+            }
+        }
+    }
+    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+}
+
+// =================================================================================
+// filter mirrors: fp32 [tap][Ci][Co] -> bf16 [tap][Ci][Co] and bf16 [tap][Co][Ci], all layers in one launch
+// =================================================================================
+struct CastTable {
+    int n;
+    struct Seg {
+        unsigned long long off;     // element offset of the layer's filter in all three arrays
+        int taps, ci, co;
+        int cit, cot;               // 32x32 tiles per tap
+        int blk0;                   // first block of this layer
+    } seg[FilterCastPlan::MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(256) void cast_filters_kernel(CastTable t, const float* __restrict__ w, bf16_t* __restrict__ io,
+                                                           bf16_t* __restrict__ oi) {
+    __shared__ float tile[32][33];
+    int s = 0;
+    while (s + 1 < t.n && (int)blockIdx.x >= t.seg[s + 1].blk0) ++s;
+    const CastTable::Seg g = t.seg[s];
+    int b = blockIdx.x - g.blk0;
+    const int cot = b % g.cot;
+    b /= g.cot;
+    const int cit = b % g.cit;
+    const int tap = b / g.cit;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t base = g.off + (size_t)tap * g.ci * g.co;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = cit * 32 + r, co = cot * 32 + tx;
+        float v = 0.f;
+        if (ci < g.ci && co < g.co) {
+            v = w[base + (size_t)ci * g.co + co];
+            io[base + (size_t)ci * g.co + co].v = f2bf(v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = cot * 32 + r, ci = cit * 32 + tx;
+        if (ci < g.ci && co < g.co) oi[base + (size_t)co * g.ci + ci].v = f2bf(tile[tx][r]);
+    }
+}
+
+void FilterCastPlan::add(size_t off, int taps, int ci, int co) {
+    SSD_REQUIRE(n < MAX_LAYERS, "too many conv layers for the filter cast table");
+    L[n].off = off; L[n].taps = taps; L[n].ci = ci; L[n].co = co;
+    ++n;
+}
+
+void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t* oi, hipStream_t s) {
+    CastTable t{};
+    t.n = plan.n;
+    int blk = 0;
+    double elems = 0;
+    for (int i = 0; i < plan.n; ++i) {
+        t.seg[i].off = plan.L[i].off; t.seg[i].taps = plan.L[i].taps; t.seg[i].ci = plan.L[i].ci; t.seg[i].co = plan.L[i].co;
+        t.seg[i].cit = cdiv(plan.L[i].ci, 32); t.seg[i].cot = cdiv(plan.L[i].co, 32);
+        t.seg[i].blk0 = blk;
+        blk += plan.L[i].taps * t.seg[i].cit * t.seg[i].cot;
+        elems += (double)plan.L[i].taps * plan.L[i].ci * plan.L[i].co;
+    }
+    if (blk == 0) return;
+    ProfScope prof("cast_filters", 0.0, 8.0 * elems, s);
+    hipLaunchKernelGGL(cast_filters_kernel, dim3(blk), dim3(256), 0, s, t, w, io, oi);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// host launchers
+// =================================================================================
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED>
+static void launch_gather_h(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t stages = 2 * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t lds = stages > ctile ? stages : ctile;
+    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    const int MT = cdiv(a.M, BM);
+    a.NT = cdiv(a.DN, BN);
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+static void check_desc_h(const ConvDesc& d) {
+    SSD_REQUIRE(d.KH * d.KW <= 9 && d.KH * d.KW >= 1, "conv: at most 9 taps (got %dx%d)", d.KH, d.KW);
+    SSD_REQUIRE(d.Co % 8 == 0 && d.Ci % 8 == 0, "bf16 conv: Ci and Co must be multiples of 8 (got %d, %d)", d.Ci, d.Co);
+    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 31) && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 31),
+                "conv: tensor too large for 32-bit byte offsets");
+}
+
+// 0: 128x128  1: 128x64  2: 64x128 (pixels x channels)  3: 256x128
+static int pick_tile_h(long long M, int N, int mode) {
+    static const int forced = env_int("SSD_TILE_BF16", -1);      // tuning override
+    if (forced >= 0 && forced < 4) return forced;
+    static const int bm[4] = {128, 128, 64, 256}, bn[4] = {128, 64, 128, 128};
+    static const double eff[4] = {1.0, 0.85, 0.85, 0.0};          // 256x128: opt-in until measured
+    int best = 0;
+    double bc = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        if (eff[c] <= 0.0) continue;
+        const long long wgs = (long long)cdiv(M, bm[c]) * cdiv(N, bn[c]);
+        const double cost = (double)((wgs + 511) / 512) * bm[c] * bn[c] / eff[c];      // 2 workgroups per CU
+        if (cost < bc * 0.999) { bc = cost; best = c; }
+    }
+    return best;
+}
+
+void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
+                   hipStream_t s) {
+    check_desc_h(d);
+    GatherArgsH a{};
+    a.src = x; a.wgt = w_oi; a.bias = bias; a.mask = nullptr; a.dst = y;
+    a.M = d.B * d.Ho * d.Wo; a.DH = d.Ho; a.DW = d.Wo; a.DN = d.Co;
+    a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
+    a.ntaps = d.KH * d.KW; a.mul = d.stride; a.div = 1;
+    a.relu = relu; a.accum = 0; a.out_f32 = y_f32;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+    const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+    switch (pick_tile_h(a.M, a.DN, MODE_FWD)) {
+    case 0: launch_gather_h<MODE_FWD, 2, 2, 2, 2, false>(a, "conv_fwd_bf16_128x128", fl, by, s); break;
+    case 1: launch_gather_h<MODE_FWD, 4, 1, 1, 2, false>(a, "conv_fwd_bf16_128x64", fl, by, s); break;
+    case 2: launch_gather_h<MODE_FWD, 2, 2, 1, 2, false>(a, "conv_fwd_bf16_64x128", fl, by, s); break;
+    default: launch_gather_h<MODE_FWD, 2, 2, 4, 2, false>(a, "conv_fwd_bf16_256x128", fl, by, s); break;
+    }
+}
+
+void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
+                     hipStream_t s) {
+    check_desc_h(d);
+    GatherArgsH a{};
+    a.src = dy; a.wgt = w_io; a.bias = nullptr; a.mask = mask; a.dst = dx;
+    a.M = d.B * d.Hi * d.Wi; a.DH = d.Hi; a.DW = d.Wi; a.DN = d.Ci;
+    a.SH = d.Ho; a.SW = d.Wo; a.SC = d.Co;
+    a.ntaps = d.KH * d.KW; a.mul = 1; a.div = d.stride;
+    a.relu = 0; a.accum = accumulate; a.out_f32 = 0;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = d.pad_h - kh * d.dil;
+            a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
+        }
+    const double fl = conv_flops(d), by = 2.0 * (conv_elems(d) + (mask ? (double)d.B * d.Hi * d.Wi * d.Ci : 0.0));
+    if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
+        launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
+        return;
+    }
+    switch (pick_tile_h(a.M, a.DN, MODE_DGRAD)) {
+    case 0: launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false>(a, "conv_dgrad_bf16_128x128", fl, by, s); break;
+    case 1: launch_gather_h<MODE_DGRAD, 4, 1, 1, 2, false>(a, "conv_dgrad_bf16_128x64", fl, by, s); break;
+    case 2: launch_gather_h<MODE_DGRAD, 2, 2, 1, 2, false>(a, "conv_dgrad_bf16_64x128", fl, by, s); break;
+    default: launch_gather_h<MODE_DGRAD, 2, 2, 4, 2, false>(a, "conv_dgrad_bf16_256x128", fl, by, s); break;
+    }
+}
+
+// ---- wgrad planning -------------------------------------------------------------------
+struct WgradPlanH {
+    int cfg;        // (channels x n) 0: 128x128, 1: 64x64, 2: 64x128, 3: 128x64
+    int bkt, bnt, CT, NT, tiles, nsplit, mchunk;
+};
+
+static WgradPlanH plan_wgrad_h(const ConvDesc& d) {
+    WgradPlanH p{};
+    const int M = d.B * d.Ho * d.Wo;
+    const int waste128 = cdiv(d.Co, 128) * 128 - d.Co, waste64 = cdiv(d.Co, 64) * 64 - d.Co;
+    if (d.Ci <= 64 && d.Co <= 64) p.cfg = 1;
+    else if (d.Ci <= 64) p.cfg = 2;
+    else if (waste64 < waste128) p.cfg = 3;      // fused heads: Co = 104 / 152
+    else p.cfg = 0;
+    static const int forced = env_int("SSD_WGRAD_CFG_BF16", -1);      // tuning override
+    if (forced >= 0 && forced < 4) p.cfg = forced;
+    p.bkt = (p.cfg == 0 || p.cfg == 3) ? 128 : 64;
+    p.bnt = (p.cfg == 1 || p.cfg == 3) ? 64 : 128;
+    p.CT = cdiv(d.Ci, p.bkt);
+    p.NT = cdiv(d.Co, p.bnt);
+    p.tiles = d.KH * d.KW * p.CT * p.NT;
+    int want = cdiv(1536, p.tiles);
+    if (want > 256) want = 256;          // the reduce pass reads every slab: keep it short
+    int maxs = cdiv(M, 512);
+    p.nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);
+    if (p.nsplit < 1) p.nsplit = 1;
+    p.mchunk = cdiv(cdiv(M, p.nsplit), 64) * 64;
+    p.nsplit = cdiv(M, p.mchunk);
+    return p;
+}
+
+size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
+    WgradPlanH p = plan_wgrad_h(d);
+    return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_wgrad_h(WgradArgsH& a, const WgradPlanH& pl, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)64 * (BKT + BNT) * 2;
+    auto kern = conv_wgrad_bf16_kernel<WM, WN, TM, TN>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit * pl.tiles), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                     float weight_decay, float* ws, hipStream_t s) {
+    check_desc_h(d);
+    WgradPlanH pl = plan_wgrad_h(d);
+    WgradArgsH a{};
+    a.x = x; a.dy = dy; a.ws = ws;
+    a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
+    a.ntaps = d.KH * d.KW; a.stride = d.stride; a.CT = pl.CT; a.NT = pl.NT;
+    a.mchunk = pl.mchunk; a.nsplit = pl.nsplit;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+    const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+    if (pl.cfg == 1) launch_wgrad_h<2, 2, 1, 1>(a, pl, "conv_wgrad_bf16_64x64", fl, by, s);
+    else if (pl.cfg == 2) launch_wgrad_h<2, 2, 1, 2>(a, pl, "conv_wgrad_bf16_64x128", fl, by, s);
+    else if (pl.cfg == 3) launch_wgrad_h<2, 2, 2, 1>(a, pl, "conv_wgrad_bf16_128x64", fl, by, s);
+    else launch_wgrad_h<2, 2, 2, 2>(a, pl, "conv_wgrad_bf16_128x128", fl, by, s);
+    wgrad_reduce(ws, pl.nsplit, (size_t)a.ntaps * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+}
+
+}  // namespace ssd

@@ -23,13 +23,10 @@
 // Global->LDS goes through registers (the gather needs zero fill), issued one
 // k-iteration ahead of the MFMAs that consume it (two LDS buffers, one barrier / iter).
 #include "conv.h"
-#include <cstdlib>
+#include "conv_detail.h"
+#include "bf16.h"
 
 namespace ssd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDA = 36;
@@ -50,16 +47,10 @@ struct GatherArgs {
     int tap_dh[9], tap_dw[9];
 };
 
-// XCD-aware bijective remap: workgroup b runs on XCD b % 8; give every XCD a
-// contiguous run of tiles so neighbouring tiles share one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nb) {
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
+// OBF: the output tensor is bf16 (conv1_1 of the bf16 configuration: fp32 image and filter in, bf16 out)
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED, bool OBF = false>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_ROWS = BM / 32;                   // rows staged per thread
@@ -331,7 +322,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
                     if (p.accum) v += p.dst[o];
                     if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
                 }
-                p.dst[o] = v;
+                if constexpr (OBF) reinterpret_cast<unsigned short*>(p.dst)[o] = f2bf(v);
+                else p.dst[o] = v;
             }
         }
     }
@@ -355,7 +347,8 @@ struct WgradArgs {
     int tap_dh[9], tap_dw[9];
 };
 
-template <int WM, int WN, int TM, int TN, bool SMALLC>
+// YBF: dy is bf16 (conv1_1 of the bf16 configuration; x stays the fp32 image)
+template <int WM, int WN, int TM, int TN, bool SMALLC, bool YBF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 32;
     // staging map: thread -> ONE pixel row (tid >> 3) and the 16-byte chunks (tid & 7) + 8*j of it,
@@ -402,8 +395,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     // tensor are steered to an out-of-range offset, for which the buffer unit returns zeros
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * (YBF ? 2u : 4u)), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned xcmask[X_N], ycmask[Y_N];
 #pragma unroll
@@ -466,11 +459,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                 xreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ((base + 128u * j) & mk) | (OOB & ~mk), 0, 0));
             }
         }
-        const unsigned ybase = (unsigned)(m * p.Co + n0 + cb) * 4u;
+        const unsigned ybase = (unsigned)(m * p.Co + n0 + cb) * (YBF ? 2u : 4u);
 #pragma unroll
         for (int j = 0; j < Y_N; ++j) {
             const unsigned mk = rowok & ycmask[j];
-            yreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ((ybase + 128u * j) & mk) | (OOB & ~mk), 0, 0));
+            if constexpr (YBF) {
+                const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(y_rsrc, ((ybase + 64u * j) & mk) | (OOB & ~mk), 0, 0));
+                yreg[j] = f32x4{lo2f(w[0]), hi2f(w[0]), lo2f(w[1]), hi2f(w[1])};
+            } else {
+                yreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ((ybase + 128u * j) & mk) | (OOB & ~mk), 0, 0));
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -608,21 +606,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
 // =================================================================================
 // host launchers
 // =================================================================================
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-template <typename K>
-static void set_lds(K kern, size_t bytes) {
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-}
-
-template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED>
+template <int MODE, int WM, int WN, int TM, int TN, bool SMALLC, bool STRIDED, bool OBF = false>
 static void launch_gather(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM * LDA + (MODE == MODE_FWD ? BK * BN : BN * LDA)) * sizeof(float);
-    auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED>;
+    auto kern = conv_gather_kernel<MODE, WM, WN, TM, TN, SMALLC, STRIDED, OBF>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
@@ -632,12 +620,7 @@ static void launch_gather(GatherArgs& a, const char* label, double flops, double
     HIP_OK(hipGetLastError());
 }
 
-// algorithmic work of one conv pass (forward, dgrad or wgrad alike): 2*M*N*K, and the bytes a
-// pass must move at least once (activations in + out, the filter)
-static double conv_flops(const ConvDesc& d) { return 2.0 * d.B * d.Ho * d.Wo * (double)d.Co * d.Ci * d.KH * d.KW; }
-static double conv_bytes(const ConvDesc& d) {
-    return 4.0 * ((double)d.B * d.Hi * d.Wi * d.Ci + (double)d.B * d.Ho * d.Wo * d.Co + (double)d.KH * d.KW * d.Ci * d.Co);
-}
+static double conv_bytes(const ConvDesc& d) { return 4.0 * conv_elems(d); }
 
 static void check_desc(const ConvDesc& d) {
     SSD_REQUIRE(d.KH * d.KW <= 9 && d.KH * d.KW >= 1, "conv: at most 9 taps (got %dx%d)", d.KH, d.KW);
@@ -668,10 +651,11 @@ static int pick_tile(long long M, int N, int mode) {
     return best;
 }
 
-void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s) {
+static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, const float* bias, void* y, bool y_bf16, bool relu,
+                         hipStream_t s) {
     check_desc(d);
     GatherArgs a{};
-    a.src = x; a.wgt = w; a.bias = bias; a.mask = nullptr; a.dst = y;
+    a.src = x; a.wgt = w; a.bias = bias; a.mask = nullptr; a.dst = static_cast<float*>(y);
     a.M = d.B * d.Ho * d.Wo; a.DH = d.Ho; a.DW = d.Wo; a.DN = d.Co;
     a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
     a.ntaps = d.KH * d.KW; a.mul = d.stride; a.div = 1;
@@ -683,8 +667,10 @@ void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bi
         }
     const bool smallc = d.Ci % 4 != 0;
     const double fl = conv_flops(d), by = conv_bytes(d);
+    SSD_REQUIRE(!y_bf16 || smallc, "bf16 output from fp32 input: only the packed small-C layer (conv1_1)");
     if (smallc) {
-        launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
+        if (y_bf16) launch_gather<MODE_FWD, 4, 1, 1, 2, true, false, true>(a, "conv_fwd_smallc_128x64_bf16out", fl, by, s);
+        else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
         return;
     }
     switch (pick_tile(a.M, a.DN, MODE_FWD)) {
@@ -693,6 +679,15 @@ void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bi
     case 2: launch_gather<MODE_FWD, 2, 2, 1, 2, false, false>(a, "conv_fwd_64x128", fl, by, s); break;
     default: launch_gather<MODE_FWD, 2, 2, 1, 1, false, false>(a, "conv_fwd_64x64", fl, by, s); break;
     }
+}
+
+void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s) {
+    conv_fwd_any(d, x, w, bias, y, false, relu, s);
+}
+
+void conv_fwd_smallc_bf16out(const ConvDesc& d, const float* x, const float* w, const float* bias, bf16_t* y, bool relu,
+                             hipStream_t s) {
+    conv_fwd_any(d, x, w, bias, y, true, relu, s);
 }
 
 void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* mask, bool accumulate,
@@ -766,11 +761,11 @@ size_t conv_wgrad_ws_floats(const ConvDesc& d) {
     return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
 }
 
-template <int WM, int WN, int TM, int TN, bool SMALLC>
+template <int WM, int WN, int TM, int TN, bool SMALLC, bool YBF = false>
 static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(32 * BKT + 32 * BNT) * sizeof(float);
-    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, SMALLC>;
+    auto kern = conv_wgrad_kernel<WM, WN, TM, TN, SMALLC, YBF>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
@@ -778,12 +773,27 @@ static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, const char* label, d
     HIP_OK(hipGetLastError());
 }
 
-void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
-                float weight_decay, float* ws, hipStream_t s) {
+void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
+                  hipStream_t s) {
+    const size_t total = wcount + Co;
+    int blocks = cdiv((long long)total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    ProfScope prof("wgrad_reduce", 0.0, 4.0 * (double)total * (nsplit + 2), s);
+    if (nsplit >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(cdiv((long long)total, 64)), dim3(256), 0, s, ws, nsplit, wcount, Co,
+                           dw, db, w, wd);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nsplit, wcount, Co, dw, db, w, wd);
+    HIP_OK(hipGetLastError());
+}
+
+static void conv_wgrad_any(const ConvDesc& d, const float* x, const void* dy, bool dy_bf16, float* dw, float* dbias,
+                           const float* w, float weight_decay, float* ws, hipStream_t s) {
     check_desc(d);
     WgradPlan pl = plan_wgrad(d);
+    SSD_REQUIRE(!dy_bf16 || pl.smallc, "bf16 dy with fp32 x: only the packed small-C layer (conv1_1)");
     WgradArgs a{};
-    a.x = x; a.dy = dy; a.ws = ws;
+    a.x = x; a.dy = static_cast<const float*>(dy); a.ws = ws;
     a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
     a.ntaps = d.KH * d.KW; a.stride = d.stride; a.CT = pl.CT; a.NT = pl.NT;
     a.mchunk = pl.mchunk; a.nsplit = pl.nsplit;
@@ -794,24 +804,24 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const double fl = conv_flops(d), by = conv_bytes(d);
-    if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
+    if (pl.smallc && dy_bf16) launch_wgrad<2, 2, 1, 1, true, true>(a, pl, "conv_wgrad_smallc_64x64_bf16dy", fl, by, s);
+    else if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
     else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, "conv_wgrad_64x64", fl, by, s);
     else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, "conv_wgrad_64x128", fl, by, s);
     else if (pl.cfg == 3) launch_wgrad<2, 2, 2, 1, false>(a, pl, "conv_wgrad_128x64", fl, by, s);
     else launch_wgrad<2, 2, 2, 2, false>(a, pl, "conv_wgrad_128x128", fl, by, s);
 
-    const size_t wcount = (size_t)a.ntaps * d.Ci * d.Co;
-    const size_t total = wcount + d.Co;
-    int blocks = cdiv((long long)total, 256 * 4);
-    if (blocks > 2048) blocks = 2048;
-    ProfScope prof("wgrad_reduce", 0.0, 4.0 * (double)total * (pl.nsplit + 2), s);
-    if (pl.nsplit >= 32)
-        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(cdiv((long long)total, 64)), dim3(256), 0, s, ws, pl.nsplit, wcount,
-                           d.Co, dw, dbias, w, weight_decay);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, pl.nsplit, wcount, d.Co, dw, dbias, w,
-                           weight_decay);
-    HIP_OK(hipGetLastError());
+    wgrad_reduce(ws, pl.nsplit, (size_t)a.ntaps * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+}
+
+void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
+                float weight_decay, float* ws, hipStream_t s) {
+    conv_wgrad_any(d, x, dy, false, dw, dbias, w, weight_decay, ws, s);
+}
+
+void conv_wgrad_smallc_bf16dy(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                              float weight_decay, float* ws, hipStream_t s) {
+    conv_wgrad_any(d, x, dy, true, dw, dbias, w, weight_decay, ws, s);
 }
 
 }  // namespace ssd

@@ -6,6 +6,7 @@
 #include "conv.h"
 #include "ops.h"
 #include "boxes.h"
+#include "bf16.h"
 #include <string>
 #include <vector>
 #include <map>
@@ -18,9 +19,15 @@ struct Tensor {
     bool relu_out = false;   // produced by conv+relu: gradients written into it get the relu mask
     int consumers = 0;       // ops reading it in forward
     int done = 0;            // backward bookkeeping
-    float* data = nullptr;
-    float* grad = nullptr;
+    bool data_f32 = true;    // storage of data: fp32, or bf16 (bf16 configuration, every tensor but the image and the head outputs)
+    bool grad_f32 = true;    // storage of grad
+    void* data = nullptr;
+    void* grad = nullptr;
     size_t per_image() const { return (size_t)H * W * C; }
+    const float* f() const { return static_cast<const float*>(data); }
+    float* gf() const { return static_cast<float*>(grad); }
+    const bf16_t* h() const { return static_cast<const bf16_t*>(data); }
+    bf16_t* gh() const { return static_cast<bf16_t*>(grad); }
 };
 
 enum OpKind { OP_CONV, OP_POOL, OP_L2NORM };
@@ -50,8 +57,10 @@ struct Variable {
 
 class Net {
 public:
+    // dtype 0: fp32 everywhere (BASELINE.json configs[1]); 1: bf16 activations / gradients / filter mirrors with fp32
+    // master weights, fp32 accumulation and fp32 loss (configs[2])
     Net(const char* preset, int num_classes, int max_batch, int device, bool training, unsigned long long seed,
-        float* ext_params, float* ext_grads, float* ext_momentum);
+        float* ext_params, float* ext_grads, float* ext_momentum, int dtype = 0);
     ~Net();
 
     static size_t arena_floats(const char* preset, int num_classes);
@@ -91,6 +100,7 @@ public:
     int nvars() const { return C_ + 5; }
     int max_batch() const { return Bmax_; }
     bool training() const { return training_; }
+    int dtype() const { return bf16_ ? 1 : 0; }
     int device() const { return device_; }
     float* params() { return params_; }
     float* grads() { return grads_; }
@@ -115,6 +125,9 @@ private:
     const Preset* preset_;
     int C_, Bmax_, device_;
     bool training_;
+    bool bf16_ = false;
+    bf16_t *wq_io_ = nullptr, *wq_oi_ = nullptr;     // bf16 mirrors of the filter region: [tap][Ci][Co] and [tap][Co][Ci]
+    FilterCastPlan cast_plan_;
     hipStream_t stream_ = nullptr;
     hipStream_t wstream_ = nullptr;        // side stream of the weight gradients (SSD_OVERLAP_WGRAD=0 disables)
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;

@@ -6,7 +6,8 @@
 
 namespace ssd {
 
-static int round4(int n) { return (n + 3) / 4 * 4; }
+// fused head width: a multiple of 8 channels = whole 16-byte pieces in fp32 and in bf16 rows
+static int round8(int n) { return (n + 7) / 8 * 8; }
 
 // ---------------------------------------------------------------------------------
 // graph (ssdvgg.py:190-372)
@@ -113,7 +114,7 @@ void Net::build_graph() {
     for (int i = 0; i < p.nmaps; ++i) {
         SSD_REQUIRE(tensors_[fmaps[i]].H == p.map_size[i], "feature map %d is %d, preset says %d", i, tensors_[fmaps[i]].H,
                     p.map_size[i]);
-        const int co = round4(p.ntypes[i] * nv);
+        const int co = round8(p.ntypes[i] * nv);
         const int t = conv("heads/map" + std::to_string(i), co, 3, 1, PAD_SAME, 1, false, i, fmaps[i]);
         head_t_.push_back(t);
         heads_.hw[i] = p.map_size[i] * p.map_size[i];
@@ -122,6 +123,12 @@ void Net::build_graph() {
         heads_.off[i] = p.off[i];
     }
     heads_.off[p.nmaps] = p.off[p.nmaps];
+    heads_.grad_bf16 = bf16_ ? 1 : 0;
+    if (bf16_) {
+        for (size_t i = 0; i < tensors_.size(); ++i) tensors_[i].data_f32 = tensors_[i].grad_f32 = false;
+        tensors_[input_t_].data_f32 = true;                 // the image is consumed as fed (fp32)
+        for (int t : head_t_) tensors_[t].data_f32 = true;   // the loss reads fp32 logits / offsets
+    }
 
     // ---- arena layout: all filters (forward order), all biases, the l2-norm scale ----
     size_t off = 0;
@@ -131,6 +138,8 @@ void Net::build_graph() {
             off += (size_t)op.KH * op.KW * tensors_[op.in].C * tensors_[op.out].C;
         }
     nfilters_ = off;
+    for (auto& op : ops_)
+        if (op.kind == OP_CONV) cast_plan_.add(op.w_off, op.KH * op.KW, tensors_[op.in].C, tensors_[op.out].C);
     for (auto& op : ops_)
         if (op.kind == OP_CONV) {
             op.b_off = off;
@@ -179,7 +188,7 @@ size_t Net::arena_floats(const char* preset, int num_classes) {
     cv(1, 256, 128); cv(3, 128, 256);
     if (p.nmaps >= 7) { cv(1, 256, 128); cv(3, 128, 256); }
     static const int fch[] = {512, 1024, 512, 256, 256, 256, 256};
-    for (int i = 0; i < p.nmaps; ++i) cv(3, fch[i], round4(p.ntypes[i] * nv));
+    for (int i = 0; i < p.nmaps; ++i) cv(3, fch[i], round8(p.ntypes[i] * nv));
     return n + 512;
 }
 
@@ -210,15 +219,20 @@ void Net::alloc() {
     for (size_t i = 0; i < tensors_.size(); ++i) {
         Tensor& t = tensors_[i];
         if ((int)i == input_t_) continue;
-        t.data = (float*)dalloc(t.per_image() * B * sizeof(float));
+        t.data = dalloc(t.per_image() * B * (t.data_f32 ? 4 : 2));
+        HIP_OK(hipMemset(t.data, 0, t.per_image() * B * (t.data_f32 ? 4 : 2)));
         if (training_) {
-            t.grad = (float*)dalloc(t.per_image() * B * sizeof(float));
-            HIP_OK(hipMemset(t.grad, 0, t.per_image() * B * sizeof(float)));   // head pad columns stay 0 forever
+            t.grad = dalloc(t.per_image() * B * (t.grad_f32 ? 4 : 2));
+            HIP_OK(hipMemset(t.grad, 0, t.per_image() * B * (t.grad_f32 ? 4 : 2)));   // head pad columns stay 0 forever
         }
     }
     for (int i = 0; i < heads_.nmaps; ++i) {
-        heads_.buf[i] = tensors_[head_t_[i]].data;
+        heads_.buf[i] = static_cast<float*>(tensors_[head_t_[i]].data);
         heads_.dbuf[i] = tensors_[head_t_[i]].grad;
+    }
+    if (bf16_) {
+        wq_io_ = (bf16_t*)dalloc(nfilters_ * 2);
+        wq_oi_ = (bf16_t*)dalloc(nfilters_ * 2);
     }
     if (!params_) { params_ = (float*)dalloc(nparams_ * sizeof(float)); own_params_ = true; }
     if (training_) {
@@ -229,7 +243,10 @@ void Net::alloc() {
         size_t ws = 0;
         for (auto& op : ops_)
             if (op.kind == OP_CONV)
-                for (int b : {1, B}) ws = std::max(ws, conv_wgrad_ws_floats(conv_desc(op, b)));
+                for (int b : {1, B}) {
+                    const ConvDesc d = conv_desc(op, b);
+                    ws = std::max(ws, (bf16_ && d.Ci % 8 == 0) ? conv_wgrad_bf16_ws_floats(d) : conv_wgrad_ws_floats(d));
+                }
         wgrad_ws_ = (float*)dalloc(ws * sizeof(float));
         l2_ws_ = (float*)dalloc(l2norm_bwd_ws_floats(B * 64 * 64, 512) * sizeof(float));
         size_t pws = 0;
@@ -283,8 +300,9 @@ void Net::init_weights(unsigned long long seed) {
 }
 
 Net::Net(const char* preset, int num_classes, int max_batch, int device, bool training, unsigned long long seed,
-         float* ext_params, float* ext_grads, float* ext_momentum)
-    : preset_(&get_preset(preset)), C_(num_classes), Bmax_(max_batch), device_(device), training_(training) {
+         float* ext_params, float* ext_grads, float* ext_momentum, int dtype)
+    : preset_(&get_preset(preset)), C_(num_classes), Bmax_(max_batch), device_(device), training_(training), bf16_(dtype == 1) {
+    SSD_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (fp32) or 1 (bf16), got %d", dtype);
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27 (got %d)", num_classes);
     SSD_REQUIRE(max_batch >= 1, "max_batch must be >= 1");
     HIP_OK(hipSetDevice(device));
@@ -330,30 +348,45 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     g_prof = &prof_;
     bool heads_on_side = false;
     tensors_[input_t_].data = const_cast<float*>(x);
+    if (bf16_) {
+        // the fp32 masters may have been updated by the optimizer, a variable load or the caller (external
+        // arena): refresh both bf16 filter mirrors, one launch
+        prof_.layer = "filters";
+        cast_filters(cast_plan_, params_, wq_io_, wq_oi_, stream_);
+    }
     for (const Op& op : ops_) {
         const Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
         prof_.layer = op.name.c_str();
         switch (op.kind) {
-        case OP_CONV:
+        case OP_CONV: {
+            hipStream_t cs = stream_;
             if (op.head >= 0 && hstream_ && overlap_) {
                 // the multibox heads hang off the trunk: they run on a side stream behind their feature
                 // map and fill the CUs the trunk's kernels leave idle between waves of workgroups
                 HIP_OK(hipEventRecord(ev_fmap_[op.head], stream_));
                 HIP_OK(hipStreamWaitEvent(hstream_, ev_fmap_[op.head], 0));
-                conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, hstream_);
+                cs = hstream_;
                 heads_on_side = true;
-            } else {
-                conv_fwd(conv_desc(op, b), in.data, params_ + op.w_off, params_ + op.b_off, out.data, op.relu, stream_);
             }
+            const ConvDesc d = conv_desc(op, b);
+            if (!bf16_)
+                conv_fwd(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<float*>(out.data), op.relu, cs);
+            else if (in.data_f32)       // conv1_1: fp32 image and master filter, bf16 out
+                conv_fwd_smallc_bf16out(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<bf16_t*>(out.data), op.relu, cs);
+            else
+                conv_fwd_bf16(d, in.h(), wq_oi_ + op.w_off, params_ + op.b_off, out.data, out.data_f32, op.relu, cs);
             break;
+        }
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-            maxpool_fwd(d, in.data, out.data, stream_);
+            if (bf16_) maxpool_fwd(d, in.h(), static_cast<bf16_t*>(out.data), stream_);
+            else maxpool_fwd(d, in.f(), static_cast<float*>(out.data), stream_);
             break;
         }
         case OP_L2NORM:
-            l2norm_fwd(b * in.H * in.W, in.C, in.data, params_ + scale_off_, out.data, stream_);
+            if (bf16_) l2norm_fwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, static_cast<bf16_t*>(out.data), stream_);
+            else l2norm_fwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, static_cast<float*>(out.data), stream_);
             break;
         }
     }
@@ -411,23 +444,33 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
                 side_used = true;
             }
-            conv_wgrad(d, in.data, out.grad, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
-            if (need_dx)
-                conv_dgrad(d, out.grad, params_ + op.w_off, in.grad, (last && in.relu_out) ? in.data : nullptr, in.done > 0,
-                           stream_);
+            const bool mask = last && in.relu_out;
+            if (!bf16_) {
+                conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
+                if (need_dx) conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, stream_);
+            } else if (in.data_f32) {   // conv1_1
+                conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
+                                         wgrad_ws_, ws);
+            } else {
+                conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
+                if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, stream_);
+            }
             lo = op.w_off;          // conv ops own descending, adjacent filter ranges
             break;
         }
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-            maxpool_bwd(d, in.data, out.grad, in.grad, in.done > 0, last && in.relu_out,
-                        maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr, stream_);
+            void* pws = maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr;
+            if (bf16_) maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
+            else maxpool_bwd(d, in.f(), out.gf(), in.gf(), in.done > 0, last && in.relu_out, pws, stream_);
             break;
         }
         case OP_L2NORM:
             SSD_REQUIRE(in.done == 0 && !last, "l2norm backward must be the first of several consumers");
-            l2norm_bwd(b * in.H * in.W, in.C, in.data, params_ + scale_off_, out.grad, in.grad, grads_ + scale_off_, l2_ws_,
-                       stream_);
+            if (bf16_)
+                l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, stream_);
+            else
+                l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, stream_);
             break;
         }
         in.done++;
@@ -552,18 +595,21 @@ void Net::activation(const char* name, int b, float* out, size_t count) {
     if (want_grad) name += 5;
     for (const Tensor& t : tensors_) {
         if (t.name != name || !t.data) continue;
-        if (want_grad) {
-            SSD_REQUIRE(t.grad != nullptr, "no gradient storage (training = 0?)");
-            SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name,
-                        t.per_image() * b, b, count);
-            HIP_OK(hipStreamSynchronize(stream_));
-            HIP_OK(hipMemcpy(out, t.grad, count * sizeof(float), hipMemcpyDeviceToHost));
-            return;
-        }
+        SSD_REQUIRE(!want_grad || t.grad != nullptr, "no gradient storage (training = 0?)");
         SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name, t.per_image() * b, b,
                     count);
+        const void* src = want_grad ? t.grad : t.data;
         HIP_OK(hipStreamSynchronize(stream_));
-        HIP_OK(hipMemcpy(out, t.data, count * sizeof(float), hipMemcpyDeviceToHost));
+        if (want_grad ? t.grad_f32 : t.data_f32) {
+            HIP_OK(hipMemcpy(out, src, count * sizeof(float), hipMemcpyDeviceToHost));
+        } else {        // bf16 storage: widen on the host (exact)
+            std::vector<unsigned short> hb(count);
+            HIP_OK(hipMemcpy(hb.data(), src, count * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < count; ++i) {
+                const unsigned u = (unsigned)hb[i] << 16;
+                memcpy(out + i, &u, 4);
+            }
+        }
         return;
     }
     fail("no such activation: %s", name ? name : "(null)");

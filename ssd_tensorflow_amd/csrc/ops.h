@@ -10,7 +10,9 @@ namespace ssd {
 struct PoolDesc {
     int B, Hi, Wi, C, Ho, Wo, k, stride, pad_h, pad_w;
 };
+struct bf16_t;      // bf16.h; every tensor-typed op below exists for fp32 and for bf16 storage (fp32 math)
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s);
+void maxpool_fwd(const PoolDesc& d, const bf16_t* x, bf16_t* y, hipStream_t s);
 // dx[cell] = sum of dy over the windows whose FIRST maximum (scan order) is this cell.
 // accumulate: += existing dx first; relu_mask: zero where x <= 0 (x is a relu output).
 // ws: optional scratch of maxpool_bwd_ws_bytes() for overlapping windows (per-window argmax bytes);
@@ -18,11 +20,16 @@ void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s);
 size_t maxpool_bwd_ws_bytes(const PoolDesc& d);
 void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
                  void* ws, hipStream_t s);
+void maxpool_bwd(const PoolDesc& d, const bf16_t* x, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask,
+                 void* ws, hipStream_t s);
 
 // ---- l2_normalization (ssdvgg.py:80-84): y = scale * x * rsqrt(max(sum_c x^2, 1e-12))
 void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s);
+void l2norm_fwd(int npix, int C, const bf16_t* x, const float* scale, bf16_t* y, hipStream_t s);
 size_t l2norm_bwd_ws_floats(int npix, int C);
 void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale,
+                float* ws, hipStream_t s);
+void l2norm_bwd(int npix, int C, const bf16_t* x, const float* scale, const bf16_t* dy, bf16_t* dx, float* dscale,
                 float* ws, hipStream_t s);
 
 // ---- multibox heads: layout + softmax + loss (ssdvgg.py:353-372, 375-580) ----------
@@ -31,10 +38,11 @@ struct HeadLayout {
     int nmaps, A, nvars;             // nvars = num_classes + 5
     int hw[MAX_MAPS];                // cells per map
     int nj[MAX_MAPS];                // box types per map
-    int ld[MAX_MAPS];                // row stride of the fused head buffer (nj*nvars rounded up to 4)
+    int ld[MAX_MAPS];                // row stride of the fused head buffer (nj*nvars rounded up to 8)
     int off[MAX_MAPS + 1];           // first anchor of each map
     float* buf[MAX_MAPS];            // [B*hw][ld] raw fused head conv outputs
-    float* dbuf[MAX_MAPS];           // same shape, gradients
+    void* dbuf[MAX_MAPS];            // same shape, gradients: fp32, or bf16 when grad_bf16
+    int grad_bf16;
 };
 // result[b][a][:] = (softmax(logits), loc) in the reference's anchor order
 // (map -> box type -> row -> col, ssdvgg.py:63,365 == ssdutils.py:104-116).

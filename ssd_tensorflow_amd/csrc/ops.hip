@@ -2,10 +2,9 @@
 // multibox head assembly / softmax / hard-negative-mined loss, momentum update.
 // All reductions use a fixed order (no float atomics): results are run-to-run identical.
 #include "ops.h"
+#include "bf16.h"
 
 namespace ssd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -31,7 +30,8 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
 // =================================================================================
 // max pooling
 // =================================================================================
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolDesc d, const float* __restrict__ x, float* __restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolDesc d, const T* __restrict__ x, T* __restrict__ y) {
     const int C4 = d.C >> 2;
     const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -50,17 +50,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolDesc d, const floa
             for (int kw = 0; kw < d.k; ++kw) {
                 const int w = w0 + kw;
                 if ((unsigned)w >= (unsigned)d.Wi) continue;
-                const f32x4 v = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+                const f32x4 v = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
             }
         }
-        st4(y + idx * 4, m);
+        st4t(y + idx * 4, m);
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const float* __restrict__ x,
-                                                          const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const T* __restrict__ x,
+                                                          const T* __restrict__ dy, T* __restrict__ dx,
                                                           int accumulate, int relu_mask) {
     const int C4 = d.C >> 2;
     const size_t total = (size_t)d.B * d.Hi * d.Wi * C4;
@@ -71,10 +72,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const floa
         pix /= d.Wi;
         const int h = (int)(pix % d.Hi);
         const int b = (int)(pix / d.Hi);
-        const f32x4 self = ld4(x + idx * 4);
+        const f32x4 self = ld4t(x + idx * 4);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         if (relu_mask && !(self[0] > 0.f) && !(self[1] > 0.f) && !(self[2] > 0.f) && !(self[3] > 0.f)) {
-            st4(dx + idx * 4, g);                    // every component is masked whatever arrives
+            st4t(dx + idx * 4, g);                    // every component is masked whatever arrives
             continue;
         }
         int n = h + d.pad_h - d.k + 1;
@@ -95,31 +96,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const floa
                         if ((unsigned)ww >= (unsigned)d.Wi) continue;
                         if (hh == h && ww == w) continue;
                         const bool before = hh < h || (hh == h && ww < w);
-                        const f32x4 v = ld4(x + (((size_t)b * d.Hi + hh) * d.Wi + ww) * d.C + c4 * 4);
+                        const f32x4 v = ld4t(x + (((size_t)b * d.Hi + hh) * d.Wi + ww) * d.C + c4 * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (before ? v[e] >= self[e] : v[e] > self[e]) first[e] = false;
                     }
                 }
-                const f32x4 gy = ld4(dy + (((size_t)b * d.Ho + oh) * d.Wo + ow) * d.C + c4 * 4);
+                const f32x4 gy = ld4t(dy + (((size_t)b * d.Ho + oh) * d.Wo + ow) * d.C + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (first[e]) g[e] += gy[e];
             }
         }
-        if (accumulate) g += ld4(dx + idx * 4);
+        if (accumulate) g += ld4t(dx + idx * 4);
         if (relu_mask) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = self[e] > 0.f ? g[e] : 0.f;
         }
-        st4(dx + idx * 4, g);
+        st4t(dx + idx * 4, g);
     }
 }
 
 // 2x2 stride-2 SAME pooling never overlaps and never pads before the image: one thread owns one
 // window (x 4 channels), finds its first maximum and writes all (<= 4) input gradients.
-__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const float* __restrict__ x,
-                                                             const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const T* __restrict__ x,
+                                                             const T* __restrict__ dy, T* __restrict__ dx,
                                                              int accumulate, int relu_mask) {
     const int C4 = d.C >> 2;
     const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const f
             const int h = h0 + (q >> 1), w = w0 + (q & 1);
             ok[q] = h < d.Hi && w < d.Wi;
             v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok[q]) v[q] = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+            if (ok[q]) v[q] = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
         }
-        const f32x4 gy = ld4(dy + idx * 4);
+        const f32x4 gy = ld4t(dy + idx * 4);
         int arg[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -155,15 +157,15 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const f
         for (int q = 0; q < 4; ++q) {
             if (!ok[q]) continue;
             const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            float* o = dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4;
+            T* o = dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4;
             f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            if (accumulate) g = ld4(o);
+            if (accumulate) g = ld4t(o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (arg[e] == q) g[e] += gy[e];
                 if (relu_mask && !(v[q][e] > 0.f)) g[e] = 0.f;
             }
-            st4(o, g);
+            st4t(o, g);
         }
     }
 }
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const f
 // Overlapping pooling (3x3 stride 1, mod_pool5): pass A finds every window's first maximum once
 // (its scan-order cell index, one byte per channel); pass B lets every input cell collect dy from
 // the <= 9 windows whose recorded maximum it is.  27 loads per cell instead of 81.
-__global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const float* __restrict__ x, unsigned* __restrict__ arg) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const T* __restrict__ x, unsigned* __restrict__ arg) {
     const int C4 = d.C >> 2;
     const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const f
             for (int kw = 0; kw < d.k; ++kw) {
                 const int w = w0 + kw;
                 if ((unsigned)w >= (unsigned)d.Wi) continue;
-                const f32x4 v = ld4(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+                const f32x4 v = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (v[e] > m[e] || a[e] == 255u) { m[e] = v[e]; a[e] = (unsigned)(kh * d.k + kw); }   // strict: first maximum
@@ -201,8 +204,9 @@ __global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const f
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(PoolDesc d, const float* __restrict__ x, const unsigned* __restrict__ arg,
-                                                              const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(PoolDesc d, const T* __restrict__ x, const unsigned* __restrict__ arg,
+                                                              const T* __restrict__ dy, T* __restrict__ dx,
                                                               int accumulate, int relu_mask) {
     const int C4 = d.C >> 2;
     const size_t total = (size_t)d.B * d.Hi * d.Wi * C4;
@@ -225,26 +229,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(PoolDesc d, const 
                 const size_t o = (((size_t)b * d.Ho + oh) * d.Wo + ow) * C4 + c4;
                 const unsigned me = (unsigned)((h - (oh * d.stride - d.pad_h)) * d.k + (w - (ow * d.stride - d.pad_w)));
                 const unsigned a = arg[o];
-                const f32x4 gy = ld4(dy + o * 4);
+                const f32x4 gy = ld4t(dy + o * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (((a >> (8 * e)) & 255u) == me) g[e] += gy[e];
             }
-        if (accumulate) g += ld4(dx + idx * 4);
+        if (accumulate) g += ld4t(dx + idx * 4);
         if (relu_mask) {
-            const f32x4 self = ld4(x + idx * 4);
+            const f32x4 self = ld4t(x + idx * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = self[e] > 0.f ? g[e] : 0.f;
         }
-        st4(dx + idx * 4, g);
+        st4t(dx + idx * 4, g);
     }
 }
 
-void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) {
+template <typename T>
+static void maxpool_fwd_t(const PoolDesc& d, const T* x, T* y, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
-    ProfScope prof("maxpool_fwd", 0.0, 4.0 * d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
+    ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
     HIP_OK(hipGetLastError());
 }
 
@@ -252,29 +257,42 @@ size_t maxpool_bwd_ws_bytes(const PoolDesc& d) {
     return (d.k == 2 && d.stride == 2) ? 0 : (size_t)d.B * d.Ho * d.Wo * (d.C / 4) * sizeof(unsigned);
 }
 
-void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask,
-                 void* ws, hipStream_t s) {
+void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) { maxpool_fwd_t(d, x, y, s); }
+void maxpool_fwd(const PoolDesc& d, const bf16_t* x, bf16_t* y, hipStream_t s) { maxpool_fwd_t(d, x, y, s); }
+
+template <typename T>
+static void maxpool_bwd_t(const PoolDesc& d, const T* x, const T* dy, T* dx, bool accumulate, bool relu_mask, void* ws,
+                          hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
-    ProfScope prof("maxpool_bwd", 0.0, 4.0 * d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
+    ProfScope prof("maxpool_bwd", 0.0, sizeof(T) * (double)d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
     if (d.k == 2 && d.stride == 2 && d.pad_h == 0 && d.pad_w == 0) {
         const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
-        hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
+        hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
                            (int)accumulate, (int)relu_mask);
         HIP_OK(hipGetLastError());
         return;
     }
     if (ws) {
         const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
-        hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (unsigned*)ws);
-        hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
+        hipLaunchKernelGGL(maxpool_argmax_kernel<T>, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (unsigned*)ws);
+        hipLaunchKernelGGL(maxpool_bwd_arg_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
                            (const unsigned*)ws, dy, dx, (int)accumulate, (int)relu_mask);
         HIP_OK(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
                        (int)accumulate, (int)relu_mask);
     HIP_OK(hipGetLastError());
+}
+
+void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, bool accumulate, bool relu_mask, void* ws,
+                 hipStream_t s) {
+    maxpool_bwd_t(d, x, dy, dx, accumulate, relu_mask, ws, s);
+}
+void maxpool_bwd(const PoolDesc& d, const bf16_t* x, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask, void* ws,
+                 hipStream_t s) {
+    maxpool_bwd_t(d, x, dy, dx, accumulate, relu_mask, ws, s);
 }
 
 // =================================================================================
@@ -282,8 +300,9 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
 // =================================================================================
 constexpr int L2_MAXJ = 4;   // C <= 1024
 
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const float* __restrict__ x,
-                                                         const float* __restrict__ scale, float* __restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const T* __restrict__ x,
+                                                         const float* __restrict__ scale, T* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const 
         for (int j = 0; j < L2_MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < C) v[j] = ld4(x + (size_t)pix * C + c);
+            if (c < C) v[j] = ld4t(x + (size_t)pix * C + c);
             ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
         }
         ss = wave_sum(ss);
@@ -302,16 +321,17 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const 
 #pragma unroll
         for (int j = 0; j < L2_MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
-            if (c < C) st4(y + (size_t)pix * C + c, ld4(scale + c) * v[j] * r);
+            if (c < C) st4t(y + (size_t)pix * C + c, ld4(scale + c) * v[j] * r);
         }
     }
 }
 
 // dx = scale*dy*r - x * (sum_c scale*dy*x) * r^3  (when sum x^2 > eps; else the norm is the
 // constant sqrt(eps) and only the first term remains).  dscale partials per block -> ws.
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const float* __restrict__ x,
-                                                         const float* __restrict__ scale, const float* __restrict__ dy,
-                                                         float* __restrict__ dx, float* __restrict__ ws) {
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const T* __restrict__ x,
+                                                         const float* __restrict__ scale, const T* __restrict__ dy,
+                                                         T* __restrict__ dx, float* __restrict__ ws) {
     __shared__ float red[4][1024];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -327,8 +347,8 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
             const int c = lane * 4 + 256 * j;
             v[j] = g[j] = sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < C) {
-                v[j] = ld4(x + (size_t)pix * C + c);
-                g[j] = ld4(dy + (size_t)pix * C + c);
+                v[j] = ld4t(x + (size_t)pix * C + c);
+                g[j] = ld4t(dy + (size_t)pix * C + c);
                 sc[j] = ld4(scale + c);
             }
 #pragma unroll
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
 #pragma unroll
         for (int j = 0; j < L2_MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
-            if (c < C) st4(dx + (size_t)pix * C + c, sc[j] * g[j] * r - v[j] * k);
+            if (c < C) st4t(dx + (size_t)pix * C + c, sc[j] * g[j] * r - v[j] * k);
             ds[j] += g[j] * v[j] * r;
         }
     }
@@ -375,25 +395,37 @@ static int l2_blocks(int npix) {
     return b > 512 ? 512 : (b < 1 ? 1 : b);
 }
 
-void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s) {
+template <typename T>
+static void l2norm_fwd_t(int npix, int C, const T* x, const float* scale, T* y, hipStream_t s) {
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
     int b = (npix + 3) / 4;
     if (b > 4096) b = 4096;
-    ProfScope prof("l2norm_fwd", 0.0, 8.0 * npix * C, s);
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(b), dim3(256), 0, s, npix, C, x, scale, y);
+    ProfScope prof("l2norm_fwd", 0.0, 2.0 * sizeof(T) * npix * C, s);
+    hipLaunchKernelGGL(l2norm_fwd_kernel<T>, dim3(b), dim3(256), 0, s, npix, C, x, scale, y);
     HIP_OK(hipGetLastError());
 }
+void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s) { l2norm_fwd_t(npix, C, x, scale, y, s); }
+void l2norm_fwd(int npix, int C, const bf16_t* x, const float* scale, bf16_t* y, hipStream_t s) { l2norm_fwd_t(npix, C, x, scale, y, s); }
 
 size_t l2norm_bwd_ws_floats(int npix, int C) { return (size_t)l2_blocks(npix) * C; }
 
-void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale,
-                float* ws, hipStream_t s) {
+template <typename T>
+static void l2norm_bwd_t(int npix, int C, const T* x, const float* scale, const T* dy, T* dx, float* dscale, float* ws,
+                         hipStream_t s) {
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
     const int nb = l2_blocks(npix);
-    ProfScope prof("l2norm_bwd", 0.0, 12.0 * npix * C, s);
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
+    ProfScope prof("l2norm_bwd", 0.0, 3.0 * sizeof(T) * npix * C, s);
+    hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nb, C, dscale);
     HIP_OK(hipGetLastError());
+}
+void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale, float* ws,
+                hipStream_t s) {
+    l2norm_bwd_t(npix, C, x, scale, dy, dx, dscale, ws, s);
+}
+void l2norm_bwd(int npix, int C, const bf16_t* x, const float* scale, const bf16_t* dy, bf16_t* dx, float* dscale, float* ws,
+                hipStream_t s) {
+    l2norm_bwd_t(npix, C, x, scale, dy, dx, dscale, ws, s);
 }
 
 // =================================================================================
@@ -670,8 +702,12 @@ void multibox_loss(const HeadLayout& L, int B, const float* result, const float*
     HIP_OK(hipGetLastError());
 }
 
+__device__ __forceinline__ void put(float* p, float v) { *p = v; }
+__device__ __forceinline__ void put(bf16_t* p, float v) { p->v = f2bf(v); }
+
 // d/d(logits) = sel * (softmax - labels) * w_b ; d/d(loc) = pos * clip(loc - gt, -1, 1) * w_b,
 // w_b = 1 / (pos_n_b * B)  (reduce_mean over the batch of per-sample normalised sums).
+template <typename T>
 __global__ __launch_bounds__(256) void loss_grad_kernel(HeadLayout L, int B, const float* __restrict__ result,
                                                         const float* __restrict__ labels,
                                                         const unsigned char* __restrict__ pos,
@@ -681,26 +717,30 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(HeadLayout L, int B, con
     if (idx >= B * L.A) return;
     const int b = idx / L.A, a = idx - b * L.A;
     const AnchorLoc p = locate(L, b, a);
-    float* dst = L.dbuf[p.map] + p.row * L.ld[p.map] + p.col0;
+    T* dst = static_cast<T*>(L.dbuf[p.map]) + p.row * L.ld[p.map] + p.col0;
     const int nv = L.nvars, nc = nv - 4;
     const float wb = sample[b * 4 + 2];
     const bool isel = sel[idx], ipos = pos[idx];
     const float* r = result + (size_t)idx * nv;
     const float* y = labels + (size_t)idx * nv;
-    for (int c = 0; c < nc; ++c) dst[c] = isel ? (r[c] - y[c]) * wb : 0.f;
+    for (int c = 0; c < nc; ++c) put(dst + c, isel ? (r[c] - y[c]) * wb : 0.f);
     for (int c = nc; c < nv; ++c) {
         float d = r[c] - y[c];
         d = fminf(fmaxf(d, -1.f), 1.f);
-        dst[c] = ipos ? d * wb : 0.f;
+        put(dst + c, ipos ? d * wb : 0.f);
     }
 }
 
 void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s) {
     const int total = B * L.A;
-    ProfScope prof("multibox_loss_grad", 0.0, 12.0 * total * L.nvars, s);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos, w.sel,
-                       w.sample);
+    ProfScope prof("multibox_loss_grad", 0.0, (L.grad_bf16 ? 10.0 : 12.0) * total * L.nvars, s);
+    if (L.grad_bf16)
+        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos,
+                           w.sel, w.sample);
+    else
+        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos, w.sel,
+                           w.sample);
     HIP_OK(hipGetLastError());
 }
 

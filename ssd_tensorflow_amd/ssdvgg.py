@@ -85,15 +85,16 @@ class SSDVGG:
 
     # ------------------------------------------------------------------ construction
     def build_from_vgg(self, vgg_dir, num_classes, a_trous=True, progress_hook='tqdm', max_batch=32,
-                       training=True, seed=42, weights=None):
+                       training=True, seed=42, weights=None, dtype='f32'):
         """ssdvgg.py:96-118.  There is no vgg.zip offline: the VGG-16 trunk starts from
         Xavier-uniform synthetic weights (seed) unless `weights` ({tf_name: array}) or
-        `<vgg_dir>/vgg16_ssd.npz` supplies them."""
+        `<vgg_dir>/vgg16_ssd.npz` supplies them.  dtype 'f32' (default) or 'bf16' (bf16 activations and
+        filter mirrors on the bf16 matrix cores; fp32 master weights, loss and optimizer)."""
         if not a_trous:
             raise NotImplementedError('only the default a_trous=True variant (ssdvgg.py:231) is built')
         self.num_classes = num_classes + 1
         self.num_vars = num_classes + 5
-        self._create(num_classes, max_batch, training, seed)
+        self._create(num_classes, max_batch, training, seed, dtype)
         path = os.path.join(vgg_dir, 'vgg16_ssd.npz') if vgg_dir else None
         if weights is None and path and os.path.exists(path):
             weights = dict(np.load(path))
@@ -101,20 +102,23 @@ class SSDVGG:
             self.load_variables(weights)
         self.__built = True
 
-    def build_from_metagraph(self, metagraph_file, checkpoint_file, max_batch=32, training=False):
+    def build_from_metagraph(self, metagraph_file, checkpoint_file, max_batch=32, training=False, dtype='f32'):
         """ssdvgg.py:120-130: restore a trained net.  checkpoint_file is an .npz written by
         save_checkpoint (variables under the reference's TF names + preset/num_classes)."""
         ck = np.load(checkpoint_file, allow_pickle=False)
         num_classes = int(ck['__num_classes__'])
         self.num_classes = num_classes + 1
         self.num_vars = num_classes + 5
-        self._create(num_classes, max_batch, training, 0)
+        self._create(num_classes, max_batch, training, 0, dtype)
         self.load_variables({k: ck[k] for k in ck.files if not k.startswith('__')})
         self._ckpt = ck
         self.__built = True
 
-    def _create(self, num_classes, max_batch, training, seed):
+    def _create(self, num_classes, max_batch, training, seed, dtype='f32'):
         import torch
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+        self.dtype = dtype
         dev = self.session.device if self.session is not None else 0
         self.device = dev
         self.max_batch = int(max_batch)
@@ -127,10 +131,11 @@ class SSDVGG:
         self.grads_flat = torch.zeros(n, dtype=torch.float32, device=tdev) if training else None
         self.momentum_flat = torch.zeros(n, dtype=torch.float32, device=tdev) if training else None
         h = C.c_void_p()
-        check(lib.ssd_create(self.preset.name.encode(), num_classes, self.max_batch, dev, int(training), seed,
-                             self.params_flat.data_ptr(),
-                             self.grads_flat.data_ptr() if training else None,
-                             self.momentum_flat.data_ptr() if training else None, C.byref(h)))
+        check(lib.ssd_create_dtype(self.preset.name.encode(), num_classes, self.max_batch, dev, int(training), seed,
+                                   self.params_flat.data_ptr(),
+                                   self.grads_flat.data_ptr() if training else None,
+                                   self.momentum_flat.data_ptr() if training else None,
+                                   1 if dtype == 'bf16' else 0, C.byref(h)))
         self._h = h
         fl = C.c_size_t(); ff = C.c_size_t()
         check(lib.ssd_arenas(h, None, None, None, C.byref(fl), C.byref(ff)))

@@ -51,8 +51,9 @@ def head_out_from_buffers(net, preset, b, prefix=''):
     return np.concatenate(parts, 1)
 
 
-def layer_local_backward_check(net, m, preset, b, x, y):
-    """Every op's backward, recomputed by the oracle from the GPU's own tensors."""
+def layer_local_backward_check(net, m, preset, b, x, y, wq=lambda w: w, tol_dout=TOL):
+    """Every op's backward, recomputed by the oracle from the GPU's own tensors.
+    wq: the rounding the product applies to a filter before it multiplies (identity for fp32)."""
     g_gpu = net.save_gradients()
     act = {'image_input': x}
 
@@ -75,7 +76,7 @@ def layer_local_backward_check(net, m, preset, b, x, y):
     out_gpu = head_out_from_buffers(net, preset, b)
     conf, loc, d_out, _ = ref.loss_numpy(out_gpu, y)
     got = head_out_from_buffers(net, preset, b, 'grad:')
-    assert report('d(loss)/d(head outputs)', max_rel(got, d_out)) < TOL
+    assert report('d(loss)/d(head outputs)', max_rel(got, d_out)) < tol_dout
     for i in range(len(preset['maps'])):      # fused-buffer padding columns never receive gradient
         gbuf = G(f'head{i}')
         nj = 2 + len(preset['maps'][i][2])
@@ -86,12 +87,13 @@ def layer_local_backward_check(net, m, preset, b, x, y):
         for op in cons:
             if op[0] == 'conv':
                 _, name, _, k, stride, padding, dil = op
-                w = m.params[name + '/filter'].detach().clone().requires_grad_(True)
+                w0 = m.params[name + '/filter'].detach()
+                w = wq(w0).clone().requires_grad_(True)
                 bias = m.params[name + '/biases'].detach().clone().requires_grad_(True)
                 xin = F.pad(a, (0, 1, 0, 1)) if padding == 'BR1' else a
                 pre = ref.conv2d_tf(xin, w, stride, 'SAME' if padding == 'SAME' else 'VALID', dil) + bias.view(1, -1, 1, 1)
                 pre.backward(nchw(G(name)))
-                worst_w = max(worst_w, report('wgrad ' + name, rel_err(g_gpu[name + '/filter'], w.grad.numpy() + WD * w.detach().numpy())))
+                worst_w = max(worst_w, report('wgrad ' + name, rel_err(g_gpu[name + '/filter'], w.grad.numpy() + WD * w0.numpy())))
                 worst_w = max(worst_w, rel_err(g_gpu[name + '/biases'], bias.grad.numpy()))
             elif op[0] == 'pool':
                 _, name, _, k, s = op
@@ -105,11 +107,12 @@ def layer_local_backward_check(net, m, preset, b, x, y):
                 gbuf = G(f'head{i}')
                 for j in range(2 + len(preset['maps'][i][2])):
                     n = f'classifiers/classifier{i}_{j}'
-                    w = m.params[n + '/filter'].detach().clone().requires_grad_(True)
+                    w0 = m.params[n + '/filter'].detach()
+                    w = wq(w0).clone().requires_grad_(True)
                     bias = m.params[n + '/biases'].detach().clone().requires_grad_(True)
                     pre = ref.conv2d_tf(a, w) + bias.view(1, -1, 1, 1)
                     pre.backward(nchw(gbuf[..., j * 25:(j + 1) * 25]))
-                    worst_w = max(worst_w, rel_err(g_gpu[n + '/filter'], w.grad.numpy() + WD * w.detach().numpy()))
+                    worst_w = max(worst_w, rel_err(g_gpu[n + '/filter'], w.grad.numpy() + WD * w0.numpy()))
                     worst_w = max(worst_w, rel_err(g_gpu[n + '/biases'], bias.grad.numpy()))
         if tname == 'image_input':
             continue
