@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 FLOPS_FWD_BWD = {'vgg300': 187.93e9, 'vgg512': 540.34e9}
 FLOPS_FWD = {'vgg300': 62.75e9, 'vgg512': 180.42e9}
 PEAK_FP32_MFMA = 157.3      # TFLOP/s, MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2500.0     # TFLOP/s dense bf16 (2.5 PFLOP/s), same guide
 PEAK_HBM = 8000.0           # GB/s spec
 
 
@@ -42,6 +43,12 @@ KERNEL_SYMBOLS = {
     'conv_wgrad_128x128': 'conv_wgrad_kernel<2, 2, 2, 2, false>', 'conv_wgrad_64x64': 'conv_wgrad_kernel<2, 2, 1, 1, false>',
     'conv_wgrad_64x128': 'conv_wgrad_kernel<2, 2, 1, 2, false>', 'conv_wgrad_128x64': 'conv_wgrad_kernel<2, 2, 2, 1, false>',
     'detect_scan': 'detect_scan_kernel',
+    'conv_fwd_bf16_128x128': 'conv_gather_bf16_kernel<0, 2, 2, 2, 2, false', 'conv_fwd_bf16_128x64': 'conv_gather_bf16_kernel<0, 4, 1, 1, 2, false',
+    'conv_fwd_bf16_64x128': 'conv_gather_bf16_kernel<0, 2, 2, 1, 2, false', 'conv_fwd_bf16_256x128': 'conv_gather_bf16_kernel<0, 2, 2, 4, 2, false',
+    'conv_dgrad_bf16_128x128': 'conv_gather_bf16_kernel<1, 2, 2, 2, 2, false', 'conv_dgrad_bf16_128x64': 'conv_gather_bf16_kernel<1, 4, 1, 1, 2, false',
+    'conv_dgrad_bf16_64x128': 'conv_gather_bf16_kernel<1, 2, 2, 1, 2, false', 'conv_dgrad_bf16_256x128': 'conv_gather_bf16_kernel<1, 2, 2, 4, 2, false',
+    'conv_wgrad_bf16_128x128': 'conv_wgrad_bf16_kernel<2, 2, 2, 2>', 'conv_wgrad_bf16_64x64': 'conv_wgrad_bf16_kernel<2, 2, 1, 1>',
+    'conv_wgrad_bf16_64x128': 'conv_wgrad_bf16_kernel<2, 2, 1, 2>', 'conv_wgrad_bf16_128x64': 'conv_wgrad_bf16_kernel<2, 2, 2, 1>',
 }
 
 
@@ -106,6 +113,8 @@ def main():
     ap.add_argument('--preset', default='vgg300')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
@@ -144,7 +153,8 @@ def main():
     sess = Session(local)
     net = SSDVGG(sess, args.preset)
     training = args.mode == 'train'
-    net.build_from_vgg(None, 20, max_batch=b, training=training, seed=42)
+    net.build_from_vgg(None, 20, max_batch=b, training=training, seed=42, dtype=args.dtype)
+    peak_mfma = PEAK_BF16_MFMA if args.dtype == 'bf16' else PEAK_FP32_MFMA
     if world > 1:      # identical replicas
         dist.broadcast(net.params_flat, 0)
     if training:
@@ -267,8 +277,8 @@ def main():
             d = kernels[dom]
             if d['flops'] > 0:
                 ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-                roofline = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA, unit='TFLOP/s',
-                                frac=round(ach / PEAK_FP32_MFMA, 4), traffic=None,
+                roofline = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=peak_mfma, unit='TFLOP/s',
+                                frac=round(ach / peak_mfma, 4), traffic=None,
                                 launches_per_step=d['launches'] // args.steps,
                                 avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
                                 flops_per_launch=d['flops'] / d['launches'],
@@ -292,12 +302,12 @@ def main():
                       else 'images/sec (%s) %s batch%d' % (args.mode, args.preset, b),
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.preset} {args.mode} step, {b} images/GPU x {world} GPU, synthetic '
-                                   f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[1])',
+                                   f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[%d])' % (2 if args.dtype == 'bf16' else 1),
                        'global_batch': b * world, 'parallelism': f'dp{world}', 'allreduce': allreduce_mode},
             'model_tflops': round(value * flops_img / 1e12, 2) if args.mode != 'decode' else None,
-            'model_mfma_frac': round(value * flops_img / 1e12 / (PEAK_FP32_MFMA * world), 4) if args.mode != 'decode' else None,
+            'model_mfma_frac': round(value * flops_img / 1e12 / (peak_mfma * world), 4) if args.mode != 'decode' else None,
             'roofline': roofline,
         }
         if roofline is not None and world == 1:
