@@ -48,19 +48,31 @@ struct GatherArgsH {
     int tap_dh[9], tap_dw[9];
 };
 
-__device__ __forceinline__ void wait_dma_and_sync() {
-    // every lane's LDS-DMA has landed (vmcnt), then the workgroup barrier publishes them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+// Pipeline step: wait until all but the `ahead` most recent tiles of this lane's LDS-DMA have landed
+// (L DMA instructions per tile; vmcnt retires loads in order), then the workgroup barrier publishes them.
+// A raw s_barrier, not __syncthreads(): the latter's fence drains vmcnt to 0 and with it the tiles that
+// are meant to stay in flight across the barrier.  Every ds_read of the previous tile has already been
+// consumed by an MFMA (lgkmcnt) when a wave arrives here, so the stage it frees can be refilled at once.
+template <int L>
+__device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
+    static_assert(2 * L <= 63, "vmcnt field");
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED>
-__global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherArgsH p) {
+    constexpr int NTHR = 64 * WM * WN;                // 4 or 8 waves
+    constexpr int RPP_S = NTHR / 8;                   // tile rows one staging pass of the workgroup covers
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int A_N = BM / 32, B_N = BN / 32;       // DMA instructions per thread and tile
+    constexpr int A_N = BM / RPP_S, B_N = BN / RPP_S; // DMA instructions per thread and tile
     constexpr int STAGE = (BM + BN) * 128;            // bytes per pipeline stage
     constexpr int LDC = BN + 4;                       // fp32 epilogue tile pitch
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    static_assert(BM % RPP_S == 0 && BN % RPP_S == 0, "tile vs staging pass");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -70,13 +82,13 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- staging: thread -> rows (tid>>3) + 32 i, LDS slot tid&7, global chunk slot ^ swizzle(row)
+    // ---- staging: thread -> rows (tid>>3) + RPP_S i, LDS slot tid&7, global chunk slot ^ swizzle(row)
     const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;      // k element offset inside the 64-wide block
     int rb[A_N], rh[A_N], rw[A_N];
     unsigned a_off[A_N], a_msk[A_N];
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
-        const int m = m0 + (tid >> 3) + 32 * i;
+        const int m = m0 + (tid >> 3) + RPP_S * i;
         const int mm = m < p.M ? m : 0;
         const int ow = mm % p.DW;
         const int t2 = mm / p.DW;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
     unsigned b_off[B_N], b_ok[B_N];      // byte offset of (row n, chunk) inside one tap's filter image; row inside the filter
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
-        const int n = n0 + (tid >> 3) + 32 * i;
+        const int n = n0 + (tid >> 3) + RPP_S * i;
         b_ok[i] = 0u - (unsigned)(n < p.DN);
         b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.SC + a_ck) * 2u;
     }
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
             for (int i = 0; i < A_N; ++i) {
                 const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
                 const unsigned off = ((a_off[i] + toff) & m) | (OOBH & ~m);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * (RPP_S * 128)), 16, off, 0, 0, 0);
             }
         } else {
             const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
                 ok = ok && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
                 const unsigned m = (0u - (unsigned)ok) & cmask;
                 const unsigned off = ((unsigned)(((rb[i] + sh * p.SW + sw) * p.SC + cc * HBK + a_ck) * 2) & m) | (OOBH & ~m);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * (RPP_S * 128)), 16, off, 0, 0, 0);
             }
         }
         const unsigned woff = (unsigned)((tap * p.DN * p.SC + cc * HBK) * 2);
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
         for (int i = 0; i < B_N; ++i) {
             const unsigned m = cmask & b_ok[i];
             const unsigned off = ((b_off[i] + woff) & m) | (OOBH & ~m);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * (RPP_S * 128)), 16, off, 0, 0, 0);
         }
     };
 
@@ -166,29 +178,44 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
 
     auto compute = [&](int stage) {
         const unsigned char* S = smem + stage * STAGE;
-#pragma unroll
-        for (int st = 0; st < HBK / 16; ++st) {
-            bf16x8 a[TM], b[TN];
+        // fragments of k-step st+1 are read while the MFMAs of step st run (two register sets)
+        bf16x8 a[2][TM], b[2][TN];
+        auto frags = [&](int st) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
-                a[mi] = *reinterpret_cast<const bf16x8*>(S + ((a_row + mi * 4096) ^ (st * 32)));
+                a[st & 1][mi] = *reinterpret_cast<const bf16x8*>(S + ((a_row + mi * 4096) ^ (st * 32)));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                b[ni] = *reinterpret_cast<const bf16x8*>(S + ((b_row + ni * 4096) ^ (st * 32)));
+                b[st & 1][ni] = *reinterpret_cast<const bf16x8*>(S + ((b_row + ni * 4096) ^ (st * 32)));
+        };
+        frags(0);
+#pragma unroll
+        for (int st = 0; st < HBK / 16; ++st) {
+            if (st + 1 < HBK / 16) frags(st + 1);
+            // keep the order written here: left alone, the scheduler folds both register sets into one and every
+            // k-step then starts parked on its own LDS reads (SQ_WAIT_ANY was 34 % of the wave cycles)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[st & 1][ni], a[st & 1][mi], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- main loop: two stages; tile k+1 streams in while tile k is multiplied --------------
-    issue(0, 0);
+    // ---- main loop: NS stages; tiles k+1 .. k+NS-1 stream in while tile k is multiplied --------
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t, t);
+    int st_c = 0, st_i = NS - 1;
     for (int k = 0; k < nk; ++k) {
-        wait_dma_and_sync();              // tile k visible; everyone is done reading the other stage
-        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
-        compute(k & 1);
+        const int later = nk - 1 - k;
+        wait_tiles_and_sync<A_N + B_N>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
+        if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
+        compute(st_c);
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+        st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
     __syncthreads();
 
@@ -208,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_kernel(GatherArgsH p) {
             }
     __syncthreads();
     constexpr int TPR = BN / 8;               // threads per row, 8 channels each
-    constexpr int RPP = 256 / TPR;            // rows per pass
+    constexpr int RPP = NTHR / TPR;           // rows per pass
     const int cg = tid % TPR, r0 = tid / TPR;
     const int n = n0 + cg * 8;
     if (n >= p.DN) return;
@@ -275,7 +302,7 @@ struct WgradArgsH {
     int tap_dh[9], tap_dw[9];
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 64;
     constexpr int XCPR = BKT / 8, YCPR = BNT / 8;               // 16-byte chunks per pixel row
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     constexpr int XROWB = BKT * 2, YROWB = BNT * 2;
     constexpr int X_LDS = BP * XROWB, STAGE = BP * (XROWB + YROWB);
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(XCPR == 8 || XCPR == 16, "channel tile 64 or 128");
+    static_assert(XCPR == 8 || XCPR == 16 || XCPR == 32, "channel tile 64, 128 or 256");
     static_assert(YCPR == 8 || YCPR == 16, "n tile 64 or 128");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -306,8 +333,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
     const bool do_bias = (tap == 0 && ct == 0);
 
-    // chunk swizzle of a pixel row r: 256-byte rows p ^ 4*(r&3); 128-byte rows p ^ 4*((r>>1)&1)
-    auto swz = [](int r, int cpr) { return cpr == 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
+    // chunk swizzle of a pixel row r: rows of 256 or 512 bytes p ^ 4*(r&3); 128-byte rows p ^ 4*((r>>1)&1)
+    auto swz = [](int r, int cpr) { return cpr >= 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
 
     // ---- staging map -----------------------------------------------------------------------
     const int xr = tid / XCPR, xs = tid % XCPR;          // pixel row within a pass, LDS slot
@@ -321,7 +348,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     const __amdgpu_buffer_rsrc_t y_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 2u), 0x00020000);
 
-    // this thread's X_N pixel rows, advanced by BP pixels per iteration (issue() runs for it = 0, 1, 2, ...)
+    // this thread's X_N pixel rows, advanced by BP pixels per iteration (issue() runs for it = 0, 1, 2, ...):
+    // a mixed-radix add of BP = (adv_b, adv_h, adv_w) to (b, oh, ow), at most one carry per digit
+    const int adv_w = BP % p.Wo, adv_t = BP / p.Wo;
+    const int adv_h = adv_t % p.Ho, adv_b = adv_t / p.Ho;
     int pw[X_N], ph[X_N], pb[X_N];
 #pragma unroll
     for (int j = 0; j < X_N; ++j) {
@@ -344,19 +374,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
                                 (0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi)));
             const unsigned off = (unsigned)((((pb[j] * p.Hi + sh) * p.Wi + sw) * p.Ci + c0 + xchunk * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (off & mk) | (OOBH & ~mk), 0, 0, 0);
-            if (p.Wo >= BP) {
-                pw[j] += BP;
-                if (pw[j] >= p.Wo) {
-                    pw[j] -= p.Wo;
-                    if (++ph[j] == p.Ho) { ph[j] = 0; ++pb[j]; }
-                }
-            } else {
-                const int m2 = m + BP;
-                pw[j] = m2 % p.Wo;
-                const int t2 = m2 / p.Wo;
-                ph[j] = t2 % p.Ho;
-                pb[j] = t2 / p.Ho;
-            }
+            pw[j] += adv_w;
+            const int cw = pw[j] >= p.Wo;
+            pw[j] -= cw ? p.Wo : 0;
+            ph[j] += adv_h + cw;
+            const int ch = ph[j] >= p.Ho;
+            ph[j] -= ch ? p.Ho : 0;
+            pb[j] += adv_b + ch;
         }
 #pragma unroll
         for (int j = 0; j < Y_N; ++j) {
@@ -397,33 +421,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
 
     auto compute = [&](int stage) {
         const unsigned char* S = smem + stage * STAGE;
+        // fragments of k-step st+1 are read while the MFMAs of step st run (two register sets).  The two
+        // transpose reads of a fragment are 4 pixel rows apart: neither swizzle term (r&3, (r>>1)&1) changes.
+        s16x8 a[2][TM], b[2][TN];
+        auto tr8 = [&](int off, int rowb) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off + 4 * rowb));
+            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto frags = [&](int st) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[st & 1][mi] = tr8(xa[mi] + (st * 16) * XROWB, XROWB);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[st & 1][ni] = tr8(ya[ni] + (st * 16) * YROWB, YROWB);
+        };
+        frags(0);
 #pragma unroll
         for (int st = 0; st < BP / 16; ++st) {
-            s16x8 a[TM], b[TN];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                // rows +4: (r&3) and ((r>>1)&1 for +4 -> flips) -- the 128-byte-row swizzle depends on bit 1 of the
-                // row only, and +4 leaves bit 1 unchanged; the 256-byte-row swizzle depends on r&3, unchanged too
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + xa[mi] + (st * 16) * XROWB));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + xa[mi] + (st * 16 + 4) * XROWB));
-                a[mi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + ya[ni] + (st * 16) * YROWB));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + ya[ni] + (st * 16 + 4) * YROWB));
-                b[ni] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+            if (st + 1 < BP / 16) frags(st + 1);
+            __builtin_amdgcn_sched_barrier(0);      // as in the gather kernel: reads of step st+1 stay ahead of the MFMAs of step st
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
-                                                                         __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[st & 1][mi]),
+                                                                         __builtin_bit_cast(bf16x8, b[st & 1][ni]), acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (do_bias && tid < BNT) {
             // column sums of dy for the bias gradient, from the same LDS tile (channel tid of every pixel row)
@@ -438,11 +461,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
         }
     };
 
-    if (niter > 0) issue(0, 0);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < niter) issue(t, t);
+    int st_c = 0, st_i = NS - 1;
     for (int it = 0; it < niter; ++it) {
-        wait_dma_and_sync();
-        if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
-        compute(it & 1);
+        const int later = niter - 1 - it;
+        wait_tiles_and_sync<X_N + Y_N>(later < NS - 2 ? later : NS - 2);
+        if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
+        compute(st_c);
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+        st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
 
     const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
@@ -535,18 +564,19 @@ void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t
 // =================================================================================
 // host launchers
 // =================================================================================
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS = 2>
 static void launch_gather_h(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t stages = 2 * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t stages = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = stages > ctile ? stages : ctile;
-    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED>;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED, NS>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(64 * WM * WN), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -557,21 +587,47 @@ static void check_desc_h(const ConvDesc& d) {
                 "conv: tensor too large for 32-bit byte offsets");
 }
 
-// 0: 128x128  1: 128x64  2: 64x128 (pixels x channels)  3: 256x128
+// Tile configurations (pixels x channels, pipeline stages -> workgroups resident per CU):
+//   0: 128x128 x2 (2/CU)   1: 128x64 x2 (2/CU)   2: 64x128 x2 (2/CU)
+//   3: 256x128 x3 (1/CU)   4: 128x128 x4 (1/CU)  5: 128x64 x3 (2/CU)
+//   6: 256x128 x3, 8 waves (1/CU)   7: 256x128 x2, 8 waves (1/CU)
+constexpr int NCFG_H = 8;
 static int pick_tile_h(long long M, int N, int mode) {
     static const int forced = env_int("SSD_TILE_BF16", -1);      // tuning override
-    if (forced >= 0 && forced < 4) return forced;
-    static const int bm[4] = {128, 128, 64, 256}, bn[4] = {128, 64, 128, 128};
-    static const double eff[4] = {1.0, 0.85, 0.85, 0.0};          // 256x128: opt-in until measured
+    if (forced >= 0 && forced < NCFG_H) return forced;
+    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128};
+    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1};
+    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0};          // > 0: in the automatic choice
     int best = 0;
     double bc = 1e300;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NCFG_H; ++c) {
         if (eff[c] <= 0.0) continue;
         const long long wgs = (long long)cdiv(M, bm[c]) * cdiv(N, bn[c]);
-        const double cost = (double)((wgs + 511) / 512) * bm[c] * bn[c] / eff[c];      // 2 workgroups per CU
+        const int slots = 256 * per_cu[c];
+        const double cost = (double)((wgs + slots - 1) / slots) * bm[c] * bn[c] * per_cu[c] / eff[c];
         if (cost < bc * 0.999) { bc = cost; best = c; }
     }
     return best;
+}
+
+template <int MODE>
+static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hipStream_t s) {
+    static const char* const names[2][NCFG_H] = {
+        {"conv_fwd_bf16_128x128", "conv_fwd_bf16_128x64", "conv_fwd_bf16_64x128", "conv_fwd_bf16_256x128x3", "conv_fwd_bf16_128x128x4",
+         "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w"},
+        {"conv_dgrad_bf16_128x128", "conv_dgrad_bf16_128x64", "conv_dgrad_bf16_64x128", "conv_dgrad_bf16_256x128x3",
+         "conv_dgrad_bf16_128x128x4", "conv_dgrad_bf16_128x64x3", "conv_dgrad_bf16_256x128x3_8w", "conv_dgrad_bf16_256x128x2_8w"}};
+    const char* label = names[MODE][cfg];
+    switch (cfg) {
+    case 0: launch_gather_h<MODE, 2, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
+    case 1: launch_gather_h<MODE, 4, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
+    case 2: launch_gather_h<MODE, 2, 2, 1, 2, false, 2>(a, label, fl, by, s); break;
+    case 3: launch_gather_h<MODE, 2, 2, 4, 2, false, 3>(a, label, fl, by, s); break;
+    case 4: launch_gather_h<MODE, 2, 2, 2, 2, false, 4>(a, label, fl, by, s); break;
+    case 5: launch_gather_h<MODE, 4, 1, 1, 2, false, 3>(a, label, fl, by, s); break;
+    case 6: launch_gather_h<MODE, 4, 2, 2, 2, false, 3>(a, label, fl, by, s); break;
+    default: launch_gather_h<MODE, 4, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
+    }
 }
 
 void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
@@ -589,12 +645,7 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
-    switch (pick_tile_h(a.M, a.DN, MODE_FWD)) {
-    case 0: launch_gather_h<MODE_FWD, 2, 2, 2, 2, false>(a, "conv_fwd_bf16_128x128", fl, by, s); break;
-    case 1: launch_gather_h<MODE_FWD, 4, 1, 1, 2, false>(a, "conv_fwd_bf16_128x64", fl, by, s); break;
-    case 2: launch_gather_h<MODE_FWD, 2, 2, 1, 2, false>(a, "conv_fwd_bf16_64x128", fl, by, s); break;
-    default: launch_gather_h<MODE_FWD, 2, 2, 4, 2, false>(a, "conv_fwd_bf16_256x128", fl, by, s); break;
-    }
+    launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD), a, fl, by, s);
 }
 
 void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
@@ -613,20 +664,15 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
         }
     const double fl = conv_flops(d), by = 2.0 * (conv_elems(d) + (mask ? (double)d.B * d.Hi * d.Wi * d.Ci : 0.0));
     if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
-        launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
+        launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true, 2>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
         return;
     }
-    switch (pick_tile_h(a.M, a.DN, MODE_DGRAD)) {
-    case 0: launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false>(a, "conv_dgrad_bf16_128x128", fl, by, s); break;
-    case 1: launch_gather_h<MODE_DGRAD, 4, 1, 1, 2, false>(a, "conv_dgrad_bf16_128x64", fl, by, s); break;
-    case 2: launch_gather_h<MODE_DGRAD, 2, 2, 1, 2, false>(a, "conv_dgrad_bf16_64x128", fl, by, s); break;
-    default: launch_gather_h<MODE_DGRAD, 2, 2, 4, 2, false>(a, "conv_dgrad_bf16_256x128", fl, by, s); break;
-    }
+    launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD), a, fl, by, s);
 }
 
 // ---- wgrad planning -------------------------------------------------------------------
 struct WgradPlanH {
-    int cfg;        // (channels x n) 0: 128x128, 1: 64x64, 2: 64x128, 3: 128x64
+    int cfg;        // (channels x n, stages) 0: 128x128x2, 1: 64x64x2, 2: 64x128x2, 3: 128x64x2, 4: 128x128x4 (1/CU), 5: 256x128x3 (1/CU)
     int bkt, bnt, CT, NT, tiles, nsplit, mchunk;
 };
 
@@ -639,8 +685,8 @@ static WgradPlanH plan_wgrad_h(const ConvDesc& d) {
     else if (waste64 < waste128) p.cfg = 3;      // fused heads: Co = 104 / 152
     else p.cfg = 0;
     static const int forced = env_int("SSD_WGRAD_CFG_BF16", -1);      // tuning override
-    if (forced >= 0 && forced < 4) p.cfg = forced;
-    p.bkt = (p.cfg == 0 || p.cfg == 3) ? 128 : 64;
+    if (forced >= 0 && forced < 6 && !(forced == 5 && d.Ci < 256)) p.cfg = forced;
+    p.bkt = p.cfg == 5 ? 256 : (p.cfg == 0 || p.cfg == 3 || p.cfg == 4) ? 128 : 64;
     p.bnt = (p.cfg == 1 || p.cfg == 3) ? 64 : 128;
     p.CT = cdiv(d.Ci, p.bkt);
     p.NT = cdiv(d.Co, p.bnt);
@@ -660,11 +706,12 @@ size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
     return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS = 2>
 static void launch_wgrad_h(WgradArgsH& a, const WgradPlanH& pl, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
-    constexpr size_t lds = 2 * (size_t)64 * (BKT + BNT) * 2;
-    auto kern = conv_wgrad_bf16_kernel<WM, WN, TM, TN>;
+    constexpr size_t lds = NS * (size_t)64 * (BKT + BNT) * 2;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv_wgrad_bf16_kernel<WM, WN, TM, TN, NS>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
@@ -687,10 +734,12 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
-    if (pl.cfg == 1) launch_wgrad_h<2, 2, 1, 1>(a, pl, "conv_wgrad_bf16_64x64", fl, by, s);
-    else if (pl.cfg == 2) launch_wgrad_h<2, 2, 1, 2>(a, pl, "conv_wgrad_bf16_64x128", fl, by, s);
-    else if (pl.cfg == 3) launch_wgrad_h<2, 2, 2, 1>(a, pl, "conv_wgrad_bf16_128x64", fl, by, s);
-    else launch_wgrad_h<2, 2, 2, 2>(a, pl, "conv_wgrad_bf16_128x128", fl, by, s);
+    if (pl.cfg == 1) launch_wgrad_h<2, 2, 1, 1, 2>(a, pl, "conv_wgrad_bf16_64x64", fl, by, s);
+    else if (pl.cfg == 2) launch_wgrad_h<2, 2, 1, 2, 2>(a, pl, "conv_wgrad_bf16_64x128", fl, by, s);
+    else if (pl.cfg == 3) launch_wgrad_h<2, 2, 2, 1, 2>(a, pl, "conv_wgrad_bf16_128x64", fl, by, s);
+    else if (pl.cfg == 4) launch_wgrad_h<2, 2, 2, 2, 4>(a, pl, "conv_wgrad_bf16_128x128x4", fl, by, s);
+    else if (pl.cfg == 5) launch_wgrad_h<2, 2, 4, 2, 3>(a, pl, "conv_wgrad_bf16_256x128x3", fl, by, s);
+    else launch_wgrad_h<2, 2, 2, 2, 2>(a, pl, "conv_wgrad_bf16_128x128", fl, by, s);
     wgrad_reduce(ws, pl.nsplit, (size_t)a.ntaps * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
 }
 
