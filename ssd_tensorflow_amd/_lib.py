@@ -101,6 +101,9 @@ SIGNATURES = {
     'ssd_op_conv2d_dgrad_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_wgrad_bf16_ws_floats': (sz, [i32] * 13),
     'ssd_op_conv2d_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_first_fwd_bf16': (i32, [vp, vp, vp, vp] + [i32] * 14 + [vp]),
+    'ssd_op_conv2d_first_wgrad_bf16_ws_floats': (sz, [i32] * 13),
+    'ssd_op_conv2d_first_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
     'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),
     'ssd_op_maxpool_bwd': (i32, [vp, vp, vp, i32, i32] + [i32] * 10 + [vp]),
     'ssd_op_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, vp]),

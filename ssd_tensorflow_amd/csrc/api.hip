@@ -603,6 +603,26 @@ int ssd_op_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, float* db
                     dbias, w, weight_decay, ws, (hipStream_t)stream);
     API_END
 }
+int ssd_op_conv2d_first_fwd_bf16(const float* x, const float* w, const float* bias, void* y, int b, int hi, int wi, int ci, int ho,
+                                 int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, int relu,
+                                 void* stream) {
+    API_BEGIN
+    conv_first_fwd_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), x, w, bias, (bf16_t*)y, relu != 0,
+                        (hipStream_t)stream);
+    API_END
+}
+size_t ssd_op_conv2d_first_wgrad_bf16_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                                                int dil, int pad_h, int pad_w) {
+    return conv_first_wgrad_bf16_ws_floats(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w));
+}
+int ssd_op_conv2d_first_wgrad_bf16(const float* x, const void* dy, float* dw, float* dbias, const float* w, float weight_decay,
+                                   float* ws, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                                   int dil, int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    conv_first_wgrad_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), x, (const bf16_t*)dy, dw, dbias, w,
+                          weight_decay, ws, (hipStream_t)stream);
+    API_END
+}
 size_t ssd_op_conv2d_wgrad_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
                                      int dil, int pad_h, int pad_w) {
     return conv_wgrad_ws_floats(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w));

@@ -38,6 +38,12 @@ void conv_fwd_smallc_bf16out(const ConvDesc& d, const float* x, const float* w, 
 void conv_wgrad_smallc_bf16dy(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                               float weight_decay, float* ws, hipStream_t s);
 
+// dedicated first-layer kernels (conv_first_bf16.hip): Ci*taps <= 32 and Co == 64; image and filter are rounded to bf16
+void conv_first_fwd_bf16(const ConvDesc& d, const float* x, const float* w, const float* bias, bf16_t* y, bool relu, hipStream_t s);
+size_t conv_first_wgrad_bf16_ws_floats(const ConvDesc& d);
+void conv_first_wgrad_bf16(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                           float weight_decay, float* ws, hipStream_t s);
+
 // One launch mirrors every layer's fp32 filter [tap][Ci][Co] as bf16 in the same order (io, the data
 // gradient's operand) and transposed [tap][Co][Ci] (oi, the forward operand), at the same offsets.
 struct FilterCastPlan {

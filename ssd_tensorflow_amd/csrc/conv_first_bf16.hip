@@ -1,0 +1,330 @@
+// First layer of the bf16 configuration (conv1_1: 3 input channels, 3x3): the whole reduction
+// k = tap*Ci + c fits one 32-deep block (27 of 32 used), so there is nothing to tile or pipeline --
+// the layer is bound by writing (forward) / reading (weight gradient) the 64-channel tensor.
+//   forward : every lane gathers the 16 image values of its pixel that its two MFMA operands need
+//             straight from the fp32 image (buffer loads, zero padding by out-of-range offsets), the
+//             filter sits in registers for the whole kernel, outputs leave through a per-wave LDS tile as
+//             full 128-byte rows (16 bytes per lane).
+//   wgrad   : dy tiles stream in by LDS-DMA and are consumed through ds_read_b64_tr_b16 exactly as in
+//             conv_bf16.hip; the im2col image tile [64 pixels][32 k] is built in registers and written
+//             next to it, so both MFMA operands come out of LDS pixel-major.
+// Image and filter values are rounded to bf16 on the way in (0..255 pixel values are exact).
+#include "conv.h"
+#include "conv_detail.h"
+#include "bf16.h"
+
+namespace ssd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned OOBF = 0xFFFFFFF0u;
+
+struct FirstArgs {
+    const float* x;         // [B][Hi][Wi][Ci] fp32
+    const float* w;         // [taps][Ci][Co] fp32 master
+    const float* bias;
+    bf16_t* y;              // forward: [M][Co] out;  wgrad: dy in
+    float* ws;              // wgrad slabs
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int ntaps, stride, relu;
+    int ntiles;             // forward: 32-pixel tiles
+    int mchunk, nsplit;     // wgrad
+    int tap_dh[9], tap_dw[9];
+};
+
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+    return u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+
+// ---------------------------------------------------------------------------------
+// forward: one wave = 32 pixels x NT*32 channels per step, grid-stride over pixel tiles
+// ---------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
+    constexpr int ROWB = NT * 64 + 16;                      // LDS row: NT*32 channels bf16 + pad
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * ROWB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned char* T = smem + wave * 32 * ROWB;
+    const int K = p.ntaps * p.Ci;
+
+    // filter operand (MFMA rows = output channels): lane (co = nt*32 + li, k = ks*16 + 8*lh + j)
+    bf16x8 wa[NT][2];
+    float bv[NT][4][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 16 + 8 * lh + j;
+                v[j] = k < K ? p.w[(size_t)k * p.Co + nt * 32 + li] : 0.f;
+            }
+            wa[nt][ks] = __builtin_bit_cast(bf16x8, pack8(v));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[nt][g][e] = p.bias ? p.bias[nt * 32 + 8 * g + 4 * lh + e] : 0.f;
+    }
+    // image operand (MFMA columns = pixels): this lane's 16 k's are fixed -> byte offset from the pixel and tap bit
+    int koff[2][8];
+    unsigned kbit[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * lh + j;
+            const bool kv = k < K;
+            const int tp = kv ? k / p.Ci : 0, c = kv ? k - tp * p.Ci : 0;
+            koff[ks][j] = ((p.tap_dh[tp] * p.Wi + p.tap_dw[tp]) * p.Ci + c) * 4;
+            kbit[ks][j] = kv ? (1u << tp) : 0u;
+        }
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
+
+    const int nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += nwaves) {
+        const int m = tile * 32 + li;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oh = t2 % p.Ho;
+        const int b = t2 / p.Ho;
+        const int h0 = oh * p.stride, w0 = ow * p.stride;
+        unsigned mk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int sh = h0 + p.tap_dh[t], sw = w0 + p.tap_dw[t];
+            if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi) mk |= 1u << t;
+        }
+        if (m >= p.M) mk = 0;
+        const unsigned base = (unsigned)(((b * p.Hi + h0) * p.Wi + w0) * p.Ci) * 4u;
+        bf16x8 xb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned ok = 0u - (unsigned)((mk & kbit[ks][j]) != 0u);
+                const unsigned off = ((base + (unsigned)koff[ks][j]) & ok) | (OOBF & ~ok);
+                v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, 0, 0));
+            }
+            xb[ks] = __builtin_bit_cast(bf16x8, pack8(v));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[nt][0], xb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[nt][1], xb[1], acc, 0, 0, 0);
+            // D rows = channels (r&3) + 8*(r>>2) + 4*lh, D col = pixel li: 4 consecutive channels per register quad
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[4 * g + e] + bv[nt][g][e];
+                    if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<u32x2*>(T + li * ROWB + (nt * 32 + 8 * g + 4 * lh) * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        }
+        // wave-private tile -> global, 16 bytes per lane, whole rows (NT*64 bytes per pixel)
+        constexpr int CPR = NT * 4;                  // 16-byte chunks per pixel row
+        constexpr int PPI = 64 / CPR;                // pixels per store instruction
+#pragma unroll
+        for (int i = 0; i < 32 / PPI; ++i) {
+            const int px = i * PPI + lane / CPR, ch = lane % CPR;
+            const int mo = tile * 32 + px;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(T + px * ROWB + ch * 16);
+            if (mo < p.M) *reinterpret_cast<u32x4*>(p.y + (size_t)mo * p.Co + ch * 8) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient: dW[k][n] = sum_m xcol[m][k] * dy[m][n], k = tap*Ci + c < 32
+// workgroup = one pixel split; waves (kh, nh): pixel half kh of every 64-pixel block, channel tile nh
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstArgs p) {
+    constexpr int BP = 64, XROWB = 64, YROWB = 128;         // LDS rows: 32 k bf16; 64 channels bf16
+    constexpr int X_LDS = BP * XROWB, STAGE = BP * (XROWB + YROWB);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int split = blockIdx.x;
+    const int mbeg = split * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int niter = (mend - mbeg + BP - 1) / BP;
+    const int K = p.ntaps * p.Ci;
+
+    // im2col staging: thread -> pixel row tid>>2, k = (tid&3)*8 .. +7
+    const int xr = tid >> 2, xq = tid & 3;
+    int koff[8];
+    unsigned kbit[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = xq * 8 + j;
+        const bool kv = k < K;
+        const int tp = kv ? k / p.Ci : 0, c = kv ? k - tp * p.Ci : 0;
+        koff[j] = ((p.tap_dh[tp] * p.Wi + p.tap_dw[tp]) * p.Ci + c) * 4;
+        kbit[j] = kv ? (1u << tp) : 0u;
+    }
+    // dy staging (LDS-DMA): 128-byte rows, slot p of row r holds chunk p ^ 4*((r>>1)&1)   (conv_bf16.hip)
+    const int yr = tid >> 3, ys = tid & 7;
+    const int ychunk = ys ^ (((yr >> 1) & 1) * 4);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((size_t)p.M * p.Co * 2u), 0x00020000);
+
+    auto stage_tile = [&](int it, int stage) {
+        unsigned char* S = smem + stage * STAGE;
+        const int mb = mbeg + it * BP;
+        {   // x: 8 gathered image values -> one 16-byte LDS store
+            const int m = mb + xr;
+            const int mm = m < mend ? m : 0;
+            const int ow = mm % p.Wo;
+            const int t2 = mm / p.Wo;
+            const int oh = t2 % p.Ho;
+            const int b = t2 / p.Ho;
+            const int h0 = oh * p.stride, w0 = ow * p.stride;
+            unsigned mk = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int sh = h0 + p.tap_dh[t], sw = w0 + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi) mk |= 1u << t;
+            }
+            if (m >= mend) mk = 0;
+            const unsigned base = (unsigned)(((b * p.Hi + h0) * p.Wi + w0) * p.Ci) * 4u;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned ok = 0u - (unsigned)((mk & kbit[j]) != 0u);
+                v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, ((base + (unsigned)koff[j]) & ok) | (OOBF & ~ok), 0, 0));
+            }
+            *reinterpret_cast<u32x4*>(S + xr * XROWB + xq * 16) = pack8(v);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {      // dy: 32 pixel rows per pass
+            const int m = mb + yr + j * 32;
+            const unsigned mk = 0u - (unsigned)(m < mend);
+            const unsigned off = (unsigned)((m * p.Co + ychunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(S + X_LDS + wave * 1024 + j * 4096), 16, (off & mk) | (OOBF & ~mk), 0, 0, 0);
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const int kh = wave >> 1, nh = wave & 1;
+    const int lh = lane >> 5, q = lane & 15, cb = (lane >> 4) & 1;
+    const int prow = kh * 32 + lh * 8 + (q >> 2);
+    // x rows are 64 bytes: four consecutive pixel rows tile one 256-byte bank row, no swizzle needed
+    const int xa = prow * XROWB + (cb * 2 + ((q >> 1) & 1)) * 16 + (q & 1) * 8;
+    const int ych = nh * 4 + cb * 2 + ((q >> 1) & 1);
+    const int ya = X_LDS + prow * YROWB + ((ych ^ (((prow >> 1) & 1) * 4)) * 16) + (q & 1) * 8;
+
+    auto tr8 = [&](const unsigned char* S, int off, int rowb) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off + 4 * rowb));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    if (niter > 0) stage_tile(0, 0);
+    for (int it = 0; it < niter; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < niter) stage_tile(it + 1, (it + 1) & 1);
+        const unsigned char* S = smem + (it & 1) * STAGE;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {       // this wave's 32 pixels = two 16-pixel MFMA steps
+            const s16x8 a = tr8(S, xa + st * 16 * XROWB, XROWB);
+            const s16x8 bq = tr8(S, ya + st * 16 * YROWB, YROWB);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), acc, 0, 0, 0);
+        }
+        if (tid < 64) {        // bias gradient: channel tid over the 64 pixel rows of the tile
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BP; ++r) {
+                const int slot = (tid >> 3) ^ (((r >> 1) & 1) * 4);
+                s += bf2f(*reinterpret_cast<const unsigned short*>(S + X_LDS + r * YROWB + slot * 16 + (tid & 7) * 2));
+            }
+            bsum += s;
+        }
+    }
+    // two partial slabs per split (pixel halves): slab index = 2*split + kh; the fixed-order reduce adds them
+    const size_t wcount = (size_t)K * p.Co;
+    float* slab = p.ws + (size_t)(2 * split + kh) * (wcount + p.Co);
+    const int li = lane & 31;
+    const int n = nh * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (k < K) slab[(size_t)k * p.Co + n] = acc[r];
+    }
+    if (tid < 64) {
+        slab[wcount + tid] = bsum;                                           // kh == 0 slab of this split
+        p.ws[(size_t)(2 * split + 1) * (wcount + p.Co) + wcount + tid] = 0.f;   // the kh == 1 slab carries no bias part
+    }
+}
+
+// ---------------------------------------------------------------------------------
+static void fill_args(FirstArgs& a, const ConvDesc& d) {
+    SSD_REQUIRE(d.Ci * d.KH * d.KW <= 32, "first-layer kernel: Ci*taps must be <= 32 (got %d)", d.Ci * d.KH * d.KW);
+    SSD_REQUIRE(d.Co == 64, "first-layer kernel: Co must be 64 (got %d)", d.Co);
+    SSD_REQUIRE((long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 30), "first-layer kernel: tensor too large");
+    a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
+    a.ntaps = d.KH * d.KW; a.stride = d.stride;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+}
+
+void conv_first_fwd_bf16(const ConvDesc& d, const float* x, const float* w, const float* bias, bf16_t* y, bool relu, hipStream_t s) {
+    FirstArgs a{};
+    fill_args(a, d);
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
+    a.ntiles = cdiv(a.M, 32);
+    int blocks = cdiv(a.ntiles, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    ProfScope prof("conv_first_fwd_bf16", conv_flops(d), 4.0 * d.B * d.Hi * d.Wi * d.Ci + 2.0 * a.M * d.Co, s);
+    hipLaunchKernelGGL(conv_first_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+static int first_wgrad_splits(const ConvDesc& d, int* mchunk) {
+    const int M = d.B * d.Ho * d.Wo;
+    int ns = cdiv(M, 64 * 24);                 // >= 24 iterations per workgroup
+    if (ns > 1024) ns = 1024;
+    if (ns < 1) ns = 1;
+    *mchunk = cdiv(cdiv(M, ns), 64) * 64;
+    return cdiv(M, *mchunk);
+}
+
+size_t conv_first_wgrad_bf16_ws_floats(const ConvDesc& d) {
+    int mchunk;
+    const int ns = first_wgrad_splits(d, &mchunk);
+    return (size_t)2 * ns * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
+}
+
+void conv_first_wgrad_bf16(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
+                           float weight_decay, float* ws, hipStream_t s) {
+    FirstArgs a{};
+    fill_args(a, d);
+    a.x = x; a.y = const_cast<bf16_t*>(dy); a.ws = ws;
+    a.nsplit = first_wgrad_splits(d, &a.mchunk);
+    {
+        ProfScope prof("conv_first_wgrad_bf16", conv_flops(d), 4.0 * d.B * d.Hi * d.Wi * d.Ci + 2.0 * a.M * d.Co, s);
+        hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(a.nsplit), dim3(256), 0, s, a);
+        HIP_OK(hipGetLastError());
+    }
+    wgrad_reduce(ws, 2 * a.nsplit, (size_t)a.ntaps * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+}
+
+}  // namespace ssd

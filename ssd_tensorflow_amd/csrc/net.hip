@@ -6,6 +6,8 @@
 
 namespace ssd {
 
+static bool first_layer_kernel(const ConvDesc& d) { return d.Ci * d.KH * d.KW <= 32 && d.Co == 64; }
+
 // fused head width: a multiple of 8 channels = whole 16-byte pieces in fp32 and in bf16 rows
 static int round8(int n) { return (n + 7) / 8 * 8; }
 
@@ -246,6 +248,7 @@ void Net::alloc() {
                 for (int b : {1, B}) {
                     const ConvDesc d = conv_desc(op, b);
                     ws = std::max(ws, (bf16_ && d.Ci % 8 == 0) ? conv_wgrad_bf16_ws_floats(d) : conv_wgrad_ws_floats(d));
+                    if (bf16_ && first_layer_kernel(d)) ws = std::max(ws, conv_first_wgrad_bf16_ws_floats(d));
                 }
         wgrad_ws_ = (float*)dalloc(ws * sizeof(float));
         l2_ws_ = (float*)dalloc(l2norm_bwd_ws_floats(B * 64 * 64, 512) * sizeof(float));
@@ -372,7 +375,9 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             const ConvDesc d = conv_desc(op, b);
             if (!bf16_)
                 conv_fwd(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<float*>(out.data), op.relu, cs);
-            else if (in.data_f32)       // conv1_1: fp32 image and master filter, bf16 out
+            else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
+                conv_first_fwd_bf16(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<bf16_t*>(out.data), op.relu, cs);
+            else if (in.data_f32)
                 conv_fwd_smallc_bf16out(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<bf16_t*>(out.data), op.relu, cs);
             else
                 conv_fwd_bf16(d, in.h(), wq_oi_ + op.w_off, params_ + op.b_off, out.data, out.data_f32, op.relu, cs);
@@ -449,8 +454,11 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
                 if (need_dx) conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, stream_);
             } else if (in.data_f32) {   // conv1_1
-                conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
-                                         wgrad_ws_, ws);
+                if (first_layer_kernel(d))
+                    conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
+                else
+                    conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
+                                             wgrad_ws_, ws);
             } else {
                 conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
                 if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, stream_);

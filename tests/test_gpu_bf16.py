@@ -159,6 +159,40 @@ def test_conv_bf16_full_size_layer():
     assert max_rel(bhost(gx_), xt.grad.permute(0, 2, 3, 1).numpy()) < TOL_BF
 
 
+FIRST_CASES = [('conv1_1 37x41 b2', 2, 37, 41), ('conv1_1 300x300 b1', 1, 300, 300), ('conv1_1 5x3 b3', 3, 5, 3),
+               ('conv1_1 64x64 b2 (whole tiles)', 2, 64, 64)]
+
+
+@pytest.mark.parametrize('case', FIRST_CASES, ids=[c[0] for c in FIRST_CASES])
+def test_first_layer_bf16(case):
+    """the dedicated conv1_1 kernels: fp32 image / master filter in, bf16 activations, fp32 gradients"""
+    name, b, hi, wi = case
+    ci, co, k = 3, 64, 3
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    ph, pw, ho, wo = conv_geom(hi, wi, k, 1, 1, 'SAME')
+    x = rng.integers(0, 256, (b, hi, wi, ci)).astype(np.float32)            # what the data pipeline feeds (training_data.py:100)
+    w = (rng.normal(0, 1, (k, k, ci, co)) / 100).astype(np.float32)
+    bias = rng.normal(0, 0.5, (co,)).astype(np.float32)
+    dy = q(rng.normal(0, 1, (b, ho, wo, co)))
+    xt, wt, bt, pre, y_ref = oracle_conv(x, q(w), bias, 1, 1, 'SAME', True)
+    gpre = qt(torch.tensor(dy).permute(0, 3, 1, 2) * (pre > 0).float())
+    pre.backward(gpre)
+    x_, w_, b_ = dev(x), dev(w), dev(bias)
+    geom = (b, hi, wi, ci, ho, wo, co, k, k, 1, 1, ph, pw)
+    y_ = torch.full((b, ho, wo, co), 9.0, dtype=torch.bfloat16, device='cuda')
+    check(lib.ssd_op_conv2d_first_fwd_bf16(ptr(x_), ptr(w_), ptr(b_), ptr(y_), *geom, 1, None))
+    e = max_rel(bhost(y_), y_ref.detach().permute(0, 2, 3, 1).numpy())
+    assert e < TOL_BF, f'{name}: forward max-rel {e:.3e}'
+    gdy_ = bdev(gpre.permute(0, 2, 3, 1).contiguous().numpy())
+    ws_ = torch.empty((lib.ssd_op_conv2d_first_wgrad_bf16_ws_floats(*geom),), dtype=torch.float32, device='cuda')
+    gw_ = torch.full((k, k, ci, co), 7.0, dtype=torch.float32, device='cuda'); gb_ = torch.full((co,), 7.0, dtype=torch.float32, device='cuda')
+    check(lib.ssd_op_conv2d_first_wgrad_bf16(ptr(x_), ptr(gdy_), ptr(gw_), ptr(gb_), ptr(w_), 0.0005, ptr(ws_), *geom, None))
+    e = max_rel(host(gw_), wt.grad.numpy() + 0.0005 * w)
+    assert e < TOL, f'{name}: wgrad max-rel {e:.3e}'
+    e = max_rel(host(gb_), bt.grad.numpy())
+    assert e < TOL, f'{name}: bias-grad max-rel {e:.3e}'
+
+
 def layer_local_forward_check(net, m, preset, b, x):
     """Every op's forward recomputed by the oracle from the GPU's own (bf16) input activation and the
     bf16-rounded filter; head outputs are fp32."""
@@ -174,8 +208,8 @@ def layer_local_forward_check(net, m, preset, b, x):
         a = nchw(A(op[2]))
         if op[0] == 'conv':
             _, name, _, k, stride, padding, dil = op
-            w = m.params[name + '/filter'].detach()
-            w = w if name == 'conv1_1' else qt(w)          # conv1_1 multiplies the fp32 image by the fp32 master
+            w = qt(m.params[name + '/filter'].detach())
+            a = qt(a)                                      # conv1_1 rounds the fp32 image too (0..255 integers are exact)
             xin = F.pad(a, (0, 1, 0, 1)) if padding == 'BR1' else a
             want = F.relu(ref.conv2d_tf(xin, w, stride, 'SAME' if padding == 'SAME' else 'VALID', dil)
                           + m.params[name + '/biases'].detach().view(1, -1, 1, 1))
