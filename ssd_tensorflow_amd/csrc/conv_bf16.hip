@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // scalar: LDS-DMA bases stay in SGPRs
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // scalar: LDS-DMA bases stay in SGPRs
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
     const int ntiles = p.ntaps * p.CT * p.NT;
     const int split = wgid / ntiles;
@@ -348,46 +348,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     const __amdgpu_buffer_rsrc_t y_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 2u), 0x00020000);
 
-    // this thread's X_N pixel rows, advanced by BP pixels per iteration (issue() runs for it = 0, 1, 2, ...):
-    // a mixed-radix add of BP = (adv_b, adv_h, adv_w) to (b, oh, ow), at most one carry per digit
+    // This thread's X_N pixel rows advance by BP pixels per iteration (issue() runs for it = 0, 1, 2, ...): a
+    // mixed-radix add of BP = (adv_b, adv_h, adv_w) to (b, oh, ow) with at most one carry per digit.  The byte
+    // offset of the row's pixel moves with it by uniform constants (no multiplies in the loop), and the tap's
+    // zero padding is an interval test on (oh, ow).
     const int adv_w = BP % p.Wo, adv_t = BP / p.Wo;
     const int adv_h = adv_t % p.Ho, adv_b = adv_t / p.Ho;
-    int pw[X_N], ph[X_N], pb[X_N];
+    const int C2 = p.Ci * 2;
+    const unsigned xadv = (unsigned)(((adv_b * p.Hi + adv_h * p.stride) * p.Wi + adv_w * p.stride) * C2);
+    const unsigned xadv_cw = (unsigned)((p.stride * p.Wi - p.Wo * p.stride) * C2);     // ow wrapped: next image row
+    const unsigned xadv_ch = (unsigned)((p.Hi - p.Ho * p.stride) * p.Wi * C2);         // oh wrapped: next image
+    const unsigned xtap = (unsigned)((dh * p.Wi + dw) * C2);
+    // oh*stride + dh in [0, Hi)  <=>  oh in [h_lo, h_hi]   (likewise ow)
+    const int h_lo = dh < 0 ? (-dh + p.stride - 1) / p.stride : 0, w_lo = dw < 0 ? (-dw + p.stride - 1) / p.stride : 0;
+    const int h_hi_ = (p.Hi - 1 - dh) >= 0 ? (p.Hi - 1 - dh) / p.stride : -1, w_hi_ = (p.Wi - 1 - dw) >= 0 ? (p.Wi - 1 - dw) / p.stride : -1;
+    const unsigned h_span = (unsigned)((h_hi_ < p.Ho - 1 ? h_hi_ : p.Ho - 1) - h_lo);   // wraps to huge when empty: the compare below then fails...
+    const unsigned w_span = (unsigned)((w_hi_ < p.Wo - 1 ? w_hi_ : p.Wo - 1) - w_lo);
+    const bool tap_empty = (int)h_span < 0 || (int)w_span < 0;                           // ...so an empty interval is flagged explicitly
+    int pw[X_N], ph[X_N];
+    unsigned xoff[X_N], yoff[Y_N];
 #pragma unroll
     for (int j = 0; j < X_N; ++j) {
         const int m = mbeg + xr + j * XRPP;
         pw[j] = m % p.Wo;
         const int t2 = m / p.Wo;
         ph[j] = t2 % p.Ho;
-        pb[j] = t2 / p.Ho;
+        const int pb = t2 / p.Ho;
+        xoff[j] = (unsigned)(((pb * p.Hi + ph[j] * p.stride) * p.Wi + pw[j] * p.stride) * C2 + (c0 + xchunk * 8) * 2) + xtap;
     }
+#pragma unroll
+    for (int j = 0; j < Y_N; ++j) yoff[j] = (unsigned)(((mbeg + yr + j * YRPP) * p.Co + n0 + ychunk * 8) * 2);
+    const unsigned xcm_t = tap_empty ? 0u : xcm;
 
+    // (the explicit (int) on the DMA offsets matters: hipcc 7.2 silently drops the HOST stub of this kernel when an
+    // unsigned expression over a captured array element converts implicitly there -- the library then fails to load)
     auto issue = [&](int it, int stage) {
         unsigned char* Xs = smem + stage * STAGE + wave * 1024;
         unsigned char* Ys = smem + stage * STAGE + X_LDS + wave * 1024;
-        const int mb = mbeg + it * BP;
+        const int left = mend - (mbeg + it * BP);          // rows of this tile inside the split
 #pragma unroll
         for (int j = 0; j < X_N; ++j) {
-            const int m = mb + xr + j * XRPP;
-            const int sh = ph[j] * p.stride + dh, sw = pw[j] * p.stride + dw;
-            const unsigned mk = xcm & (0u - (unsigned)(m < mend)) &
-                                (0u - ((unsigned)((unsigned)sh < (unsigned)p.Hi) & (unsigned)((unsigned)sw < (unsigned)p.Wi)));
-            const unsigned off = (unsigned)((((pb[j] * p.Hi + sh) * p.Wi + sw) * p.Ci + c0 + xchunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (off & mk) | (OOBH & ~mk), 0, 0, 0);
+            const bool ok = (xr + j * XRPP < left) && (unsigned)(ph[j] - h_lo) <= h_span && (unsigned)(pw[j] - w_lo) <= w_span;
+            const unsigned mk = xcm_t & (0u - (unsigned)ok);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)((xoff[j] & mk) | (OOBH & ~mk)), 0, 0, 0);
             pw[j] += adv_w;
-            const int cw = pw[j] >= p.Wo;
+            const bool cw = pw[j] >= p.Wo;
             pw[j] -= cw ? p.Wo : 0;
-            ph[j] += adv_h + cw;
-            const int ch = ph[j] >= p.Ho;
+            ph[j] += adv_h + (cw ? 1 : 0);
+            const bool ch = ph[j] >= p.Ho;
             ph[j] -= ch ? p.Ho : 0;
-            pb[j] += adv_b + ch;
+            xoff[j] += xadv + (cw ? xadv_cw : 0u) + (ch ? xadv_ch : 0u);
         }
 #pragma unroll
         for (int j = 0; j < Y_N; ++j) {
-            const int m = mb + yr + j * YRPP;
-            const unsigned mk = ycm & (0u - (unsigned)(m < mend));
-            const unsigned off = (unsigned)((m * p.Co + n0 + ychunk * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (off & mk) | (OOBH & ~mk), 0, 0, 0);
+            const unsigned mk = ycm & (0u - (unsigned)(yr + j * YRPP < left));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)((yoff[j] & mk) | (OOBH & ~mk)), 0, 0, 0);
+            yoff[j] += (unsigned)(BP * p.Co * 2);
         }
     };
 
