@@ -707,7 +707,8 @@ static WgradPlanH plan_wgrad_h(const ConvDesc& d) {
     p.CT = cdiv(d.Ci, p.bkt);
     p.NT = cdiv(d.Co, p.bnt);
     p.tiles = d.KH * d.KW * p.CT * p.NT;
-    int want = cdiv(1536, p.tiles);
+    static const int target_wgs = env_int("SSD_WGRAD_WGS_BF16", 1536);      // tuning override
+    int want = cdiv(target_wgs, p.tiles);
     if (want > 256) want = 256;          // the reduce pass reads every slab: keep it short
     int maxs = cdiv(M, 512);
     p.nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);

@@ -42,8 +42,10 @@ done
 cd "$R"
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap --per-layer $EXTRA > /dev/null 2> "$O/per_layer_events.txt"
 python bench.py $EXTRA > "$O/bench.json" 2> "$O/bench.stderr"
-python bench.py --mode infer --batch 128 --no-cpu-baseline > "$O/bench_infer_b128.json" 2>/dev/null
-python bench.py --mode decode --batch 128 --no-cpu-baseline > "$O/bench_decode_b128.json" 2>/dev/null
-python bench.py --preset vgg512 --batch 16 --no-cpu-baseline > "$O/bench_vgg512_b16.json" 2>/dev/null
+python bench.py --mode infer --batch 128 --no-cpu-baseline $EXTRA > "$O/bench_infer_b128.json" 2>/dev/null
+python bench.py --preset vgg512 --batch 16 --no-cpu-baseline $EXTRA > "$O/bench_vgg512_b16.json" 2>/dev/null
+if [ -z "$EXTRA" ]; then
+    python bench.py --mode decode --batch 128 --no-cpu-baseline > "$O/bench_decode_b128.json" 2>/dev/null
+fi
 cat "$O/bench.json"
 head -4 "$O/rocprofv3_kernel_stats_serialized.csv" | cut -c1-160
