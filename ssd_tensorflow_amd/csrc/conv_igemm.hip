@@ -330,6 +330,188 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 }
 
 // =================================================================================
+// The same gather-GEMM with LDS-DMA staging (`buffer_load_dwordx4 ... lds`, as conv_bf16.hip): no staging
+// registers, no ds_write, the zero padding still a per-lane out-of-range offset.  Tiles are unpadded
+// 128-byte rows (32 k); the +4 pad's job is done by an XOR swizzle on the SOURCE chunk: LDS slot p of row
+// r holds 16-byte chunk p ^ ((r>>1)&7), which keeps every 16-lane ds_read_b128 group on 16 distinct slots.
+// The forward filter tile stays [32 k][BN] (natural HWIO rows, ds_read_b32 by n).  Fast path only
+// (channel counts multiples of 4, no strided data gradient); the register-staged kernel above keeps the rest.
+// =================================================================================
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_N = BM / 32;                      // DMA instructions per thread: A tile (8 rows x 128 B per wave-instruction)
+    constexpr int B_CPR = BN / 4;                     // forward: 16-byte chunks per k-row of the filter tile
+    constexpr int B_RPP = 256 / B_CPR;                // forward: k-rows per pass
+    constexpr int B_N = MODE == MODE_FWD ? BK / B_RPP : BN / 32;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BK % B_RPP == 0, "filter tile vs staging pass");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / p.NT, nt = wg - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int a_c4 = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;      // this lane's (swizzled) k offset inside the 32-wide block
+    unsigned a_off[A_N], a_msk[A_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.DW;
+        const int t2 = mm / p.DW;
+        const int oh = t2 % p.DH;
+        const int b = t2 / p.DH;
+        const int rh = m < p.M ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
+        a_off[i] = (unsigned)((b * p.SH * p.SW + rh * p.SW + rw) * p.SC + a_c4) * 4u;
+        unsigned mk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int sh = rh + p.tap_dh[t], sw = rw + p.tap_dw[t];
+            if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+        }
+        a_msk[i] = mk;
+    }
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.wci * p.wco * 4u), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    // filter tile addressing that does not change over the k loop
+    unsigned b_off[B_N], b_ok[B_N];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+        if constexpr (MODE == MODE_FWD) {           // row = k (channel), 16-byte chunk = 4 output channels
+            const int kr = tid / B_CPR + B_RPP * i, col = (tid % B_CPR) * 4;
+            b_ok[i] = 0u - (unsigned)(n0 + col < p.DN);
+            b_off[i] = (unsigned)(kr * p.wco + n0 + col) * 4u;
+        } else {                                     // row = n (dx channel), chunk = 4 dy channels (swizzled like A)
+            const int n = n0 + (tid >> 3) + 32 * i;
+            b_ok[i] = 0u - (unsigned)(n < p.DN);
+            b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.wco + a_c4) * 4u;
+        }
+    }
+
+    const int nchunks = (p.SC + BK - 1) / BK;
+    const int nk = nchunks * p.ntaps;
+
+    auto issue = [&](int kiter, int stage) {
+        const int cc = kiter / p.ntaps;
+        const int tap = kiter - cc * p.ntaps;
+        unsigned char* As = lds + stage * STAGE + wave * 1024;
+        unsigned char* Bs = lds + stage * STAGE + A_BYTES + wave * 1024;
+        const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * BK) * 4);
+        const unsigned cmask = 0u - (unsigned)(cc * BK + a_c4 < p.SC);
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)(((a_off[i] + toff) & m) | (OOB & ~m)), 0, 0, 0);
+        }
+        if constexpr (MODE == MODE_FWD) {
+            const unsigned woff = (unsigned)((tap * p.wci + cc * BK) * p.wco) * 4u;
+#pragma unroll
+            for (int i = 0; i < B_N; ++i) {
+                const int kr = tid / B_CPR + B_RPP * i;
+                const unsigned m = b_ok[i] & (0u - (unsigned)(cc * BK + kr < p.SC));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOB & ~m)), 0, 0, 0);
+            }
+        } else {
+            const unsigned woff = (unsigned)(tap * p.wci * p.wco + cc * BK) * 4u;
+#pragma unroll
+            for (int i = 0; i < B_N; ++i) {
+                const unsigned m = b_ok[i] & cmask;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOB & ~m)), 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    // fragment byte address inside a stage: row*128 + ((2g + lh) ^ swz(row))*16 = (row*128 + q0) ^ (g*32)
+    const int q0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int a_row = (wm * 32 * TM + li) * 128 + q0;
+    const int b_row = A_BYTES + (wn * 32 * TN + li) * 128 + q0;                // data gradient
+    const int b_col = A_BYTES + (wn * 32 * TN + li) * 4;                        // forward: [k][BN] floats
+
+    auto compute = [&](int stage) {
+        const unsigned char* S = lds + stage * STAGE;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(S + ((a_row + mi * 4096) ^ (g * 32)));
+            if constexpr (MODE == MODE_FWD) {
+                const int kb = g * 8 + lh * 4;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[ni][t] = *reinterpret_cast<const float*>(S + b_col + ((kb + t) * BN + ni * 32) * 4);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(S + ((b_row + ni * 4096) ^ (g * 32)));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
+    issue(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
+        compute(k & 1);
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.DN) continue;
+            float bv = 0.f;
+            if constexpr (MODE == MODE_FWD) bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const size_t o = (size_t)m * p.DN + n;
+                float v = acc[mi][ni][r];
+                if constexpr (MODE == MODE_FWD) {
+                    v += bv;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                } else {
+                    if (p.accum) v += p.dst[o];
+                    if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
+                }
+                p.dst[o] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================
 // weight gradient:  dW[(tap, c)][n] = sum_m x[pix(m, tap)][c] * dy[m][n]
 // One workgroup owns (tap, channel tile, n tile, pixel split); 32 pixels per iteration.
 // MFMA roles: A[i = channel][k = pixel], B[k = pixel][j = n]; both tiles are stored
@@ -630,6 +812,26 @@ static void check_desc(const ConvDesc& d) {
                 "conv: tensor too large for 32-bit pixel indexing");
 }
 
+template <int MODE, int WM, int WN, int TM, int TN>
+static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    const int MT = cdiv(a.M, BM);
+    a.NT = cdiv(a.DN, BN);
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+// LDS-DMA staging for the fast path (SSD_GLDS=0 selects the register-staged kernels: A/B switch)
+static bool use_dma() {
+    static const int v = env_int("SSD_GLDS", 1);
+    return v != 0;
+}
+
 // Tile choice: all co-resident workgroups of a CU share its matrix pipes, so a launch costs
 // about ceil(workgroups / 256 CUs) * BM * BN (tile work incl. padded rows/columns) divided by a
 // per-tile efficiency (bigger tiles re-use LDS fragments better).  0:128x128 1:128x64 2:64x128 3:64x64
@@ -673,6 +875,15 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
         else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
         return;
     }
+    if (use_dma()) {
+        switch (pick_tile(a.M, a.DN, MODE_FWD)) {
+        case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2>(a, "conv_fwd_128x128", fl, by, s); break;
+        case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2>(a, "conv_fwd_128x64", fl, by, s); break;
+        case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2>(a, "conv_fwd_64x128", fl, by, s); break;
+        default: launch_gather_dma<MODE_FWD, 2, 2, 1, 1>(a, "conv_fwd_64x64", fl, by, s); break;
+        }
+        return;
+    }
     switch (pick_tile(a.M, a.DN, MODE_FWD)) {
     case 0: launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, "conv_fwd_128x128", fl, by, s); break;
     case 1: launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, "conv_fwd_128x64", fl, by, s); break;
@@ -710,6 +921,13 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
         if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
+    } else if (use_dma()) {
+        switch (cfg) {
+        case 0: launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2>(a, "conv_dgrad_128x128", fl, by, s); break;
+        case 1: launch_gather_dma<MODE_DGRAD, 4, 1, 1, 2>(a, "conv_dgrad_128x64", fl, by, s); break;
+        case 2: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2>(a, "conv_dgrad_64x128", fl, by, s); break;
+        default: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1>(a, "conv_dgrad_64x64", fl, by, s); break;
+        }
     } else {
         switch (cfg) {
         case 0: launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, "conv_dgrad_128x128", fl, by, s); break;
