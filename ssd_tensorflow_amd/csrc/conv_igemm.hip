@@ -842,7 +842,11 @@ static int pick_tile(long long M, int N, int mode) {
     // relative per-tile efficiency measured on vgg300 layers at batch 32 (tools/bench_conv.py):
     // forward runs 116-125 TF/s on every tile; the data-gradient is fastest on 64x64
     static const double eff_fwd[4] = {0.98, 1.0, 1.0, 0.95}, eff_dg[4] = {0.93, 0.92, 0.93, 1.0};
-    const double* eff = mode == MODE_FWD ? eff_fwd : eff_dg;
+    // ... and again with the LDS-DMA kernels (no staging registers): forward is best on 128x128 (conv2_2 126,
+    // conv3_2 131, conv4_2 125 TF/s), the data gradient on 64x128 (123-128), on 64x64 when N = 64 (conv1_2 110)
+    static const double dma_fwd[4] = {1.03, 1.0, 1.0, 0.96}, dma_dg[4] = {0.96, 0.97, 1.0, 0.94};
+    if (use_dma() && mode == MODE_DGRAD && N <= 64) return 3;
+    const double* eff = use_dma() ? (mode == MODE_FWD ? dma_fwd : dma_dg) : (mode == MODE_FWD ? eff_fwd : eff_dg);
     int best = 0;
     double bc = 1e300;
     for (int c = 0; c < 4; ++c) {
