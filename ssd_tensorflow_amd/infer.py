@@ -49,6 +49,7 @@ def main(argv=None):
     parser.add_argument('--pascal-summary', default='False', help='out of scope (VOC submission files)')
     parser.add_argument('--synthetic', type=int, default=0, help='run on N synthetic images instead of files')
     parser.add_argument('--preset', default=None, help='preset when no checkpoint is given')
+    parser.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='f32, or bf16 activations on the bf16 matrix cores (fp32 master weights, loss and optimizer)')
     args = parser.parse_args(argv)
 
     # ---- checkpoint lookup (infer.py:111-126) --------------------------------------------------
@@ -77,10 +78,10 @@ def main(argv=None):
         if ckpt:
             pname = str(np.load(ckpt)['__preset__'])
             net = SSDVGG(sess, get_preset_by_name(pname))
-            net.build_from_metagraph(None, ckpt, max_batch=args.batch_size)
+            net.build_from_metagraph(None, ckpt, max_batch=args.batch_size, dtype=args.dtype)
         else:
             net = SSDVGG(sess, get_preset_by_name(args.preset))
-            net.build_from_vgg(None, 20, max_batch=args.batch_size, training=False)
+            net.build_from_vgg(None, 20, max_batch=args.batch_size, training=False, dtype=args.dtype)
         size = net.preset.image_size
         files = list(args.files)
         if args.synthetic:

@@ -37,6 +37,7 @@ def main(argv=None):
     parser.add_argument('--continue-training', type=str2bool, default='False', help='continue training from the latest checkpoint')
     parser.add_argument('--num-workers', type=int, default=0, help='number of parallel generators')
     parser.add_argument('--preset', default='vgg300')
+    parser.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='f32, or bf16 activations on the bf16 matrix cores (fp32 master weights, loss and optimizer)')
     parser.add_argument('--synthetic-train', type=int, default=64, help='synthetic training samples per epoch')
     parser.add_argument('--synthetic-valid', type=int, default=16)
     args = parser.parse_args(argv)
@@ -89,10 +90,10 @@ def main(argv=None):
         say('[i] Creating the model...')
         net = SSDVGG(sess, td.preset)
         if ckpt:
-            net.build_from_metagraph(None, ckpt, max_batch=args.batch_size, training=True)
+            net.build_from_metagraph(None, ckpt, max_batch=args.batch_size, training=True, dtype=args.dtype)
             net.build_optimizer_from_metagraph()
         else:
-            net.build_from_vgg(args.vgg_dir, td.num_classes, max_batch=args.batch_size)
+            net.build_from_vgg(args.vgg_dir, td.num_classes, max_batch=args.batch_size, dtype=args.dtype)
             net.build_optimizer(learning_rate=lr, weight_decay=args.weight_decay, momentum=args.momentum)
         if world > 1:
             torch.distributed.broadcast(net.params_flat, 0)
