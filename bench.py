@@ -35,37 +35,44 @@ PEAK_HBM = 8000.0           # GB/s spec
 
 
 # kernel label (event profiler) -> substring of the kernel symbol in rocprofv3 output
+def _gather(mode, wm, wn, tm, tn):
+    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d>' % (mode, wm, wn, tm, tn),            # default (LDS-DMA staging)
+            'conv_gather_kernel<%d, %d, %d, %d, %d, false, false' % (mode, wm, wn, tm, tn)]    # SSD_GLDS=0
+
+
+# profiler label -> kernel symbol(s) in the rocprofv3 --pmc passes
 KERNEL_SYMBOLS = {
-    'conv_fwd_128x128': 'conv_gather_kernel<0, 2, 2, 2, 2, false, false', 'conv_fwd_128x64': 'conv_gather_kernel<0, 4, 1, 1, 2, false, false',
-    'conv_fwd_64x128': 'conv_gather_kernel<0, 2, 2, 1, 2, false, false', 'conv_fwd_64x64': 'conv_gather_kernel<0, 2, 2, 1, 1, false, false',
-    'conv_dgrad_128x128': 'conv_gather_kernel<1, 2, 2, 2, 2, false, false', 'conv_dgrad_128x64': 'conv_gather_kernel<1, 4, 1, 1, 2, false, false',
-    'conv_dgrad_64x128': 'conv_gather_kernel<1, 2, 2, 1, 2, false, false', 'conv_dgrad_64x64': 'conv_gather_kernel<1, 2, 2, 1, 1, false, false',
-    'conv_wgrad_128x128': 'conv_wgrad_kernel<2, 2, 2, 2, false>', 'conv_wgrad_64x64': 'conv_wgrad_kernel<2, 2, 1, 1, false>',
-    'conv_wgrad_64x128': 'conv_wgrad_kernel<2, 2, 1, 2, false>', 'conv_wgrad_128x64': 'conv_wgrad_kernel<2, 2, 2, 1, false>',
-    'detect_scan': 'detect_scan_kernel',
-    'conv_fwd_bf16_128x128': 'conv_gather_bf16_kernel<0, 2, 2, 2, 2, false', 'conv_fwd_bf16_128x64': 'conv_gather_bf16_kernel<0, 4, 1, 1, 2, false',
-    'conv_fwd_bf16_64x128': 'conv_gather_bf16_kernel<0, 2, 2, 1, 2, false', 'conv_fwd_bf16_256x128': 'conv_gather_bf16_kernel<0, 2, 2, 4, 2, false',
-    'conv_dgrad_bf16_128x128': 'conv_gather_bf16_kernel<1, 2, 2, 2, 2, false', 'conv_dgrad_bf16_128x64': 'conv_gather_bf16_kernel<1, 4, 1, 1, 2, false',
-    'conv_dgrad_bf16_64x128': 'conv_gather_bf16_kernel<1, 2, 2, 1, 2, false', 'conv_dgrad_bf16_256x128': 'conv_gather_bf16_kernel<1, 2, 2, 4, 2, false',
-    'conv_wgrad_bf16_128x128': 'conv_wgrad_bf16_kernel<2, 2, 2, 2>', 'conv_wgrad_bf16_64x64': 'conv_wgrad_bf16_kernel<2, 2, 1, 1>',
-    'conv_wgrad_bf16_64x128': 'conv_wgrad_bf16_kernel<2, 2, 1, 2>', 'conv_wgrad_bf16_128x64': 'conv_wgrad_bf16_kernel<2, 2, 2, 1>',
+    'conv_fwd_128x128': _gather(0, 2, 2, 2, 2), 'conv_fwd_128x64': _gather(0, 4, 1, 1, 2),
+    'conv_fwd_64x128': _gather(0, 2, 2, 1, 2), 'conv_fwd_64x64': _gather(0, 2, 2, 1, 1),
+    'conv_dgrad_128x128': _gather(1, 2, 2, 2, 2), 'conv_dgrad_128x64': _gather(1, 4, 1, 1, 2),
+    'conv_dgrad_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_64x64': _gather(1, 2, 2, 1, 1),
+    'conv_wgrad_128x128': ['conv_wgrad_kernel<2, 2, 2, 2, false'], 'conv_wgrad_64x64': ['conv_wgrad_kernel<2, 2, 1, 1, false'],
+    'conv_wgrad_64x128': ['conv_wgrad_kernel<2, 2, 1, 2, false'], 'conv_wgrad_128x64': ['conv_wgrad_kernel<2, 2, 2, 1, false'],
+    'detect_scan': ['detect_scan_kernel'],
+    'conv_fwd_bf16_128x128': ['conv_gather_bf16_kernel<0, 2, 2, 2, 2, false, 2>'], 'conv_fwd_bf16_128x64': ['conv_gather_bf16_kernel<0, 4, 1, 1, 2, false, 2>'],
+    'conv_fwd_bf16_64x128': ['conv_gather_bf16_kernel<0, 2, 2, 1, 2, false, 2>'],
+    'conv_dgrad_bf16_128x128': ['conv_gather_bf16_kernel<1, 2, 2, 2, 2, false, 2>'], 'conv_dgrad_bf16_128x64': ['conv_gather_bf16_kernel<1, 4, 1, 1, 2, false, 2>'],
+    'conv_dgrad_bf16_64x128': ['conv_gather_bf16_kernel<1, 2, 2, 1, 2, false, 2>'],
+    'conv_wgrad_bf16_128x128': ['conv_wgrad_bf16_kernel<2, 2, 2, 2, 2>'], 'conv_wgrad_bf16_64x64': ['conv_wgrad_bf16_kernel<2, 2, 1, 1, 2>'],
+    'conv_wgrad_bf16_64x128': ['conv_wgrad_bf16_kernel<2, 2, 1, 2, 2>'], 'conv_wgrad_bf16_128x64': ['conv_wgrad_bf16_kernel<2, 2, 2, 1, 2>'],
 }
 
 
-def pmc_traffic(label):
-    """HBM bytes per launch of `label`'s kernel from the newest committed rocprofv3 --pmc passes
+def pmc_traffic(label, dtype='f32'):
+    """HBM bytes per launch of `label`'s kernel from the newest committed rocprofv3 --pmc passes of that dtype
     (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt; separate passes, KB units, FETCH_SIZE
     doubled on gfx950 as MI355X_MICROARCH.md prescribes).  None when no pass is committed."""
     import glob
-    sym = KERNEL_SYMBOLS.get(label)
-    f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_FETCH_SIZE.txt')))
-    w = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_WRITE_SIZE.txt')))
-    if not sym or not f or not w:
+    syms = KERNEL_SYMBOLS.get(label)
+    pick = (lambda n: 'bf16' in os.path.basename(n)) if dtype == 'bf16' else (lambda n: 'bf16' not in os.path.basename(n))
+    f = sorted(n for n in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_FETCH_SIZE.txt')) if pick(n))
+    w = sorted(n for n in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_WRITE_SIZE.txt')) if pick(n))
+    if not syms or not f or not w:
         return None, None
 
     def avg(path):
         for line in open(path):
-            if sym in line:
+            if any(sym in line for sym in syms):
                 return float(line.split('avg=')[1].split()[0])
         return None
     fa, wa = avg(f[-1]), avg(w[-1])
@@ -311,7 +318,7 @@ def main():
             'roofline': roofline,
         }
         if roofline is not None and world == 1:
-            tr, src = pmc_traffic(roofline['kernel'])
+            tr, src = pmc_traffic(roofline['kernel'], args.dtype)
             if tr is not None:
                 roofline['traffic'] = tr
                 roofline['traffic_source'] = src
