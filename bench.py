@@ -46,8 +46,10 @@ KERNEL_SYMBOLS = {
     'conv_fwd_64x128': _gather(0, 2, 2, 1, 2), 'conv_fwd_64x64': _gather(0, 2, 2, 1, 1),
     'conv_dgrad_128x128': _gather(1, 2, 2, 2, 2), 'conv_dgrad_128x64': _gather(1, 4, 1, 1, 2),
     'conv_dgrad_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_64x64': _gather(1, 2, 2, 1, 1),
-    'conv_wgrad_128x128': ['conv_wgrad_kernel<2, 2, 2, 2, false'], 'conv_wgrad_64x64': ['conv_wgrad_kernel<2, 2, 1, 1, false'],
-    'conv_wgrad_64x128': ['conv_wgrad_kernel<2, 2, 1, 2, false'], 'conv_wgrad_128x64': ['conv_wgrad_kernel<2, 2, 2, 1, false'],
+    'conv_wgrad_128x128': ['conv_wgrad_kernel<2, 2, 2, 2, false', 'conv_wgrad_dma_kernel<2, 2, 2, 2>'],
+    'conv_wgrad_64x64': ['conv_wgrad_dma_kernel<2, 2, 1, 1>', 'conv_wgrad_kernel<2, 2, 1, 1, false'],
+    'conv_wgrad_64x128': ['conv_wgrad_dma_kernel<2, 2, 1, 2>', 'conv_wgrad_kernel<2, 2, 1, 2, false'],
+    'conv_wgrad_128x64': ['conv_wgrad_kernel<2, 2, 2, 1, false', 'conv_wgrad_dma_kernel<2, 2, 2, 1>'],
     'detect_scan': ['detect_scan_kernel'],
     'conv_fwd_bf16_128x128': ['conv_gather_bf16_kernel<0, 2, 2, 2, 2, false, 2>'], 'conv_fwd_bf16_128x64': ['conv_gather_bf16_kernel<0, 4, 1, 1, 2, false, 2>'],
     'conv_fwd_bf16_64x128': ['conv_gather_bf16_kernel<0, 2, 2, 1, 2, false, 2>'],

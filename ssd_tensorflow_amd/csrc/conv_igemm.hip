@@ -739,6 +739,163 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
 }
 
+// The weight gradient with LDS-DMA staging: x and dy tiles keep their pixel-major global rows in LDS (what the
+// ds_read_b32 fragment reads want anyway), so a tile is a plain DMA copy -- no staging registers, no ds_write.
+// Each staged row walks (b, oh, ow) by a mixed-radix add of 32 pixels per iteration; its byte offset moves with it
+// by uniform constants and the tap's zero padding is an interval test (no multiplies or divisions in the loop).
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 32;
+    constexpr int XC = BKT / 4, YC = BNT / 4;                   // 16-byte chunks per pixel row
+    constexpr int XRPP = 256 / XC, YRPP = 256 / YC;             // pixel rows per DMA pass of the workgroup
+    constexpr int X_N = BP / XRPP, Y_N = BP / YRPP;
+    constexpr int X_BYTES = BP * BKT * 4, STAGE = BP * (BKT + BNT) * 4;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = p.ntaps_grid * p.CT * p.NT;
+    const int split = wgid / ntiles;
+    int tile = wgid - split * ntiles;
+    const int nt = tile % p.NT;
+    tile /= p.NT;
+    const int ct = tile % p.CT;
+    const int tap = tile / p.CT;
+    const int c0 = ct * BKT, n0 = nt * BNT;
+    const int mbeg = split * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    const int niter = (mend - mbeg + BP - 1) / BP;
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const bool do_bias = (tap == 0 && ct == 0);
+
+    const int xr = tid / XC, xc = tid % XC, yr = tid / YC, yc = tid % YC;
+    const unsigned xcm = 0u - (unsigned)(c0 + xc * 4 < p.Ci), ycm = 0u - (unsigned)(n0 + yc * 4 < p.Co);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)((size_t)p.M * p.Co * 4u), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    const int adv_w = BP % p.Wo, adv_t = BP / p.Wo;
+    const int adv_h = adv_t % p.Ho, adv_b = adv_t / p.Ho;
+    const int C4 = p.Ci * 4;
+    const unsigned xadv = (unsigned)(((adv_b * p.Hi + adv_h * p.stride) * p.Wi + adv_w * p.stride) * C4);
+    const unsigned xadv_cw = (unsigned)((p.stride * p.Wi - p.Wo * p.stride) * C4);     // ow wrapped: next image row
+    const unsigned xadv_ch = (unsigned)((p.Hi - p.Ho * p.stride) * p.Wi * C4);         // oh wrapped: next image
+    // oh*stride + dh in [0, Hi)  <=>  oh in [h_lo, h_lo + h_span]   (likewise ow)
+    const int h_lo = dh < 0 ? (-dh + p.stride - 1) / p.stride : 0, w_lo = dw < 0 ? (-dw + p.stride - 1) / p.stride : 0;
+    const int h_hi = (p.Hi - 1 - dh) >= 0 ? (p.Hi - 1 - dh) / p.stride : -1, w_hi = (p.Wi - 1 - dw) >= 0 ? (p.Wi - 1 - dw) / p.stride : -1;
+    const int h_span_i = (h_hi < p.Ho - 1 ? h_hi : p.Ho - 1) - h_lo, w_span_i = (w_hi < p.Wo - 1 ? w_hi : p.Wo - 1) - w_lo;
+    const unsigned xcm_t = (h_span_i < 0 || w_span_i < 0) ? 0u : xcm;                  // the tap never touches the image
+    const unsigned h_span = (unsigned)h_span_i, w_span = (unsigned)w_span_i;
+    int pw[X_N], ph[X_N];
+    unsigned xoff[X_N], yoff[Y_N];
+#pragma unroll
+    for (int j = 0; j < X_N; ++j) {
+        const int m = mbeg + xr + j * XRPP;
+        pw[j] = m % p.Wo;
+        const int t2 = m / p.Wo;
+        ph[j] = t2 % p.Ho;
+        const int pb = t2 / p.Ho;
+        xoff[j] = (unsigned)(((pb * p.Hi + ph[j] * p.stride + dh) * p.Wi + pw[j] * p.stride + dw) * C4 + (c0 + xc * 4) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < Y_N; ++j) yoff[j] = (unsigned)(((mbeg + yr + j * YRPP) * p.Co + n0 + yc * 4) * 4);
+
+    auto issue = [&](int it, int stage) {
+        unsigned char* Xs = lds + stage * STAGE + wave * 1024;
+        unsigned char* Ys = lds + stage * STAGE + X_BYTES + wave * 1024;
+        const int left = mend - (mbeg + it * BP);
+#pragma unroll
+        for (int j = 0; j < X_N; ++j) {
+            const bool ok = (xr + j * XRPP < left) && (unsigned)(ph[j] - h_lo) <= h_span && (unsigned)(pw[j] - w_lo) <= w_span;
+            const unsigned mk = xcm_t & (0u - (unsigned)ok);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)((xoff[j] & mk) | (OOB & ~mk)), 0, 0, 0);
+            pw[j] += adv_w;
+            const bool cw = pw[j] >= p.Wo;
+            pw[j] -= cw ? p.Wo : 0;
+            ph[j] += adv_h + (cw ? 1 : 0);
+            const bool ch = ph[j] >= p.Ho;
+            ph[j] -= ch ? p.Ho : 0;
+            xoff[j] += xadv + (cw ? xadv_cw : 0u) + (ch ? xadv_ch : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < Y_N; ++j) {
+            const unsigned mk = ycm & (0u - (unsigned)(yr + j * YRPP < left));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)((yoff[j] & mk) | (OOB & ~mk)), 0, 0, 0);
+            yoff[j] += (unsigned)(BP * p.Co * 4);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int stage) {
+        const float* Xs = reinterpret_cast<const float*>(lds + stage * STAGE);
+        const float* Ys = reinterpret_cast<const float*>(lds + stage * STAGE + X_BYTES);
+#pragma unroll 4
+        for (int st = 0; st < BP / 2; ++st) {
+            const int r = st * 2 + lh;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = Xs[r * BKT + wm * 32 * TM + mi * 32 + li];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = Ys[r * BNT + wn * 32 * TN + ni * 32 + li];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (do_bias && tid < BNT) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BP; ++r) s += Ys[r * BNT + tid];
+            bsum += s;
+        }
+    };
+
+    if (niter > 0) issue(0, 0);
+    for (int it = 0; it < niter; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+        compute(it & 1);
+    }
+
+    const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c0 + kl >= p.Ci) continue;
+                slab[((size_t)tap * p.Ci + c0 + kl) * p.Co + n] = acc[mi][ni][r];
+            }
+        }
+    }
+    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+}
+
 // Fixed-order reduce of the split slabs: dw = sum_s slab_s + wd*w ; db = sum_s bias_s.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t wcount,
                                                            int Co, float* __restrict__ dw, float* __restrict__ db,
@@ -830,6 +987,11 @@ static void launch_gather_dma(GatherArgs& a, const char* label, double flops, do
 static bool use_dma() {
     static const int v = env_int("SSD_GLDS", 1);
     return v != 0;
+}
+
+static int use_wgrad_dma() {
+    static const int v = env_int("SSD_GLDS_WGRAD", 1);
+    return use_dma() ? v : 0;
 }
 
 // Tile choice: all co-resident workgroups of a CU share its matrix pipes, so a launch costs
@@ -995,6 +1157,18 @@ static void launch_wgrad(WgradArgs& a, const WgradPlan& pl, const char* label, d
     HIP_OK(hipGetLastError());
 }
 
+template <int WM, int WN, int TM, int TN>
+static void launch_wgrad_dma(WgradArgs& a, const WgradPlan& pl, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)(32 * BKT + 32 * BNT) * sizeof(float);
+    auto kern = conv_wgrad_dma_kernel<WM, WN, TM, TN>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit * pl.tiles), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
 void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
                   hipStream_t s) {
     const size_t total = wcount + Co;
@@ -1028,6 +1202,12 @@ static void conv_wgrad_any(const ConvDesc& d, const float* x, const void* dy, bo
     const double fl = conv_flops(d), by = conv_bytes(d);
     if (pl.smallc && dy_bf16) launch_wgrad<2, 2, 1, 1, true, true>(a, pl, "conv_wgrad_smallc_64x64_bf16dy", fl, by, s);
     else if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
+    // LDS-DMA staging pays on the 64-channel layers (conv1_2 86 -> 95, conv2_1 TF/s: their x rows are re-read by 9
+    // taps and the staging registers were the occupancy limit); the 128-wide tiles measure 0..-3 % (SSD_GLDS_WGRAD=2 forces them)
+    else if (use_wgrad_dma() >= 1 && pl.cfg == 1) launch_wgrad_dma<2, 2, 1, 1>(a, pl, "conv_wgrad_64x64", fl, by, s);
+    else if (use_wgrad_dma() >= 1 && pl.cfg == 2) launch_wgrad_dma<2, 2, 1, 2>(a, pl, "conv_wgrad_64x128", fl, by, s);
+    else if (use_wgrad_dma() >= 2 && pl.cfg == 3) launch_wgrad_dma<2, 2, 2, 1>(a, pl, "conv_wgrad_128x64", fl, by, s);
+    else if (use_wgrad_dma() >= 2 && pl.cfg == 0) launch_wgrad_dma<2, 2, 2, 2>(a, pl, "conv_wgrad_128x128", fl, by, s);
     else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, "conv_wgrad_64x64", fl, by, s);
     else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, "conv_wgrad_64x128", fl, by, s);
     else if (pl.cfg == 3) launch_wgrad<2, 2, 2, 1, false>(a, pl, "conv_wgrad_128x64", fl, by, s);
