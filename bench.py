@@ -114,6 +114,83 @@ def cpu_baseline(preset, seconds_hint=20):
                 sample=f'{n} full training steps at batch {b} ({preset}, fp32 torch-CPU restatement oracle/ssdvgg_ref.py)')
 
 
+def bench_augment(args, rank, world, local):
+    """the train augmentation recipe for one batch, decisions on the host (untimed, they are
+    microseconds per image), pixels on the GPU (timed: the two launches of ssd_augment_batch_dev on plans and
+    source images already resident).  CPU figure beside it: the numpy restatement (oracle/augment.py), one core."""
+    import random
+    import ctypes as C2
+    import torch
+    from ssd_tensorflow_amd._lib import lib, check
+    from ssd_tensorflow_amd import transforms as T
+    from ssd_tensorflow_amd.ssdutils import get_preset_by_name
+    from ssd_tensorflow_amd.utils import Sample, Box, Point, Size
+    preset = get_preset_by_name(args.preset)
+    W, H = preset.image_size.w, preset.image_size.h
+    nrng = np.random.default_rng(1234 + rank)
+    random.seed(1234 + rank)
+    b = args.batch
+    plans, raw = [], []
+    for i in range(b):
+        w0, h0 = int(nrng.integers(300, 640)), int(nrng.integers(300, 640))       # VOC-like image sizes
+        img = nrng.integers(0, 256, (h0, w0, 3)).astype(np.uint8)
+        n = int(nrng.integers(1, 6))
+        bw = nrng.uniform(0.1, 0.6, n); bh = nrng.uniform(0.1, 0.6, n)
+        boxes = [Box('c', int(c), Point(float(x), float(y)), Size(float(ww), float(hh)))
+                 for x, y, ww, hh, c in zip(nrng.uniform(bw / 2, 1 - bw / 2), nrng.uniform(bh / 2, 1 - bh / 2), bw, bh, nrng.integers(0, 20, n))]
+        tfs = [t for t in T.build_train_transforms(preset, 20, 50, 0.5, images={'im': img}) if not isinstance(t, T.LabelCreatorTransform)]
+        a = (None, None, Sample('im', boxes, Size(w0, h0)))
+        for t in tfs:
+            a = t(*a)
+        plans.append(a[0]); raw.append((img, boxes, (w0, h0)))
+    arr, packed = T.plan_params(plans, W, H)
+    dev = torch.device('cuda', local)
+    images = torch.from_numpy(packed).to(dev)
+    out = torch.empty((b, H, W, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.ssd_augment_ws_bytes(b, W, H),), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        check(lib.ssd_augment_batch_dev(images.data_ptr(), C2.cast(arr, C2.c_void_p), b, W, H, out.data_ptr(), ws.data_ptr(), stream))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / args.steps
+    bytes_launch = out.numel() * 4 + packed.size
+    ach = bytes_launch / (gpu_ms * 1e-3) / 1e9
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import augment as oa
+        ncpu = min(b, 8)
+        random.seed(1234 + rank)
+        t1 = time.perf_counter()
+        for i in range(ncpu):
+            img, boxes, size = raw[i]
+            p = oa.plan(oa.new_rng(99 + i), size, [(bb.center.x, bb.center.y, bb.size.w, bb.size.h) for bb in boxes], [bb.labelid for bb in boxes])
+            oa.apply(p, img, (W, H))
+        cpu = dict(value=round(ncpu / (time.perf_counter() - t1), 2), unit='images/s', cores=1, kind='port',
+                   sample=f'{ncpu} images through oracle/augment.py (numpy restatement of the recipe; OpenCV is not installed)')
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (train augmentation recipe -> %dx%d float32 batch) %s batch%d' % (W, H, args.preset, b),
+            'value': round(b * args.steps / dt, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u8->f32', 'data': 'synthetic',
+            'config': {'workload': 'process_dataset.py train recipe on %d synthetic uint8 images (300..640 px), plans and sources resident in HBM' % b},
+            'roofline': {'bound': 'hbm', 'kernel': 'augment_gather', 'achieved': round(ach, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
+                         'frac': round(ach / PEAK_HBM, 4), 'traffic': None, 'avg_launch_us': round(gpu_ms * 1e3, 2), 'bytes_per_launch': bytes_launch,
+                         'measured': 'HIP events around %d back-to-back batches (taps + gather launches)' % args.steps},
+            'cpu_baseline': cpu}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -121,7 +198,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--preset', default='vgg300')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment'])
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -156,6 +233,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.mode == 'augment':
+        return bench_augment(args, rank, world, local)
     b = args.batch
     bucket = int(args.bucket_mb * 1e6 / 4)
     state = {'bucket': bucket}

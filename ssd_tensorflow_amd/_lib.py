@@ -55,6 +55,8 @@ SIGNATURES = {
     'ssd_anchors_dev': (i32, [cstr, vp, vp, vp]),
     'ssd_average_precision': (i32, [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_double, vp, vp]),
     'ssd_arena_floats': (sz, [cstr, i32]),
+    'ssd_augment_ws_bytes': (sz, [i32, i32, i32]),
+    'ssd_augment_batch_dev': (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'ssd_create': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, C.POINTER(handle)]),
     'ssd_create_dtype': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, i32, C.POINTER(handle)]),
     'ssd_get_dtype': (i32, [handle, p_i32]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     'ssd_eval_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_infer_dev': (i32, [handle, vp, i32]),
     'ssd_result_dev': (i32, [handle, C.POINTER(vp)]),
+    'ssd_get_result': (i32, [handle, i32, vp]),
     'ssd_get_losses': (i32, [handle, vp]),
     'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),

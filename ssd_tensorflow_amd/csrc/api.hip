@@ -1,6 +1,7 @@
 // extern "C" boundary of libssdvgg_hip.so (include/ssdvgg_hip.h).
 #include "../../include/ssdvgg_hip.h"
 #include "net.h"
+#include "augment.h"
 #include "metrics.h"
 #include <vector>
 
@@ -267,6 +268,16 @@ size_t ssd_arena_floats(const char* preset, int num_classes) {
     }
 }
 
+size_t ssd_augment_ws_bytes(int b, int out_w, int out_h) { return augment_ws_bytes(b, out_w, out_h); }
+
+int ssd_augment_batch_dev(const unsigned char* images_dev, const ssd_augment_params* params, int b, int out_w, int out_h,
+                          float* out_dev, void* ws_dev, void* stream) {
+    API_BEGIN
+    SSD_REQUIRE(images_dev && params && out_dev && ws_dev, "null argument");
+    augment_batch(images_dev, params, b, out_w, out_h, out_dev, ws_dev, (hipStream_t)stream);
+    API_END
+}
+
 int ssd_create(const char* preset, int num_classes, int max_batch, int device, int training, unsigned long long seed,
                float* ext_params_dev, float* ext_grads_dev, float* ext_momentum_dev, ssd_handle* out) {
     API_BEGIN
@@ -437,6 +448,14 @@ int ssd_set_result_dev(ssd_handle h, const float* pred_dev, int b) {
     N(h).set_result(pred_dev, b);
     API_END
 }
+int ssd_get_result(ssd_handle h, int b, float* result_out) {
+    API_BEGIN
+    SSD_REQUIRE(h != nullptr && result_out != nullptr, "null argument");
+    SSD_REQUIRE(b >= 1 && b <= h->net->max_batch(), "batch %d outside 1..%d", b, h->net->max_batch());
+    h->net->copy_result(result_out, b);
+    API_END
+}
+
 int ssd_get_losses(ssd_handle h, float losses_out[4]) {
     API_BEGIN
     N(h).get_losses(losses_out);

@@ -1,0 +1,288 @@
+// Training augmentation on the GPU: the PIXEL half of the reference's recipe
+// (process_dataset.py:66-140; transforms.py:117-232, 276-301, 345-359, 378-392) for a whole batch in two
+// launches.  The decisions (which transforms fire, the expand / crop windows, the surviving boxes) are
+// made on the host by the transform mirror (ssd_tensorflow_amd/transforms.py) from Python's `random`
+// exactly as the reference draws them; what arrives here is one ssd_augment_params per image.
+//
+// The reference runs brightness -> distort chain -> channel reorder on the loaded uint8 image, then
+// expand (float64 canvas of the mean value) -> crop -> flip -> cv2.resize to the preset's size, then
+// astype(float32) (training_data.py:100).  All photometric steps are pointwise, all geometric steps are
+// index maps, and every cv2.resize kernel is separable, so the whole chain collapses into a gather:
+//   kernel 1: per image and axis, the resize taps (source index + weight) of every output coordinate
+//             in the cropped / flipped / expanded frame (OpenCV's conventions, see oracle/augment.py);
+//   kernel 2: one thread per output pixel: sum over its taps of photometric(source pixel) or the mean
+//             value outside the pasted image; round-and-clamp when the image never left uint8.
+// HBM-bound: 3 x 4 bytes written per output pixel, a few source bytes read per tap through L2.
+// Compiled with -ffp-contract=off: the HSV round trip and the truncations to uint8 are not FMA-safe.
+#include "augment.h"
+
+namespace ssd {
+
+constexpr int AUG_TMAX = 16;          // taps per axis (INTER_AREA shrinking by up to 14x)
+enum { ALG_NEAREST = 0, ALG_LINEAR = 1, ALG_CUBIC = 2, ALG_AREA = 3, ALG_LANCZOS4 = 4 };
+
+struct TapTable {
+    int* idx;         // [b][2][dst][AUG_TMAX]
+    float* w;         // same
+    int* n;           // [b][2][dst]
+};
+
+__device__ static void cubic_w(float x, float* c) {
+    const float a = -0.75f;
+    // oracle/_cubic_w evaluates in double on a float32 x and rounds the weights to float32
+    const double X = x;
+    const double c0 = ((a * (X + 1) - 5 * a) * (X + 1) + 8 * a) * (X + 1) - 4 * a;
+    const double c1 = ((a + 2) * X - (a + 3)) * X * X + 1;
+    const double c2 = ((a + 2) * (1 - X) - (a + 3)) * (1 - X) * (1 - X) + 1;
+    c[0] = (float)c0; c[1] = (float)c1; c[2] = (float)c2; c[3] = (float)(1 - c0 - c1 - c2);
+}
+
+__device__ static void lanczos4_w(float x, float* c) {
+    const double s45 = 0.70710678118654752440084436210485;
+    const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-07f) {
+        for (int i = 0; i < 8; ++i) c[i] = 0.f;
+        c[3] = 1.f;
+        return;
+    }
+    const double X = x;
+    const double y0 = -(X + 3) * 3.14159265358979323846 * 0.25;
+    const double s0 = sin(y0), c0 = cos(y0);
+    double sum = 0;
+    float t[8];
+    for (int i = 0; i < 8; ++i) {
+        const double y = -(X + 3 - i) * 3.14159265358979323846 * 0.25;
+        t[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += (double)t[i];
+    }
+    for (int i = 0; i < 8; ++i) c[i] = (float)((double)t[i] / sum);
+}
+
+// taps of destination coordinate d along one axis (src -> dst samples), OpenCV conventions
+__device__ static int axis_taps(int src, int dst, int alg, int d, int* idx, float* w) {
+    const double scale = (double)src / (double)dst;
+    if (alg == ALG_NEAREST) {
+        int s = (int)floor(d * scale);
+        idx[0] = s < src - 1 ? s : src - 1;
+        w[0] = 1.f;
+        return 1;
+    }
+    if (alg == ALG_AREA && scale >= 1.0) {
+        const double f1 = d * scale, f2 = f1 + scale;
+        const double cell = fmin(scale, src - f1);
+        int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+        if (s2 > src - 1) s2 = src - 1;
+        if (s1 > s2) s1 = s2;
+        int k = 0;
+        if (s1 - f1 > 1e-3) { idx[k] = s1 - 1; w[k] = (float)((s1 - f1) / cell); ++k; }
+        for (int s = s1; s < s2 && k < AUG_TMAX; ++s) { idx[k] = s; w[k] = (float)(1.0 / cell); ++k; }
+        if (f2 - s2 > 1e-3 && k < AUG_TMAX) { idx[k] = s2; w[k] = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell); ++k; }
+        return k;
+    }
+    if (alg == ALG_LINEAR || alg == ALG_AREA) {
+        // OpenCV rounds the source coordinate to float BEFORE taking its floor (fx = (float)(...); sx = cvFloor(fx);
+        // fx -= sx): a coordinate a hair below an integer lands ON it, not at fraction 1.0 (where Lanczos divides by 0)
+        int s;
+        float f;
+        if (alg == ALG_AREA) {      // enlarging with INTER_AREA: the linear path with the area-mode coefficient
+            s = (int)floor(d * scale);
+            f = (float)((d + 1) - (s + 1) / scale);
+            f = f <= 0.f ? 0.f : f - floorf(f);
+        } else {
+            const float fx = (float)((d + 0.5) * scale - 0.5);
+            s = (int)floorf(fx);
+            f = fx - floorf(fx);
+        }
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= src - 1) { f = 0; s = src - 1; }
+        idx[0] = s; idx[1] = s + 1 < src - 1 ? s + 1 : src - 1;
+        w[0] = 1.f - f; w[1] = f;
+        return 2;
+    }
+    const float fx = (float)((d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(fx);
+    const float f = fx - floorf(fx);
+    const int T = alg == ALG_CUBIC ? 4 : 8, first = alg == ALG_CUBIC ? -1 : -3;
+    if (alg == ALG_CUBIC) cubic_w(f, w); else lanczos4_w(f, w);
+    for (int i = 0; i < T; ++i) {
+        int q = s + first + i;
+        idx[i] = q < 0 ? 0 : (q > src - 1 ? src - 1 : q);
+    }
+    return T;
+}
+
+__global__ __launch_bounds__(256) void augment_taps_kernel(const ssd_augment_params* __restrict__ prm, int b, int out_w, int out_h, TapTable t) {
+    const int per = out_w + out_h;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= b * per) return;
+    const int img = gid / per, r = gid - img * per;
+    const int axis = r >= out_w;                 // 0: x, 1: y
+    const int d = axis ? r - out_w : r;
+    const int dst = axis ? out_h : out_w;
+    const ssd_augment_params& p = prm[img];
+    const int src = axis ? p.crop_h : p.crop_w;
+    const size_t row = ((size_t)(img * 2 + axis)) * (out_w > out_h ? out_w : out_h) + d;
+    t.n[row] = axis_taps(src, dst, p.resize_alg, d, t.idx + row * AUG_TMAX, t.w + row * AUG_TMAX);
+}
+
+// ---- photometric chain on one uint8 BGR pixel (oracle/augment.py brightness / contrast / hue / saturation) ----
+__device__ __forceinline__ float u8f(float v) {       // clip to [0, 255], astype(uint8) truncates
+    v = v > 255.f ? 255.f : v;
+    v = v < 0.f ? 0.f : v;
+    return floorf(v);
+}
+__device__ static void bgr2hsv_u8(float* px) {
+    const float b = px[0], g = px[1], r = px[2];
+    const float v = fmaxf(fmaxf(b, g), r), mn = fminf(fminf(b, g), r);
+    const float diff = v - mn;
+    const float s = v > 0.f ? diff * 255.0f / v : 0.f;
+    const float safe = diff > 0.f ? diff : 1.f;
+    float h = v == r ? (g - b) / safe * 60.0f : (v == g ? 120.0f + (b - r) / safe * 60.0f : 240.0f + (r - g) / safe * 60.0f);
+    h = diff > 0.f ? h : 0.f;
+    h = h < 0.f ? h + 360.0f : h;
+    int hi = (int)floorf(h / 2.f + 0.5f) % 180;
+    float si = floorf(s + 0.5f);
+    si = si < 0.f ? 0.f : (si > 255.f ? 255.f : si);
+    px[0] = (float)hi; px[1] = si; px[2] = v;
+}
+__device__ static void hsv2bgr_u8(float* px) {
+    const float h = px[0] * 2.0f, s = px[1] / 255.0f, v = px[2];
+    const float hh = h / 60.0f;
+    const float fl = floorf(hh);
+    const int sector = ((int)fl) % 6;
+    const float f = hh - fl;
+    const float p_ = v * (1 - s), q_ = v * (1 - s * f), t_ = v * (1 - s * (1 - f));
+    float r, g, b;
+    switch (sector) {
+    case 0: r = v; g = t_; b = p_; break;
+    case 1: r = q_; g = v; b = p_; break;
+    case 2: r = p_; g = v; b = t_; break;
+    case 3: r = p_; g = q_; b = v; break;
+    case 4: r = t_; g = p_; b = v; break;
+    default: r = v; g = p_; b = q_; break;
+    }
+    const float o[3] = {b, g, r};
+    for (int c = 0; c < 3; ++c) {
+        float x = floorf(o[c] + 0.5f);
+        px[c] = x < 0.f ? 0.f : (x > 255.f ? 255.f : x);
+    }
+}
+
+__device__ static void photometric(const ssd_augment_params& p, int row, float* px) {
+    if (p.brightness_on)
+        for (int c = 0; c < 3; ++c) px[c] = u8f(px[c] + (float)p.brightness_delta);
+    for (int i = 0; i < p.n_distort; ++i) {
+        const int kind = p.distort_kind[i];
+        const float val = p.distort_val[i];
+        if (kind == 0) {                                   // contrast
+            for (int c = 0; c < 3; ++c) px[c] = u8f(px[c] * val);
+        } else if (kind == 1) {                            // saturation: HSV round trip; image ROW 1 is scaled (reference quirk)
+            bgr2hsv_u8(px);
+            if (row == 1)
+                for (int c = 0; c < 3; ++c) { float x = px[c] * val; x = x > 255.f ? 255.f : x; x = x < 0.f ? 0.f : x; px[c] = floorf(x); }
+            hsv2bgr_u8(px);
+        } else {                                           // hue: HSV round trip; image ROW 0 is shifted (reference quirk)
+            bgr2hsv_u8(px);
+            if (row == 0)
+                for (int c = 0; c < 3; ++c) {
+                    float x = px[c] + val;
+                    if (x > 180.f) x -= 180.f;
+                    if (x < 0.f) x += 180.f;
+                    px[c] = (float)(unsigned char)(int)x;   // astype(uint8) of a value in [0, 255+)
+                }
+            hsv2bgr_u8(px);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char* __restrict__ images, const ssd_augment_params* __restrict__ prm,
+                                                             int b, int out_w, int out_h, TapTable t, float* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)b * out_w * out_h;
+    if (gid >= total) return;
+    const int ox = (int)(gid % out_w);
+    const int oy = (int)((gid / out_w) % out_h);
+    const int img = (int)(gid / ((size_t)out_w * out_h));
+    const ssd_augment_params p = prm[img];
+    const int pitch = out_w > out_h ? out_w : out_h;
+    const size_t rx = ((size_t)(img * 2 + 0)) * pitch + ox, ry = ((size_t)(img * 2 + 1)) * pitch + oy;
+    const int nx = t.n[rx], ny = t.n[ry];
+    const unsigned char* src = images + p.src_off;
+    const double mean[3] = {104.0, 117.0, 123.0};
+    double acc[3] = {0, 0, 0};
+    for (int j = 0; j < ny; ++j) {
+        const int sy = t.idx[ry * AUG_TMAX + j] + p.crop_y0;               // row in the (expanded) frame
+        const double wy = t.w[ry * AUG_TMAX + j];
+        double rowacc[3] = {0, 0, 0};
+        for (int i = 0; i < nx; ++i) {
+            int sx = t.idx[rx * AUG_TMAX + i];
+            if (p.flip) sx = p.crop_w - 1 - sx;
+            sx += p.crop_x0;
+            const double wx = t.w[rx * AUG_TMAX + i];
+            const int y0 = sy - p.exp_hoff, x0 = sx - p.exp_woff;         // position in the loaded image (offsets are 0 when not expanded)
+            float px[3];
+            if ((unsigned)y0 < (unsigned)p.src_h && (unsigned)x0 < (unsigned)p.src_w) {
+                const unsigned char* q = src + ((size_t)y0 * p.src_w + x0) * 3;
+                float raw[3] = {(float)q[0], (float)q[1], (float)q[2]};
+                photometric(p, y0, raw);
+                for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
+            } else {
+                for (int c = 0; c < 3; ++c) px[c] = (float)mean[c];
+            }
+            for (int c = 0; c < 3; ++c) rowacc[c] += wx * (double)px[c];
+        }
+        for (int c = 0; c < 3; ++c) acc[c] += wy * rowacc[c];
+    }
+    float* o = out + gid * 3;
+    for (int c = 0; c < 3; ++c) {
+        double v = acc[c];
+        if (!p.expand_on) {                   // the image is still uint8 in the reference: cv2.resize saturates to uint8
+            v = floor(v + 0.5);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        o[c] = (float)v;
+    }
+}
+
+size_t augment_ws_bytes(int b, int out_w, int out_h) {
+    const size_t rows = (size_t)b * 2 * (out_w > out_h ? out_w : out_h);
+    return rows * AUG_TMAX * (sizeof(int) + sizeof(float)) + rows * sizeof(int) + (size_t)b * sizeof(ssd_augment_params) + 256;
+}
+
+void augment_batch(const unsigned char* images_dev, const ssd_augment_params* params_host, int b, int out_w, int out_h, float* out_dev,
+                   void* ws, hipStream_t s) {
+    SSD_REQUIRE(b >= 1 && out_w >= 1 && out_h >= 1, "augment: empty batch");
+    for (int i = 0; i < b; ++i) {
+        const ssd_augment_params& p = params_host[i];
+        SSD_REQUIRE(p.src_w >= 1 && p.src_h >= 1 && p.crop_w >= 1 && p.crop_h >= 1, "augment: image %d has an empty source or crop window", i);
+        SSD_REQUIRE(p.resize_alg >= 0 && p.resize_alg <= 4, "augment: image %d: unknown resize algorithm %d", i, p.resize_alg);
+        SSD_REQUIRE(p.n_distort >= 0 && p.n_distort <= 3, "augment: image %d: distort chain length %d", i, p.n_distort);
+        for (int c = 0; c < 3; ++c) SSD_REQUIRE(p.reorder[c] >= 0 && p.reorder[c] <= 2, "augment: image %d: channel permutation", i);
+        const double sx = (double)p.crop_w / out_w, sy = (double)p.crop_h / out_h;
+        SSD_REQUIRE(p.resize_alg != ALG_AREA || (sx <= AUG_TMAX - 2 && sy <= AUG_TMAX - 2), "augment: image %d shrinks by more than %dx (INTER_AREA tap table)",
+                    i, AUG_TMAX - 2);
+        const int fw = p.expand_on ? p.exp_w : p.src_w, fh = p.expand_on ? p.exp_h : p.src_h;
+        SSD_REQUIRE(p.crop_x0 >= 0 && p.crop_y0 >= 0 && p.crop_x0 + p.crop_w <= fw && p.crop_y0 + p.crop_h <= fh, "augment: image %d: crop window outside the frame", i);
+    }
+    const size_t rows = (size_t)b * 2 * (out_w > out_h ? out_w : out_h);
+    char* base = static_cast<char*>(ws);
+    TapTable t;
+    t.idx = reinterpret_cast<int*>(base);
+    t.w = reinterpret_cast<float*>(base + rows * AUG_TMAX * sizeof(int));
+    t.n = reinterpret_cast<int*>(base + rows * AUG_TMAX * (sizeof(int) + sizeof(float)));
+    ssd_augment_params* prm = reinterpret_cast<ssd_augment_params*>(base + ((rows * AUG_TMAX * 8 + rows * 4 + 255) / 256) * 256);
+    HIP_OK(hipMemcpyAsync(prm, params_host, (size_t)b * sizeof(ssd_augment_params), hipMemcpyHostToDevice, s));
+    {
+        const int n = b * (out_w + out_h);
+        ProfScope prof("augment_taps", 0.0, (double)n * AUG_TMAX * 8, s);
+        hipLaunchKernelGGL(augment_taps_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, prm, b, out_w, out_h, t);
+    }
+    {
+        const size_t total = (size_t)b * out_w * out_h;
+        ProfScope prof("augment_gather", 0.0, (double)total * 12, s);
+        hipLaunchKernelGGL(augment_gather_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, s, images_dev, prm, b, out_w, out_h, t, out_dev);
+    }
+    HIP_OK(hipGetLastError());
+}
+
+}  // namespace ssd

@@ -223,6 +223,34 @@ def non_maximum_suppression(boxes, overlap_threshold):
     return suppress_overlaps(boxes)
 
 
+_ANCHORS_ABS = {}
+
+
+def has_positive_anchor(preset, boxes):
+    """Would LabelCreatorTransform mark at least one anchor positive for these Box records?  That is the only
+    thing the reference's redraw loop looks at (training_data.py:92-95: num_bg < rows), and an anchor turns
+    positive iff its IoU (+1 pixel, 1000-pixel grid) with some box exceeds 0.5 (transforms.py:76-107,
+    ssdutils.py:152-169).  A handful of boxes against the cached integer anchor table, on the host."""
+    from .utils import prop2abs, Size
+    key = preset.name
+    if key not in _ANCHORS_ABS:
+        out = np.empty((preset.num_anchors, 4), np.int32)
+        check(lib.ssd_anchors_abs(_pname(preset), _DEVICE, np_ptr(out)))
+        _ANCHORS_ABS[key] = out.astype(np.float64)
+    an = _ANCHORS_ABS[key]
+    area_a = (an[:, 1] - an[:, 0] + 1) * (an[:, 3] - an[:, 2] + 1)
+    grid = Size(1000, 1000)
+    for b in boxes:
+        xmin, xmax, ymin, ymax = prop2abs(b.center, b.size, grid)
+        w = np.maximum(0, np.minimum(xmax, an[:, 1]) - np.maximum(xmin, an[:, 0]) + 1)
+        h = np.maximum(0, np.minimum(ymax, an[:, 3]) - np.maximum(ymin, an[:, 2]) + 1)
+        inter = w * h
+        iou = inter / ((xmax - xmin + 1) * (ymax - ymin + 1) + area_a - inter)
+        if (iou > 0.5).any():
+            return True
+    return False
+
+
 def encode_labels_batch(preset, num_classes, gt_boxes_list, gt_cls_list):
     """LabelCreatorTransform for a batch on the GPU: lists (one per image) of [n,4] float64
     proportional (cx, cy, w, h) and [n] class ids -> [b, A, num_classes+5] float32."""

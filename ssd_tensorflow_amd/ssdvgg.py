@@ -272,7 +272,39 @@ class SSDVGG:
             raise ValueError(f'labels must be [{b}, {self.preset.num_anchors}, {self.num_vars}] float32, got {y.shape}')
         return y
 
+    # ---- device-resident feeds: a torch CUDA tensor in the feed goes through the *_dev entry points --------------
+    @staticmethod
+    def _is_cuda(t):
+        return hasattr(t, 'is_cuda') and t.is_cuda
+
+    def _dev_xy(self, x, y):
+        import torch
+        H, W = self.preset.image_size.h, self.preset.image_size.w
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (H, W, 3):
+            raise ValueError(f'image_input must be [b, {H}, {W}, 3] float32, got {tuple(x.shape)} {x.dtype}')
+        if x.shape[0] < 1 or x.shape[0] > self.max_batch:
+            raise ValueError(f'batch {x.shape[0]} outside 1..{self.max_batch} (max_batch)')
+        x = x.contiguous()
+        if y is not None:
+            if not self._is_cuda(y):
+                y = torch.from_numpy(self._check_y(y, x.shape[0])).to(x.device)
+            if y.dtype != torch.float32 or tuple(y.shape) != (x.shape[0], self.preset.num_anchors, self.num_vars):
+                raise ValueError(f'labels must be [{x.shape[0]}, {self.preset.num_anchors}, {self.num_vars}] float32, got {tuple(y.shape)}')
+            y = y.contiguous()
+        return x, y
+
+    def _dev_result(self, b, want_result):
+        if not want_result:
+            return None
+        res = np.empty((b, self.preset.num_anchors, self.num_vars), np.float32)
+        check(lib.ssd_get_result(self._h, b, np_ptr(res)))
+        return res
+
     def train_step(self, x, y, want_result=True):
+        if self._is_cuda(x):
+            x, y = self._dev_xy(x, y)
+            self.train_step_dev(x, y)
+            return self._dev_result(x.shape[0], want_result), self.get_losses()
         x = self._check_x(x); y = self._check_y(y, x.shape[0])
         res = np.empty(y.shape, np.float32) if want_result else None
         L = np.zeros(4, np.float32)
@@ -280,6 +312,10 @@ class SSDVGG:
         return res, dict(zip(LOSS_NAMES, (float(v) for v in L)))
 
     def eval_step(self, x, y, want_result=True):
+        if self._is_cuda(x):
+            x, y = self._dev_xy(x, y)
+            self.eval_step_dev(x, y)
+            return self._dev_result(x.shape[0], want_result), self.get_losses()
         x = self._check_x(x); y = self._check_y(y, x.shape[0])
         res = np.empty(y.shape, np.float32) if want_result else None
         L = np.zeros(4, np.float32)
@@ -287,6 +323,10 @@ class SSDVGG:
         return res, dict(zip(LOSS_NAMES, (float(v) for v in L)))
 
     def infer(self, x):
+        if self._is_cuda(x):
+            x, _ = self._dev_xy(x, None)
+            self.infer_dev(x)
+            return self._dev_result(x.shape[0], True)
         x = self._check_x(x)
         res = np.empty((x.shape[0], self.preset.num_anchors, self.num_vars), np.float32)
         check(lib.ssd_infer(self._h, np_ptr(x), x.shape[0], np_ptr(res)))

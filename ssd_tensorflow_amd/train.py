@@ -40,6 +40,7 @@ def main(argv=None):
     parser.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='f32, or bf16 activations on the bf16 matrix cores (fp32 master weights, loss and optimizer)')
     parser.add_argument('--synthetic-train', type=int, default=64, help='synthetic training samples per epoch')
     parser.add_argument('--synthetic-valid', type=int, default=16)
+    parser.add_argument('--augment', type=str2bool, default='False', help="run the reference's train augmentation recipe (process_dataset.py) on the GPU over a uint8 synthetic dataset")
     args = parser.parse_args(argv)
 
     rank, local, world = parallel.init()
@@ -76,7 +77,8 @@ def main(argv=None):
         os.makedirs(args.name, exist_ok=True)
 
     try:
-        td = TrainingData(args.data_dir, args.preset, args.synthetic_train, args.synthetic_valid, rank=rank, world=world)
+        td = TrainingData(args.data_dir, args.preset, args.synthetic_train, args.synthetic_valid, rank=rank, world=world,
+                          augment=args.augment, device=local)
     except RuntimeError as e:
         print('[!] Unable to load training data:', str(e)); return 1                       # train.py:155-161
     say('[i] # training samples:   ', td.num_train)
@@ -108,7 +110,8 @@ def main(argv=None):
             tot = np.zeros(4); seen = 0
             for x, y, gt_boxes in td.train_generator(args.batch_size, args.num_workers):
                 if world > 1:
-                    xt = torch.from_numpy(x).cuda(non_blocking=True); yt = torch.from_numpy(y).cuda(non_blocking=True)
+                    xt = x if torch.is_tensor(x) else torch.from_numpy(x).cuda(non_blocking=True)
+                    yt = torch.from_numpy(y).cuda(non_blocking=True)
                     parallel.train_step_dp(net, xt, yt, world)
                     loss_batch = net.get_losses()
                 else:

@@ -1,9 +1,70 @@
-"""LabelCreatorTransform of the reference's transforms.py:57-114, backed by the HIP label
-encoder (ssd_encode_labels).  Same constructor keywords (preset, num_classes) and the same
-(data, label, gt) -> (data, label, gt) call convention."""
+"""The reference's transforms.py (:31-392) for the GPU feed path, same class names, same keyword
+parameters, same `(data, label, gt) -> (data, label, gt)` call convention, same draws from Python's
+`random` in the same order -- but no transform touches a pixel.  Between ImageLoaderTransform and the
+batch kernel `data` is an ImagePlan: the loaded uint8 image plus the list of decisions taken so far
+(brightness delta, distort chain, channel order, expand offsets, crop window, flip, resize algorithm).
+`augment_batch()` then executes a whole batch of plans in two HIP launches (csrc/augment.hip,
+ssd_augment_batch_dev): every photometric step is pointwise and every geometric step an index map, so
+the chain collapses into one gather per output pixel.  The ground-truth boxes are transformed here, on
+the host, exactly as the reference does (transform_box / transform_gt, transforms.py:236-270).
+
+LabelCreatorTransform (transforms.py:57-114) is backed by the HIP label encoder.
+
+Order the kernel supports (what process_dataset.py:126-136 builds): photometric* -> expand? -> crop* ->
+flip? -> resize.  A transform applied outside that order raises NotImplementedError rather than
+silently producing something else.
+"""
+import ctypes as C
+import random
+from math import sqrt
+
 import numpy as np
 
+from . import _lib
+from ._lib import lib, check
 from .ssdutils import encode_labels_batch
+from .utils import Size, Sample, Point, Box, abs2prop, prop2abs
+
+# cv2's interpolation enum values (the mirror does not import cv2)
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
+
+
+class ImagePlan:
+    """Stands in for the ndarray `data` of the reference between loading and the batch kernel."""
+
+    def __init__(self, image):
+        image = np.ascontiguousarray(image)
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError('ImagePlan needs a uint8 [H, W, 3] BGR image, got %s %s' % (image.dtype, image.shape))
+        self.image = image
+        self.src = Size(image.shape[1], image.shape[0])
+        self.brightness = None
+        self.distort = []              # [(kind, value)] kind: 0 contrast, 1 saturation, 2 hue
+        self.reorder = [0, 1, 2]
+        self.expand = None             # (Size new, h_off, w_off)
+        self.crop = None               # (x0, y0, w, h) in the (expanded) frame, before the flip
+        self.flip = False
+        self.resize = None             # (width, height, algorithm)
+
+    # the frame the next geometric transform sees
+    @property
+    def size(self):
+        if self.crop is not None:
+            return Size(self.crop[2], self.crop[3])
+        return self.expand[0] if self.expand is not None else self.src
+
+    @property
+    def shape(self):
+        s = Size(self.resize[0], self.resize[1]) if self.resize is not None else self.size
+        return (s.h, s.w, 3)
+
+    def _photometric_ok(self, what):
+        if self.expand is not None or self.crop is not None or self.flip or self.resize is not None:
+            raise NotImplementedError(what + ' after a geometric transform is outside the order the batch kernel runs')
+
+    def _geometric_ok(self, what):
+        if self.resize is not None:
+            raise NotImplementedError(what + ' after ResizeTransform is outside the order the batch kernel runs')
 
 
 class Transform:
@@ -14,6 +75,18 @@ class Transform:
         self.initialized = False
 
 
+class ImageLoaderTransform(Transform):
+    """transforms.py:38-43 reads gt.filename with cv2.imread.  Without OpenCV the pixels come from `images`
+    (a mapping filename -> uint8 BGR array) or from a .npy file of that name."""
+    def __call__(self, data, label, gt):
+        images = getattr(self, 'images', None)
+        if images is not None and gt.filename in images:
+            return ImagePlan(images[gt.filename]), label, gt
+        if isinstance(gt.filename, str) and gt.filename.endswith('.npy'):
+            return ImagePlan(np.load(gt.filename)), label, gt
+        raise RuntimeError('cannot load %r: no OpenCV in this build (pass images={filename: uint8 BGR array} or a .npy file)' % (gt.filename,))
+
+
 class LabelCreatorTransform(Transform):
     """Parameters: preset, num_classes"""
     def __call__(self, data, label, gt):
@@ -21,3 +94,320 @@ class LabelCreatorTransform(Transform):
         cls = np.array([b.labelid for b in gt.boxes], np.int32)
         vec = encode_labels_batch(self.preset, self.num_classes, [boxes], [cls])[0]
         return data, vec, gt
+
+
+class ResizeTransform(Transform):
+    """Parameters: width, height, algorithms (transforms.py:117-126)"""
+    def __call__(self, data, label, gt):
+        alg = random.choice(self.algorithms)
+        data._geometric_ok('ResizeTransform')
+        data.resize = (int(self.width), int(self.height), int(alg))
+        return data, label, gt
+
+
+class RandomTransform(Transform):
+    """Parameters: prob, transform (transforms.py:129-139)"""
+    def __call__(self, data, label, gt):
+        p = random.uniform(0, 1)
+        if p < self.prob:
+            return self.transform(data, label, gt)
+        return data, label, gt
+
+
+class ComposeTransform(Transform):
+    """Parameters: transforms (transforms.py:142-151)"""
+    def __call__(self, data, label, gt):
+        args = (data, label, gt)
+        for t in self.transforms:
+            args = t(*args)
+        return args
+
+
+class TransformPickerTransform(Transform):
+    """Parameters: transforms (transforms.py:154-161)"""
+    def __call__(self, data, label, gt):
+        pick = random.randint(0, len(self.transforms) - 1)
+        return self.transforms[pick](data, label, gt)
+
+
+class BrightnessTransform(Transform):
+    """Parameters: delta (transforms.py:164-176)"""
+    def __call__(self, data, label, gt):
+        delta = random.randint(-self.delta, self.delta)
+        data._photometric_ok('BrightnessTransform')
+        if data.brightness is not None or data.distort or data.reorder != [0, 1, 2]:
+            raise NotImplementedError('the batch kernel runs brightness once, before the distort chain')
+        data.brightness = int(delta)
+        return data, label, gt
+
+
+def _distort(data, kind, value, what):
+    data._photometric_ok(what)
+    if data.reorder != [0, 1, 2]:
+        raise NotImplementedError(what + ' after ReorderChannelsTransform is outside the order the batch kernel runs')
+    if len(data.distort) >= 3:
+        raise NotImplementedError('the batch kernel runs at most 3 distort steps')
+    data.distort.append((kind, float(value)))
+
+
+class ContrastTransform(Transform):
+    """Parameters: lower, upper (transforms.py:179-191)"""
+    def __call__(self, data, label, gt):
+        _distort(data, 0, random.uniform(self.lower, self.upper), 'ContrastTransform')
+        return data, label, gt
+
+
+class HueTransform(Transform):
+    """Parameters: delta (transforms.py:194-208; shifts image ROW 0 of the HSV image, as the reference does)"""
+    def __call__(self, data, label, gt):
+        _distort(data, 2, random.randint(-self.delta, self.delta), 'HueTransform')
+        return data, label, gt
+
+
+class SaturationTransform(Transform):
+    """Parameters: lower, upper (transforms.py:211-225; scales image ROW 1 of the HSV image, as the reference does)"""
+    def __call__(self, data, label, gt):
+        _distort(data, 1, random.uniform(self.lower, self.upper), 'SaturationTransform')
+        return data, label, gt
+
+
+class ReorderChannelsTransform(Transform):
+    """transforms.py:228-234"""
+    def __call__(self, data, label, gt):
+        channels = [0, 1, 2]
+        random.shuffle(channels)
+        data._photometric_ok('ReorderChannelsTransform')
+        data.reorder = [data.reorder[c] for c in channels]
+        return data, label, gt
+
+
+def transform_box(box, orig_size, new_size, h_off, w_off):
+    """transforms.py:236-259"""
+    xmin, xmax, ymin, ymax = prop2abs(box.center, box.size, orig_size)
+    xmin += w_off
+    xmax += w_off
+    ymin += h_off
+    ymax += h_off
+    width = xmax - xmin
+    height = ymax - ymin
+    new_cx = xmin + int(width / 2)
+    new_cy = ymin + int(height / 2)
+    if new_cx < 0 or new_cx >= new_size.w:
+        return None
+    if new_cy < 0 or new_cy >= new_size.h:
+        return None
+    center, size = abs2prop(xmin, xmax, ymin, ymax, new_size)
+    return Box(box.label, box.labelid, center, size)
+
+
+def transform_gt(gt, new_size, h_off, w_off):
+    """transforms.py:262-270"""
+    boxes = []
+    for box in gt.boxes:
+        box = transform_box(box, gt.imgsize, new_size, h_off, w_off)
+        if box is None:
+            continue
+        boxes.append(box)
+    return Sample(gt.filename, boxes, new_size)
+
+
+class ExpandTransform(Transform):
+    """Parameters: max_ratio, mean_value (transforms.py:273-301).  The kernel fills with 104, 117, 123."""
+    def __call__(self, data, label, gt):
+        ratio = random.uniform(1, self.max_ratio)
+        orig_size = gt.imgsize
+        new_size = Size(int(orig_size.w * ratio), int(orig_size.h * ratio))
+        h_off = random.randint(0, new_size.h - orig_size.h)
+        w_off = random.randint(0, new_size.w - orig_size.w)
+        data._geometric_ok('ExpandTransform')
+        if data.expand is not None or data.crop is not None or data.flip:
+            raise NotImplementedError('the batch kernel expands once, before any crop or flip')
+        if list(getattr(self, 'mean_value', [104, 117, 123])) != [104, 117, 123]:
+            raise NotImplementedError('the batch kernel fills with the mean value 104, 117, 123')
+        if (orig_size.w, orig_size.h) != tuple(data.src):
+            raise ValueError('gt.imgsize %s does not match the loaded image %s' % (orig_size, data.src))
+        data.expand = (new_size, int(h_off), int(w_off))
+        gt = transform_gt(gt, new_size, h_off, w_off)
+        return data, label, gt
+
+
+def _jaccard_plus1(box_arr, others):
+    """ssdutils.py:139-149 on the host: a handful of boxes per image"""
+    areaa = (others[:, 1] - others[:, 0] + 1) * (others[:, 3] - others[:, 2] + 1)
+    areab = (box_arr[1] - box_arr[0] + 1) * (box_arr[3] - box_arr[2] + 1)
+    xxmin = np.maximum(box_arr[0], others[:, 0]); xxmax = np.minimum(box_arr[1], others[:, 1])
+    yymin = np.maximum(box_arr[2], others[:, 2]); yymax = np.minimum(box_arr[3], others[:, 3])
+    w = np.maximum(0, xxmax - xxmin + 1); h = np.maximum(0, yymax - yymin + 1)
+    inter = w * h
+    return inter / (areab + areaa - inter)
+
+
+class SamplerTransform(Transform):
+    """Params: sample, min_scale, max_scale, min_aspect_ratio, max_aspect_ratio, min_jaccard_overlap, max_trials
+    (transforms.py:304-359).  Returns None when no window satisfies the overlap constraint."""
+    def __call__(self, data, label, gt):
+        if not self.sample:
+            return data, label, gt
+        source_boxes = np.zeros((len(gt.boxes), 4))
+        for i, b in enumerate(gt.boxes):
+            source_boxes[i] = prop2abs(b.center, b.size, gt.imgsize)
+        box_arr = None
+        found = False
+        for _ in range(self.max_trials):
+            scale = random.uniform(self.min_scale, self.max_scale)
+            aspect_ratio = random.uniform(self.min_aspect_ratio, self.max_aspect_ratio)
+            aspect_ratio = max(aspect_ratio, scale ** 2)
+            aspect_ratio = min(aspect_ratio, 1 / (scale ** 2))
+            width = scale * sqrt(aspect_ratio)
+            height = scale / sqrt(aspect_ratio)
+            cx = 0.5 * width + random.uniform(0, 1 - width)
+            cy = 0.5 * height + random.uniform(0, 1 - height)
+            box_arr = np.array(prop2abs(Point(cx, cy), Size(width, height), gt.imgsize))
+            iou = _jaccard_plus1(box_arr, source_boxes)
+            best = int(np.argmax(iou))
+            if iou[best] > 0 and iou[best] >= self.min_jaccard_overlap:      # compute_overlap(.., 0).best and its score
+                found = True
+                break
+        if not found:
+            return None
+        new_size = Size(int(box_arr[1] - box_arr[0]), int(box_arr[3] - box_arr[2]))
+        w_off = -int(box_arr[0])
+        h_off = -int(box_arr[2])
+        out = _copy_plan(data)
+        out._geometric_ok('SamplerTransform')
+        if out.flip:
+            raise NotImplementedError('the batch kernel crops before it flips')
+        x0, y0 = (out.crop[0], out.crop[1]) if out.crop is not None else (0, 0)
+        out.crop = (x0 + int(box_arr[0]), y0 + int(box_arr[2]), new_size.w, new_size.h)
+        gt = transform_gt(gt, new_size, h_off, w_off)
+        return out, label, gt
+
+
+def _copy_plan(p):
+    q = ImagePlan.__new__(ImagePlan)
+    q.__dict__.update(p.__dict__)
+    q.distort = list(p.distort)
+    q.reorder = list(p.reorder)
+    return q
+
+
+class SamplePickerTransform(Transform):
+    """Parameters: samplers (transforms.py:362-376)"""
+    def __call__(self, data, label, gt):
+        samples = []
+        for sampler in self.samplers:
+            sample = sampler(data, label, gt)
+            if sample is not None:
+                samples.append(sample)
+        return random.choice(samples)
+
+
+class HorizontalFlipTransform(Transform):
+    """transforms.py:379-392"""
+    def __call__(self, data, label, gt):
+        data = _copy_plan(data)
+        data._geometric_ok('HorizontalFlipTransform')
+        data.flip = not data.flip
+        boxes = []
+        for box in gt.boxes:
+            center = Point(1 - box.center.x, box.center.y)
+            boxes.append(Box(box.label, box.labelid, center, box.size))
+        return data, label, Sample(gt.filename, boxes, gt.imgsize)
+
+
+# ------------------------------------------------------------------------------------------------
+# the batch kernel
+# ------------------------------------------------------------------------------------------------
+class _Params(C.Structure):
+    """ssd_augment_params (include/ssdvgg_hip.h)"""
+    _fields_ = [('src_off', C.c_ulonglong), ('src_w', C.c_int), ('src_h', C.c_int),
+                ('brightness_on', C.c_int), ('brightness_delta', C.c_int),
+                ('n_distort', C.c_int), ('distort_kind', C.c_int * 3), ('distort_val', C.c_float * 3),
+                ('reorder', C.c_int * 3),
+                ('expand_on', C.c_int), ('exp_w', C.c_int), ('exp_h', C.c_int), ('exp_hoff', C.c_int), ('exp_woff', C.c_int),
+                ('crop_x0', C.c_int), ('crop_y0', C.c_int), ('crop_w', C.c_int), ('crop_h', C.c_int),
+                ('flip', C.c_int), ('resize_alg', C.c_int)]
+
+
+def plan_params(plans, width, height):
+    """(ctypes array of ssd_augment_params, packed uint8 image bytes) for a list of ImagePlans"""
+    arr = (_Params * len(plans))()
+    chunks, off = [], 0
+    for i, p in enumerate(plans):
+        if p.resize is None:
+            raise ValueError('plan %d was not resized: the batch needs one output size (ResizeTransform last)' % i)
+        if (p.resize[0], p.resize[1]) != (width, height):
+            raise ValueError('plan %d resizes to %s, the batch is %s' % (i, p.resize[:2], (width, height)))
+        q = arr[i]
+        q.src_off = off; q.src_w = p.src.w; q.src_h = p.src.h
+        q.brightness_on = int(p.brightness is not None); q.brightness_delta = p.brightness or 0
+        q.n_distort = len(p.distort)
+        for k, (kind, val) in enumerate(p.distort):
+            q.distort_kind[k] = kind; q.distort_val[k] = val
+        for c in range(3):
+            q.reorder[c] = p.reorder[c]
+        if p.expand is not None:
+            q.expand_on = 1; q.exp_w = p.expand[0].w; q.exp_h = p.expand[0].h; q.exp_hoff = p.expand[1]; q.exp_woff = p.expand[2]
+        frame = p.expand[0] if p.expand is not None else p.src
+        x0, y0, cw, ch = p.crop if p.crop is not None else (0, 0, frame.w, frame.h)
+        q.crop_x0 = x0; q.crop_y0 = y0; q.crop_w = cw; q.crop_h = ch
+        q.flip = int(p.flip); q.resize_alg = p.resize[2]
+        n = p.image.size
+        padded = (n + 15) // 16 * 16
+        chunk = np.zeros(padded, np.uint8)
+        chunk[:n] = p.image.reshape(-1)
+        chunks.append(chunk)
+        off += padded
+    return arr, np.concatenate(chunks)
+
+
+def augment_batch(plans, width, height, device=0, out=None):
+    """Run a batch of ImagePlans on the GPU, on torch's current stream.  Returns a torch float32 tensor
+    [b, height, width, 3] on `device` (what training_data.py:100-104 stacks on the host)."""
+    import torch
+    arr, packed = plan_params(plans, width, height)
+    dev = torch.device('cuda', device)
+    images = torch.from_numpy(packed).to(dev)
+    b = len(plans)
+    if out is None:
+        out = torch.empty((b, height, width, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.ssd_augment_ws_bytes(b, width, height),), dtype=torch.uint8, device=dev)
+    check(lib.ssd_augment_batch_dev(images.data_ptr(), C.cast(arr, C.c_void_p), b, width, height, out.data_ptr(), ws.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream))
+    # the scratch tensors are released in stream order by torch's allocator; the parameter structs were copied by the call
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the recipes of process_dataset.py:60-147
+# ------------------------------------------------------------------------------------------------
+def build_sampler(overlap, trials):
+    """process_dataset.py:60-63"""
+    return SamplerTransform(sample=True, min_scale=0.3, max_scale=1.0, min_aspect_ratio=0.5, max_aspect_ratio=2.0,
+                            min_jaccard_overlap=overlap, max_trials=trials)
+
+
+def build_train_transforms(preset, num_classes, sampler_trials, expand_prob, images=None):
+    """process_dataset.py:66-140"""
+    tf_resize = ResizeTransform(width=preset.image_size.w, height=preset.image_size.h,
+                                algorithms=[INTER_LINEAR, INTER_AREA, INTER_NEAREST, INTER_CUBIC, INTER_LANCZOS4])
+    tf_rnd_brightness = RandomTransform(prob=0.5, transform=BrightnessTransform(delta=32))
+    tf_rnd_contrast = RandomTransform(prob=0.5, transform=ContrastTransform(lower=0.5, upper=1.5))
+    tf_rnd_hue = RandomTransform(prob=0.5, transform=HueTransform(delta=18))
+    tf_rnd_saturation = RandomTransform(prob=0.5, transform=SaturationTransform(lower=0.5, upper=1.5))
+    tf_rnd_reorder_channels = RandomTransform(prob=0.5, transform=ReorderChannelsTransform())
+    tf_distort_lst = [tf_rnd_contrast, tf_rnd_saturation, tf_rnd_hue, tf_rnd_contrast]
+    tf_distort = TransformPickerTransform(transforms=[ComposeTransform(transforms=tf_distort_lst[:-1]),
+                                                      ComposeTransform(transforms=tf_distort_lst[1:])])
+    tf_rnd_expand = RandomTransform(prob=expand_prob, transform=ExpandTransform(max_ratio=4.0, mean_value=[104, 117, 123]))
+    samplers = [SamplerTransform(sample=False)] + [build_sampler(o, sampler_trials) for o in (0.1, 0.3, 0.5, 0.7, 0.9, 1.0)]
+    tf_sample_picker = SamplePickerTransform(samplers=samplers)
+    tf_rnd_flip = RandomTransform(prob=0.5, transform=HorizontalFlipTransform())
+    return [ImageLoaderTransform(images=images), tf_rnd_brightness, tf_distort, tf_rnd_reorder_channels, tf_rnd_expand,
+            tf_sample_picker, tf_rnd_flip, LabelCreatorTransform(preset=preset, num_classes=num_classes), tf_resize]
+
+
+def build_valid_transforms(preset, num_classes, images=None):
+    """process_dataset.py:143-153"""
+    return [ImageLoaderTransform(images=images), LabelCreatorTransform(preset=preset, num_classes=num_classes),
+            ResizeTransform(width=preset.image_size.w, height=preset.image_size.h, algorithms=[INTER_LINEAR])]

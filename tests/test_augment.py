@@ -1,0 +1,122 @@
+"""SURVEY.md 8f N1, CPU half: the augmentation DECISIONS and GEOMETRY.
+  * oracle/augment.py against the golden vectors captured from the imported reference
+    (tests/golden/g9_augment.npz: RandomTransform(Expand) -> SamplePicker, and Brightness -> Contrast -> Reorder pixels);
+  * the product's transform mirror (ssd_tensorflow_amd/transforms.py, plan mode: no pixel is touched on the
+    host) against the same vectors and, for the whole train recipe, against the oracle's plan() under the same
+    `random` stream."""
+import random
+
+import numpy as np
+
+from golden_util import load
+from oracle import augment as oa
+
+
+def g9():
+    return load('g9_augment.npz')
+
+
+def test_oracle_geometry_matches_reference_goldens():
+    g = g9()
+    for case in range(int(g['ncases'][0])):
+        size = tuple(int(v) for v in g[f'size_{case}']); boxes = [tuple(b) for b in g[f'boxes_{case}']]; cls = list(g[f'cls_{case}'])
+        rng = oa.new_rng(int(g[f'seed_{case}'][0]))
+        ex = oa.plan_expand(rng, size, boxes, cls, 0.5)
+        sz, b, c = (size, boxes, cls) if ex is None else (ex[0], ex[3], ex[4])
+        win, sz2, b2, c2 = oa.plan_sample_picker(rng, sz, b, c, 50)
+        assert tuple(sz2) == tuple(g[f'out_size_{case}'])
+        assert np.array_equal(np.array(b2, np.float64).reshape(-1, 4), g[f'out_boxes_{case}'])          # bit-exact
+        assert list(c2) == list(g[f'out_cls_{case}'])
+        # the window: the coordinate image's corner pixels say where the result came from
+        yy, xx = np.mgrid[0:size[1], 0:size[0]]
+        img = np.stack([yy, xx, np.full_like(yy, 7)], -1).astype(np.int32)
+        frame = oa.expand(img, *ex[:3]) if ex is not None else img
+        x0, y0 = (0, 0) if win is None else (win[0], win[2])
+        out = frame[y0:y0 + sz2[1], x0:x0 + sz2[0]]
+        assert np.array_equal(np.asarray(out[0, 0], np.float64), g[f'corner00_{case}'])
+        assert np.array_equal(np.asarray(out[-1, -1], np.float64), g[f'corner11_{case}'])
+
+
+def test_oracle_pixels_match_reference_goldens():
+    g = g9()
+    for case in range(int(g['npix'][0])):
+        rng = oa.new_rng(int(g[f'pix_seed_{case}'][0]))
+        o = g[f'pix_in_{case}']
+        b = oa.plan_brightness(rng)
+        o = oa.brightness(o, b) if b is not None else o
+        c = oa.plan_contrast(rng)
+        o = oa.contrast(o, c) if c is not None else o
+        r = oa.plan_reorder(rng)
+        o = o[:, :, r] if r is not None else o
+        assert o.dtype == np.uint8 and np.array_equal(o, g[f'pix_out_{case}'])
+
+
+def _sample(size, boxes, cls):
+    from ssd_tensorflow_amd.utils import Sample, Box, Point, Size
+    return Sample('img', [Box('c%d' % c, int(c), Point(b[0], b[1]), Size(b[2], b[3])) for b, c in zip(boxes, cls)], Size(*size))
+
+
+def test_product_transforms_match_reference_goldens():
+    from ssd_tensorflow_amd import transforms as T
+    g = g9()
+    rnd_expand = T.RandomTransform(prob=0.5, transform=T.ExpandTransform(max_ratio=4.0, mean_value=[104, 117, 123]))
+    picker = T.SamplePickerTransform(samplers=[T.SamplerTransform(sample=False)] + [T.build_sampler(o, 50) for o in (0.1, 0.3, 0.5, 0.7, 0.9, 1.0)])
+    for case in range(int(g['ncases'][0])):
+        size = tuple(int(v) for v in g[f'size_{case}'])
+        gt = _sample(size, g[f'boxes_{case}'], g[f'cls_{case}'])
+        plan = T.ImagePlan(np.zeros((size[1], size[0], 3), np.uint8))
+        random.seed(int(g[f'seed_{case}'][0]))
+        d, _, gt2 = rnd_expand(plan, None, gt)
+        d, _, gt2 = picker(d, None, gt2)
+        assert (gt2.imgsize.w, gt2.imgsize.h) == tuple(g[f'out_size_{case}']) == tuple(d.size)
+        got = np.array([[b.center.x, b.center.y, b.size.w, b.size.h] for b in gt2.boxes], np.float64).reshape(-1, 4)
+        assert np.array_equal(got, g[f'out_boxes_{case}']) and [b.labelid for b in gt2.boxes] == list(g[f'out_cls_{case}'])
+        # window origin in the loaded image's coordinates: corner pixel (row, col) of the coordinate image, or the mean value
+        x0, y0 = (d.crop[0], d.crop[1]) if d.crop is not None else (0, 0)
+        if d.expand is not None:
+            x0 -= d.expand[2]; y0 -= d.expand[1]
+        inside = 0 <= x0 < size[0] and 0 <= y0 < size[1]
+        want = g[f'corner00_{case}']
+        assert (list(want) == [y0, x0, 7]) if inside else (list(want) == [104, 117, 123])
+
+
+def test_product_recipe_draws_like_the_oracle_plan():
+    """the whole train recipe (process_dataset.py:126-136) minus the GPU label encoder: same stream, same decisions"""
+    from ssd_tensorflow_amd import transforms as T
+    from ssd_tensorflow_amd.ssdutils import get_preset_by_name
+    preset = get_preset_by_name('vgg300')
+    nrng = np.random.default_rng(5)
+    n_exp = n_crop = n_flip = 0
+    for case in range(60):
+        size, boxes, cls = oa.synth_sample(nrng)
+        img = nrng.integers(0, 256, (size[1], size[0], 3)).astype(np.uint8)
+        tfs = [t for t in T.build_train_transforms(preset, 20, 50, 0.5, images={'img': img}) if not isinstance(t, T.LabelCreatorTransform)]
+        random.seed(300 + case)
+        args = (None, None, _sample(size, boxes, cls))
+        for t in tfs:
+            args = t(*args)
+        d, _, gt = args
+        p = oa.plan(oa.new_rng(300 + case), size, boxes, cls, 50, 0.5)
+        assert d.brightness == p['brightness']
+        kinds = {'contrast': 0, 'saturation': 1, 'hue': 2}
+        assert d.distort == [(kinds[n], float(v)) for n, v in p['distort'] if v is not None]
+        assert d.reorder == (p['reorder'] if p['reorder'] is not None else [0, 1, 2])
+        assert (None if d.expand is None else (tuple(d.expand[0]), d.expand[1], d.expand[2])) == p['expand']
+        assert (None if d.crop is None else (d.crop[0], d.crop[0] + d.crop[2], d.crop[1], d.crop[1] + d.crop[3])) == (None if p['crop'] is None else tuple(p['crop']))
+        assert d.flip == p['flip'] and d.resize == (300, 300, p['resize_alg'])
+        got = np.array([[b.center.x, b.center.y, b.size.w, b.size.h] for b in gt.boxes], np.float64).reshape(-1, 4)
+        assert np.array_equal(got, np.array(p['boxes'], np.float64).reshape(-1, 4)) and [b.labelid for b in gt.boxes] == p['cls']
+        n_exp += d.expand is not None; n_crop += d.crop is not None; n_flip += d.flip
+    assert n_exp > 10 and n_crop > 10 and n_flip > 10          # the cases exercise every branch
+
+
+def test_plan_order_is_enforced():
+    from ssd_tensorflow_amd import transforms as T
+    import pytest
+    p = T.ImagePlan(np.zeros((8, 8, 3), np.uint8))
+    gt = _sample((8, 8), [(0.5, 0.5, 0.5, 0.5)], [1])
+    p, _, gt = T.HorizontalFlipTransform()(p, None, gt)
+    with pytest.raises(NotImplementedError):
+        T.BrightnessTransform(delta=3)(p, None, gt)
+    with pytest.raises(ValueError):
+        T.ImagePlan(np.zeros((8, 8, 3), np.float32))

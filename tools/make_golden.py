@@ -270,6 +270,80 @@ def main():
         print('G8 case', case, 'detections', len(dc), 'gt', len(gk), 'mAP', oap.aps2map(mine))
     g8['ncases'] = np.array([3])
     np.savez_compressed(os.path.join(OUT, 'g8_average_precision.npz'), **g8)
+
+    # ---- G9 augmentation: the transforms that run without OpenCV, under the reference's own
+    # `random` stream.  (a) geometry: RandomTransform(Expand) -> SamplePicker(7 samplers) on a coordinate image
+    # (channel 0 = row, 1 = column), so the expand / crop window is read off the result; (b) pixels:
+    # RandomTransform(Brightness) -> RandomTransform(Contrast) -> RandomTransform(ReorderChannels) on uint8 noise.
+    import random as pyrandom
+    from oracle import augment as oa
+
+    def build_picker(trials):
+        def sampler(ov):
+            return tf.SamplerTransform(sample=True, min_scale=0.3, max_scale=1.0, min_aspect_ratio=0.5, max_aspect_ratio=2.0,
+                                       min_jaccard_overlap=ov, max_trials=trials)
+        return tf.SamplePickerTransform(samplers=[tf.SamplerTransform(sample=False)] + [sampler(o) for o in oa.SAMPLER_OVERLAPS[1:]])
+
+    g9 = {}
+    nrng = np.random.default_rng(99)
+    ncase = 40
+    tf_rnd_expand = tf.RandomTransform(prob=0.5, transform=tf.ExpandTransform(max_ratio=4.0, mean_value=[104, 117, 123]))
+    picker = build_picker(50)
+    n_exp = n_crop = n_drop = 0
+    for case in range(ncase):
+        size, boxes, cls = oa.synth_sample(nrng)
+        gt = ut.Sample('x', [ut.Box('c%d' % c, c, ut.Point(b[0], b[1]), ut.Size(b[2], b[3])) for b, c in zip(boxes, cls)], ut.Size(*size))
+        yy, xx = np.mgrid[0:size[1], 0:size[0]]
+        img = np.stack([yy, xx, np.full_like(yy, 7)], -1).astype(np.int32)
+        seed = 1000 + case
+        pyrandom.seed(seed)
+        d, _, g = tf_rnd_expand(img, None, gt)
+        d, _, g = picker(d, None, g)
+        # the same through the oracle
+        rng = oa.new_rng(seed)
+        ex = oa.plan_expand(rng, size, boxes, cls, 0.5)
+        osz, ob_, oc_ = (size, boxes, cls) if ex is None else (ex[0], ex[3], ex[4])
+        win, osz2, ob2, oc2 = oa.plan_sample_picker(rng, osz, ob_, oc_, 50)
+        assert (g.imgsize.w, g.imgsize.h) == tuple(osz2) and d.shape[:2] == (osz2[1], osz2[0]), ('G9 size', case)
+        rb = np.array([[b.center.x, b.center.y, b.size.w, b.size.h] for b in g.boxes], np.float64).reshape(-1, 4)
+        assert np.array_equal(rb, np.array(ob2, np.float64).reshape(-1, 4)), ('G9 boxes', case)
+        assert [b.labelid for b in g.boxes] == list(oc2), ('G9 classes', case)
+        x0 = 0 if win is None else win[0]; y0 = 0 if win is None else win[2]
+        exp_img = oa.expand(img, *ex[:3]) if ex is not None else img
+        assert np.array_equal(np.asarray(d, np.float64), np.asarray(exp_img[y0:y0 + osz2[1], x0:x0 + osz2[0]], np.float64)), ('G9 window', case)
+        n_exp += ex is not None; n_crop += win is not None; n_drop += len(oc2) < len(cls)
+        g9[f'size_{case}'] = np.array(size, np.int32); g9[f'boxes_{case}'] = np.array(boxes, np.float64); g9[f'cls_{case}'] = np.array(cls, np.int32)
+        g9[f'seed_{case}'] = np.array([seed]); g9[f'out_size_{case}'] = np.array([g.imgsize.w, g.imgsize.h], np.int32)
+        g9[f'out_boxes_{case}'] = rb; g9[f'out_cls_{case}'] = np.array([b.labelid for b in g.boxes], np.int32)
+        # where the result's corner pixels came from: (row, col) of the source image, or the mean value when expanded
+        g9[f'corner00_{case}'] = np.asarray(d[0, 0], np.float64); g9[f'corner11_{case}'] = np.asarray(d[-1, -1], np.float64)
+    print(f'G9 geometry: {ncase} cases, {n_exp} expanded, {n_crop} cropped, {n_drop} lost a box')
+    tf_b = tf.RandomTransform(prob=0.5, transform=tf.BrightnessTransform(delta=32))
+    tf_c = tf.RandomTransform(prob=0.5, transform=tf.ContrastTransform(lower=0.5, upper=1.5))
+    tf_r = tf.RandomTransform(prob=0.5, transform=tf.ReorderChannelsTransform())
+    npix = 16
+    for case in range(npix):
+        img = nrng.integers(0, 256, (20, 24, 3)).astype(np.uint8)
+        seed = 5000 + case
+        pyrandom.seed(seed)
+        d = img
+        for t in (tf_b, tf_c, tf_r):
+            d, _, _ = t(d, None, None)
+        rng = oa.new_rng(seed)
+        o = img
+        b_ = oa.plan_brightness(rng)
+        if b_ is not None:
+            o = oa.brightness(o, b_)
+        c_ = oa.plan_contrast(rng)
+        if c_ is not None:
+            o = oa.contrast(o, c_)
+        r_ = oa.plan_reorder(rng)
+        if r_ is not None:
+            o = o[:, :, r_]
+        assert d.dtype == o.dtype and np.array_equal(d, o), ('G9 pixels', case)
+        g9[f'pix_in_{case}'] = img; g9[f'pix_seed_{case}'] = np.array([seed]); g9[f'pix_out_{case}'] = np.asarray(d)
+    g9['ncases'] = np.array([ncase]); g9['npix'] = np.array([npix])
+    np.savez_compressed(os.path.join(OUT, 'g9_augment.npz'), **g9)
     print('all golden fixtures written and oracle agrees bit-exactly')
 
 
