@@ -599,8 +599,8 @@ static void launch_gather_h(GatherArgsH& a, const char* label, double flops, dou
 static void check_desc_h(const ConvDesc& d) {
     SSD_REQUIRE(d.KH * d.KW <= 9 && d.KH * d.KW >= 1, "conv: at most 9 taps (got %dx%d)", d.KH, d.KW);
     SSD_REQUIRE(d.Co % 8 == 0 && d.Ci % 8 == 0, "bf16 conv: Ci and Co must be multiples of 8 (got %d, %d)", d.Ci, d.Co);
-    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 31) && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 31),
-                "conv: tensor too large for 32-bit byte offsets");
+    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 31) - 8 && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 31) - 8,
+                "bf16 conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
 // Tile configurations (pixels x channels, pipeline stages -> workgroups resident per CU):

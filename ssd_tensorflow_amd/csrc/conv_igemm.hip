@@ -965,8 +965,9 @@ static void check_desc(const ConvDesc& d) {
     SSD_REQUIRE(d.KH * d.KW <= 9 && d.KH * d.KW >= 1, "conv: at most 9 taps (got %dx%d)", d.KH, d.KW);
     SSD_REQUIRE(d.Co % 4 == 0, "conv: Co must be a multiple of 4 (got %d)", d.Co);
     SSD_REQUIRE(d.Ci % 4 == 0 || d.Ci * d.KH * d.KW <= 32, "conv: Ci must be a multiple of 4 or Ci*taps <= 32 (got %d)", d.Ci);
-    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 31) && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 31),
-                "conv: tensor too large for 32-bit pixel indexing");
+    // buffer descriptors and gather offsets are 32-bit BYTE quantities (0xFFFFFFF0 is the out-of-range sentinel)
+    SSD_REQUIRE((long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 30) - 4 && (long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 30) - 4,
+                "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
 template <int MODE, int WM, int WN, int TM, int TN>
