@@ -1,0 +1,133 @@
+// First layer, fp32 (conv1_1: 3 input channels, 3x3): the whole reduction k = tap*Ci + c fits one 32-deep
+// block, so the layer is bound by writing its 64-channel output.  Every lane gathers the image values its
+// MFMA operands need straight from the fp32 image (zero padding = out-of-range buffer offsets), the filter
+// sits in registers for the whole kernel (exact fp32 products on v_mfma_f32_32x32x2_f32), and outputs leave
+// through a per-wave LDS tile as full rows, 16 bytes per lane.  (The generic gather kernel's packed small-C
+// path stored 4 bytes per lane: 0.40 ms; this kernel is bound by the 737 MB write.)
+#include "conv.h"
+#include "conv_detail.h"
+#include "bf16.h"
+
+namespace ssd {
+
+struct FirstF32Args {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int M, Hi, Wi, Ci, Ho, Wo, Co;
+    int ntaps, stride, relu, ntiles;
+    int tap_dh[9], tap_dw[9];
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_fwd_f32_kernel(FirstF32Args p) {
+    constexpr int ROWF = NT * 32 + 4;                       // floats per LDS row (+4: conflict-free float4 writes)
+    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * ROWF];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    float* T = smem + wave * 32 * ROWF;
+    const int K = p.ntaps * p.Ci;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // MFMA k-step j multiplies k = 2j + lh: filter operand rows = output channels, image operand columns = pixels
+    float wa[NT][16];
+    int koff[16];
+    unsigned kbit[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = 2 * j + lh;
+        const bool kv = k < K;
+        const int tp = kv ? k / p.Ci : 0, c = kv ? k - tp * p.Ci : 0;
+        koff[j] = ((p.tap_dh[tp] * p.Wi + p.tap_dw[tp]) * p.Ci + c) * 4;
+        kbit[j] = kv ? (1u << tp) : 0u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wa[nt][j] = kv ? p.w[(size_t)k * p.Co + nt * 32 + li] : 0.f;
+    }
+    float bv[NT][4][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[nt][g][e] = p.bias ? p.bias[nt * 32 + 8 * g + 4 * lh + e] : 0.f;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
+
+    const int nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += nwaves) {
+        const int m = tile * 32 + li;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oh = t2 % p.Ho;
+        const int b = t2 / p.Ho;
+        const int h0 = oh * p.stride, w0 = ow * p.stride;
+        unsigned mk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int sh = h0 + p.tap_dh[t], sw = w0 + p.tap_dw[t];
+            if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi) mk |= 1u << t;
+        }
+        if (m >= p.M) mk = 0;
+        const unsigned base = (unsigned)(((b * p.Hi + h0) * p.Wi + w0) * p.Ci) * 4u;
+        float xb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned ok = 0u - (unsigned)((mk & kbit[j]) != 0u);
+            xb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)(((base + (unsigned)koff[j]) & ok) | (OOB & ~ok)), 0, 0));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nt][j], xb[j], acc, 0, 0, 0);
+            // D rows = channels (r&3) + 8*(r>>2) + 4*lh, D col = pixel li
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[4 * g + e] + bv[nt][g][e];
+                    if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(T + li * ROWF + nt * 32 + 8 * g + 4 * lh) = v;
+            }
+        }
+        constexpr int CPR = NT * 8;                  // 16-byte chunks per pixel row
+        constexpr int PPI = 64 / CPR;                // pixels per store instruction
+#pragma unroll
+        for (int i = 0; i < 32 / PPI; ++i) {
+            const int px = i * PPI + lane / CPR, ch = lane % CPR;
+            const int mo = tile * 32 + px;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + px * ROWF + ch * 4);
+            if (mo < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)mo * p.Co + ch * 4) = v;
+        }
+    }
+}
+
+bool conv_first_fwd_f32_applicable(const ConvDesc& d) { return d.Ci * d.KH * d.KW <= 32 && d.Co == 64 && d.Ci % 4 != 0; }
+
+void conv_first_fwd_f32(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s) {
+    SSD_REQUIRE(conv_first_fwd_f32_applicable(d), "first-layer kernel: Ci*taps <= 32 and Co == 64");
+    SSD_REQUIRE((long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 30) - 4 && (long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 30) - 4,
+                "first-layer kernel: tensor exceeds 4 GiB");
+    FirstF32Args a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
+    a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
+    a.ntaps = d.KH * d.KW; a.stride = d.stride;
+    for (int kh = 0; kh < d.KH; ++kh)
+        for (int kw = 0; kw < d.KW; ++kw) {
+            a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+            a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+        }
+    a.ntiles = cdiv(a.M, 32);
+    int blocks = cdiv(a.ntiles, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    ProfScope prof("conv_first_fwd", conv_flops(d), 4.0 * ((double)d.B * d.Hi * d.Wi * d.Ci + (double)a.M * d.Co), s);
+    hipLaunchKernelGGL(conv_first_fwd_f32_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+}  // namespace ssd

@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 // =================================================================================
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int MODE, int WM, int WN, int TM, int TN>
+// STRIDED: data gradient of a stride-2^k convolution (conv8_2, conv9_2): source pixel = (oh + dh) / stride when that
+// division is exact; the validity of a (row, tap) pair is recomputed per iteration with shifts and masks.
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false>
 __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_N = BM / 32;                      // DMA instructions per thread: A tile (8 rows x 128 B per wave-instruction)
@@ -361,6 +363,8 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
 
     const int a_c4 = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;      // this lane's (swizzled) k offset inside the 32-wide block
     unsigned a_off[A_N], a_msk[A_N];
+    int s_b[A_N], s_h[A_N], s_w[A_N];                          // STRIDED: image base, row and column of the output pixel
+    const int dshift = 31 - __builtin_clz(p.div);              // div is a power of two (checked by the launcher)
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
@@ -371,10 +375,13 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
         const int b = t2 / p.DH;
         const int rh = m < p.M ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
         a_off[i] = (unsigned)((b * p.SH * p.SW + rh * p.SW + rw) * p.SC + a_c4) * 4u;
+        s_b[i] = b * p.SH * p.SW; s_h[i] = rh; s_w[i] = rw;
         unsigned mk = 0;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int sh = rh + p.tap_dh[t], sw = rw + p.tap_dw[t];
-            if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+        if constexpr (!STRIDED) {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int sh = rh + p.tap_dh[t], sw = rw + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+            }
         }
         a_msk[i] = mk;
     }
@@ -408,10 +415,23 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
         unsigned char* Bs = lds + stage * STAGE + A_BYTES + wave * 1024;
         const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * BK) * 4);
         const unsigned cmask = 0u - (unsigned)(cc * BK + a_c4 < p.SC);
+        if constexpr (STRIDED) {
+            const int dh = p.tap_dh[tap], dw = p.tap_dw[tap], lowbits = p.div - 1;
 #pragma unroll
-        for (int i = 0; i < A_N; ++i) {
-            const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)(((a_off[i] + toff) & m) | (OOB & ~m)), 0, 0, 0);
+            for (int i = 0; i < A_N; ++i) {
+                const int sh = s_h[i] + dh, sw = s_w[i] + dw;
+                const int qh = sh >> dshift, qw = sw >> dshift;                 // arithmetic shifts: a negative stays negative
+                const bool ok = ((sh | sw) & lowbits) == 0 && (unsigned)qh < (unsigned)p.SH && (unsigned)qw < (unsigned)p.SW;
+                const unsigned m = (0u - (unsigned)ok) & cmask;
+                const unsigned off = (unsigned)((s_b[i] + qh * p.SW + qw) * p.SC + cc * BK + a_c4) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)((off & m) | (OOB & ~m)), 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_N; ++i) {
+                const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)(((a_off[i] + toff) & m) | (OOB & ~m)), 0, 0, 0);
+            }
         }
         if constexpr (MODE == MODE_FWD) {
             const unsigned woff = (unsigned)((tap * p.wci + cc * BK) * p.wco) * 4u;
@@ -970,11 +990,11 @@ static void check_desc(const ConvDesc& d) {
                 "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false>
 static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN>;
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
@@ -1037,6 +1057,11 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
     const bool smallc = d.Ci % 4 != 0;
     const double fl = conv_flops(d), by = conv_bytes(d);
     SSD_REQUIRE(!y_bf16 || smallc, "bf16 output from fp32 input: only the packed small-C layer (conv1_1)");
+    static const int first_kernel = env_int("SSD_FIRST_F32", 1);        // A/B switch
+    if (smallc && !y_bf16 && first_kernel && conv_first_fwd_f32_applicable(d)) {
+        conv_first_fwd_f32(d, x, w, bias, static_cast<float*>(y), relu, s);
+        return;
+    }
     if (smallc) {
         if (y_bf16) launch_gather<MODE_FWD, 4, 1, 1, 2, true, false, true>(a, "conv_fwd_smallc_128x64_bf16out", fl, by, s);
         else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
@@ -1085,7 +1110,10 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
         }
     const double fl = conv_flops(d), by = conv_bytes(d) + (mask ? 4.0 * d.B * d.Hi * d.Wi * d.Ci : 0.0);
     const int cfg = pick_tile(a.M, a.DN, MODE_DGRAD);
-    if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
+    if (d.stride > 1 && use_dma() && (d.stride & (d.stride - 1)) == 0) {      // conv8_2, conv9_2, vgg512 conv10_2
+        if (cfg == 0 || cfg == 1) launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
+        else launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2, true>(a, "conv_dgrad_strided_64x128", fl, by, s);
+    } else if (d.stride > 1) {
         if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
     } else if (use_dma()) {
