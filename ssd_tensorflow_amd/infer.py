@@ -14,6 +14,8 @@ import numpy as np
 from .ssdvgg import SSDVGG, Session
 from .ssdutils import get_preset_by_name, boxes_from_detection
 from .training_data import VOC_NAMES
+from .pascal_summary import PascalSummary
+from .utils import Size
 
 
 def sample_generator(samples, image_size, batch_size):
@@ -46,7 +48,8 @@ def main(argv=None):
     parser.add_argument('--data-source', default=None, help='out of scope (dataset readers)')
     parser.add_argument('--data-dir', default='pascal-voc', help='out of scope (dataset readers)')
     parser.add_argument('--sample', default='test', choices=['test', 'trainval'], help='out of scope')
-    parser.add_argument('--pascal-summary', default='False', help='out of scope (VOC submission files)')
+    parser.add_argument('--pascal-summary', type=lambda v: v.lower() in ('1', 'true', 'yes', 'y', 't'), default=False,
+                        help='write VOC comp4 submission files (pascal_summary.py) to --output-dir')
     parser.add_argument('--synthetic', type=int, default=0, help='run on N synthetic images instead of files')
     parser.add_argument('--preset', default=None, help='preset when no checkpoint is given')
     parser.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='f32, or bf16 activations on the bf16 matrix cores (fp32 master weights, loss and optimizer)')
@@ -88,9 +91,11 @@ def main(argv=None):
             rng = np.random.default_rng(1)
             files = [rng.integers(0, 256, (size.h, size.w, 3)).astype(np.float32) for _ in range(args.synthetic)]
         if not files:
-            print('[!] No files specified'); return 1                                        # infer.py:147-149
-        if args.dump_predictions:
+            print('[!] No files specified'); return 1
+        sizes = [Size(size.w, size.h)] * len(files)       # the images fed ARE the files here (no decode / resize step)                                        # infer.py:147-149
+        if args.dump_predictions or args.pascal_summary:
             os.makedirs(args.output_dir, exist_ok=True)
+        pascal_summary = PascalSummary() if args.pascal_summary else None                    # infer.py:208-209
         total = 0
         for x, idxs in sample_generator(files, size, args.batch_size):
             enc_boxes = sess.run(net.result, feed_dict={net.image_input: x, net.keep_prob: 1})
@@ -99,10 +104,15 @@ def main(argv=None):
             for i, det in enumerate(dets):
                 boxes = boxes_from_detection(det, lid2name)
                 total += len(boxes)
+                if pascal_summary is not None:                                               # infer.py:263-264
+                    name = files[idxs[i]] if isinstance(files[idxs[i]], str) else f'{idxs[i]:06d}.npy'
+                    pascal_summary.add_detections(name, boxes, img_size=sizes[idxs[i]])
                 if args.dump_predictions:
                     with open(os.path.join(args.output_dir, f'{idxs[i]:06d}.txt'), 'w') as f:
                         for conf, b in boxes:                                                # infer.py:251-258
                             f.write('{} {} {} {} {} {}\n'.format(b.label, b.center.x, b.center.y, b.size.w, b.size.h, conf))
+        if pascal_summary is not None:                                                       # infer.py:278-279
+            pascal_summary.write_summary(args.output_dir)
         print('[i] Processed {} images, {} detections'.format(len(files), total))
     return 0
 

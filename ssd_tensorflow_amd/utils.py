@@ -59,3 +59,13 @@ def normalize_box(box):
     xmin = min(xmin, xmax); ymin = min(ymin, ymax)
     center, size = abs2prop(xmin, xmax, ymin, ymax, img)
     return Box(box.label, box.labelid, center, size)
+
+
+def load_data_source(data_source):
+    """utils.py:44-55: the module `source_<name>` must provide get_source()"""
+    import importlib
+    try:
+        module = importlib.import_module('ssd_tensorflow_amd.source_' + data_source)
+    except ImportError:
+        module = importlib.import_module('source_' + data_source)
+    return module.get_source()
