@@ -52,9 +52,9 @@ KERNEL_SYMBOLS = {
     'conv_wgrad_128x64': ['conv_wgrad_kernel<2, 2, 2, 1, false', 'conv_wgrad_dma_kernel<2, 2, 2, 1>'],
     'detect_scan': ['detect_scan_kernel'],
     'conv_fwd_bf16_128x128': ['conv_gather_bf16_kernel<0, 2, 2, 2, 2, false, 2>'], 'conv_fwd_bf16_128x64': ['conv_gather_bf16_kernel<0, 4, 1, 1, 2, false, 2>'],
-    'conv_fwd_bf16_64x128': ['conv_gather_bf16_kernel<0, 2, 2, 1, 2, false, 2>'],
+    'conv_fwd_bf16_64x128': ['conv_gather_bf16_kernel<0, 2, 2, 1, 2, false, 2>'], 'conv_fwd_bf16_256x64_8w': ['conv_gather_bf16_kernel<0, 8, 1, 1, 2, false, 2>'],
     'conv_dgrad_bf16_128x128': ['conv_gather_bf16_kernel<1, 2, 2, 2, 2, false, 2>'], 'conv_dgrad_bf16_128x64': ['conv_gather_bf16_kernel<1, 4, 1, 1, 2, false, 2>'],
-    'conv_dgrad_bf16_64x128': ['conv_gather_bf16_kernel<1, 2, 2, 1, 2, false, 2>'],
+    'conv_dgrad_bf16_64x128': ['conv_gather_bf16_kernel<1, 2, 2, 1, 2, false, 2>'], 'conv_dgrad_bf16_256x64_8w': ['conv_gather_bf16_kernel<1, 8, 1, 1, 2, false, 2>'],
     'conv_wgrad_bf16_128x128': ['conv_wgrad_bf16_kernel<2, 2, 2, 2, 2>'], 'conv_wgrad_bf16_64x64': ['conv_wgrad_bf16_kernel<2, 2, 1, 1, 2>'],
     'conv_wgrad_bf16_64x128': ['conv_wgrad_bf16_kernel<2, 2, 1, 2, 2>'], 'conv_wgrad_bf16_128x64': ['conv_wgrad_bf16_kernel<2, 2, 2, 1, 2>'],
 }
