@@ -56,7 +56,8 @@ KERNEL_SYMBOLS = {
     'conv_dgrad_bf16_128x128': ['conv_gather_bf16_kernel<1, 2, 2, 2, 2, false, 2>'], 'conv_dgrad_bf16_128x64': ['conv_gather_bf16_kernel<1, 4, 1, 1, 2, false, 2>'],
     'conv_dgrad_bf16_64x128': ['conv_gather_bf16_kernel<1, 2, 2, 1, 2, false, 2>'], 'conv_dgrad_bf16_256x64_8w': ['conv_gather_bf16_kernel<1, 8, 1, 1, 2, false, 2>'],
     'conv_wgrad_bf16_128x128': ['conv_wgrad_bf16_kernel<2, 2, 2, 2, 2>'], 'conv_wgrad_bf16_64x64': ['conv_wgrad_bf16_kernel<2, 2, 1, 1, 2>'],
-    'conv_wgrad_bf16_64x128': ['conv_wgrad_bf16_kernel<2, 2, 1, 2, 2>'], 'conv_wgrad_bf16_128x64': ['conv_wgrad_bf16_kernel<2, 2, 2, 1, 2>'],
+    'conv_wgrad_bf16_64x128': ['conv_wgrad_bf16_kernel<2, 2, 1, 2, 2>'], 'conv_wgrad_bf16_rows_64x64': ['conv_wgrad_bf16_rows_kernel<1>'],
+    'conv_wgrad_bf16_rows_64x128': ['conv_wgrad_bf16_rows_kernel<2>'], 'conv_wgrad_bf16_128x64': ['conv_wgrad_bf16_kernel<2, 2, 2, 1, 2>'],
 }
 
 

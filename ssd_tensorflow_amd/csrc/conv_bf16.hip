@@ -22,6 +22,7 @@
 #include "conv.h"
 #include "conv_detail.h"
 #include "bf16.h"
+#include <algorithm>
 
 namespace ssd {
 
@@ -510,6 +511,179 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
 }
 
 // =================================================================================
+// Weight gradient of the 64-input-channel 3x3 layers (conv1_2, conv2_1): one workgroup owns a whole KERNEL ROW
+// (the three taps dw = -1, 0, +1).  These layers have so little arithmetic per staged byte (K tile of 64
+// channels) that the per-tap kernel above is bound by the tile DMA; here the dy tile is loaded once for three taps
+// and the three shifted x tiles collapse into ONE tile with a one-pixel halo, 136 rows instead of 384 per 64 pixels.
+// The k dimension walks row-aligned blocks of <= 64 pixels of one image row, so a shift by +-1 never leaves the
+// image row inside a block: the halo pixel is either a real neighbour or outside the image, and the DMA's zero
+// fill is the zero padding -- no per-pixel masking of MFMA operands.
+// =================================================================================
+struct WgradRowsArgs {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* ws;              // [nsplit][9*Ci*Co + Co]
+    int B, H, W, Ci, Co;
+    int pad_h;              // kernel row kh reads image row oh + kh - pad_h
+    int nb, L;              // blocks per image row, pixels per block (<= 64)
+    int nblocks, bchunk, nsplit, NT;
+};
+
+template <int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs p) {
+    constexpr int BNT = 64 * TN, BP = 64, XROWS = 72;
+    constexpr int XROWB = 128, YROWB = BNT * 2;
+    constexpr int YCPR = BNT / 8, YRPP = 256 / YCPR, Y_N = BP / YRPP;
+    constexpr int X_LDS = XROWS * XROWB, STAGE = X_LDS + BP * YROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_split = 3 * p.NT;
+    const int split = wgid / per_split;
+    const int rem = wgid - split * per_split;
+    const int kh = rem / p.NT, nt = rem - kh * p.NT;
+    const int n0 = nt * BNT;
+    const int dh = kh - p.pad_h;
+    const int blk0 = split * p.bchunk;
+    const int blk1 = min(p.nblocks, blk0 + p.bchunk);
+    const int niter = blk1 - blk0;
+    const bool do_bias = kh == 0;
+
+    auto yswz = [](int r) { return YCPR == 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
+    // x staging: 128-byte rows, 8 lanes per row; pass 0, 1 = rows 0..63, pass 2 = rows 64..71 (wave 0 only)
+    const int xr = tid >> 3, xs = tid & 7;
+    const int xchunk = xs ^ (((xr >> 1) & 1) * 4);            // rows +32 / +64 keep bit 1 of the row
+    const unsigned xcm = 0u - (unsigned)(xchunk * 8 < p.Ci);
+    const int yr = tid / YCPR, ys = tid % YCPR;
+    const int ychunk = ys ^ yswz(yr);
+    const unsigned ycm = 0u - (unsigned)(n0 + ychunk * 8 < p.Co);
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Ci * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Co * 2u), 0x00020000);
+
+    auto issue = [&](int it, int stage) {
+        unsigned char* Xs = smem + stage * STAGE + wave * 1024;
+        unsigned char* Ys = smem + stage * STAGE + X_LDS + wave * 1024;
+        const int blk = blk0 + it;                        // uniform: block -> (image, row, block of the row)
+        const int bi = blk % p.nb;
+        const int t2 = blk / p.nb;
+        const int oh = t2 % p.H;
+        const int b = t2 / p.H;
+        const int ow0 = bi * p.L;
+        const int len = min(p.L, p.W - ow0);
+        const int sh = oh + dh;
+        const unsigned rowok = 0u - (unsigned)((unsigned)sh < (unsigned)p.H);
+        const int xbase = ((b * p.H + sh) * p.W + ow0 - 1) * p.Ci + xchunk * 8;       // element offset of tile row 0
+        const int ybase = ((b * p.H + oh) * p.W + ow0) * p.Co + n0 + ychunk * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = xr + 32 * j;                    // tile row r holds image column ow0 - 1 + r
+            const int ow = ow0 - 1 + r;
+            const unsigned mk = xcm & rowok & (0u - (unsigned)((unsigned)ow < (unsigned)p.W && r <= len + 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)(((unsigned)((xbase + r * p.Ci) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        }
+        if (wave == 0) {
+            const int r = 64 + xr;
+            const int ow = ow0 - 1 + r;
+            const unsigned mk = xcm & rowok & (0u - (unsigned)((unsigned)ow < (unsigned)p.W && r <= len + 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + 2 * 4096), 16, (int)(((unsigned)((xbase + r * p.Ci) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < Y_N; ++j) {
+            const int r = yr + j * YRPP;
+            const unsigned mk = ycm & (0u - (unsigned)(r < len));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)(((unsigned)((ybase + r * p.Co) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[3][TN];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
+    float bsum = 0.f;
+
+    const int wm = wave >> 1, wn = wave & 1;               // 2 x 2 waves: 32 input channels x 32*TN output channels each
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = lane & 15, cb = (lane >> 4) & 1;
+    const int prow = lh * 8 + (q >> 2);
+    int xa[3], ya[TN];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                            // tap t = dw + 1 reads x tile rows j + t
+        const int r = prow + t;
+        const int ch = (wm * 32) / 8 + cb * 2 + ((q >> 1) & 1);
+        xa[t] = r * XROWB + ((ch ^ (((r >> 1) & 1) * 4)) * 16) + (q & 1) * 8;
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int ch = (wn * 32 * TN + ni * 32) / 8 + cb * 2 + ((q >> 1) & 1);
+        ya[ni] = X_LDS + prow * YROWB + ((ch ^ yswz(prow)) * 16) + (q & 1) * 8;
+    }
+
+    auto compute = [&](int stage) {
+        const unsigned char* S = smem + stage * STAGE;
+        auto tr8 = [&](int off, int rowb) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off + 4 * rowb));
+            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+#pragma unroll
+        for (int st = 0; st < BP / 16; ++st) {
+            s16x8 a[3], b[TN];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[t] = tr8(xa[t] + st * 16 * XROWB, XROWB);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = tr8(ya[ni] + st * 16 * YROWB, YROWB);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, b[ni]),
+                                                                        acc[t][ni], 0, 0, 0);
+        }
+        if (do_bias && tid < BNT) {
+            const unsigned char* Ys = S + X_LDS;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BP; ++r) {
+                const int slot = (tid >> 3) ^ yswz(r);
+                s += bf2f(*reinterpret_cast<const unsigned short*>(Ys + r * YROWB + slot * 16 + (tid & 7) * 2));
+            }
+            bsum += s;
+        }
+    };
+
+    if (niter > 0) issue(0, 0);
+    for (int it = 0; it < niter; ++it) {
+        wait_tiles_and_sync<1>(0);
+        if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+        compute(it & 1);
+    }
+
+    const size_t wcount = (size_t)9 * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci >= p.Ci) continue;
+                slab[((size_t)(kh * 3 + t) * p.Ci + ci) * p.Co + n] = acc[t][ni][r];
+            }
+        }
+    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+}
+
+// =================================================================================
 // filter mirrors: fp32 [tap][Ci][Co] -> bf16 [tap][Ci][Co] and bf16 [tap][Co][Ci], all layers in one launch
 // =================================================================================
 struct CastTable {
@@ -722,11 +896,6 @@ static WgradPlanH plan_wgrad_h(const ConvDesc& d) {
     return p;
 }
 
-size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
-    WgradPlanH p = plan_wgrad_h(d);
-    return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
-}
-
 template <int WM, int WN, int TM, int TN, int NS = 2>
 static void launch_wgrad_h(WgradArgsH& a, const WgradPlanH& pl, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
@@ -740,9 +909,65 @@ static void launch_wgrad_h(WgradArgsH& a, const WgradPlanH& pl, const char* labe
     HIP_OK(hipGetLastError());
 }
 
+// ---- kernel-row variant (64 input channels, 3x3, stride 1, SAME) -------------------------------------------
+static bool rows_applicable(const ConvDesc& d) {
+    static const int on = env_int("SSD_WGRAD_ROWS_BF16", 1);      // A/B switch
+    return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo &&
+           d.Ci <= 64;
+}
+struct RowsPlan {
+    int nb, L, nblocks, bchunk, nsplit, NT, tn;
+};
+static RowsPlan plan_rows(const ConvDesc& d) {
+    RowsPlan p{};
+    p.nb = cdiv(d.Wo, 64);
+    p.L = cdiv(d.Wo, p.nb);
+    p.nblocks = d.B * d.Ho * p.nb;
+    p.tn = d.Co > 64 ? 2 : 1;
+    p.NT = cdiv(d.Co, 64 * p.tn);
+    int want = cdiv(1024, 3 * p.NT);
+    if (want > 256) want = 256;
+    const int maxs = cdiv(p.nblocks, 16);
+    p.nsplit = want > maxs ? maxs : want;
+    if (p.nsplit < 1) p.nsplit = 1;
+    p.bchunk = cdiv(p.nblocks, p.nsplit);
+    p.nsplit = cdiv(p.nblocks, p.bchunk);
+    return p;
+}
+
+template <int TN>
+static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(72 * 128 + 64 * 64 * TN * 2);
+    auto kern = conv_wgrad_bf16_rows_kernel<TN>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(a.nsplit * 3 * a.NT), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
+    const size_t per = (size_t)d.KH * d.KW * d.Ci * d.Co + d.Co;
+    size_t n = (size_t)plan_wgrad_h(d).nsplit * per;
+    if (rows_applicable(d)) n = std::max(n, (size_t)plan_rows(d).nsplit * per);
+    return n;
+}
+
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s) {
     check_desc_h(d);
+    if (rows_applicable(d)) {
+        const RowsPlan rp = plan_rows(d);
+        WgradRowsArgs r{};
+        r.x = x; r.dy = dy; r.ws = ws;
+        r.B = d.B; r.H = d.Ho; r.W = d.Wo; r.Ci = d.Ci; r.Co = d.Co; r.pad_h = d.pad_h;
+        r.nb = rp.nb; r.L = rp.L; r.nblocks = rp.nblocks; r.bchunk = rp.bchunk; r.nsplit = rp.nsplit; r.NT = rp.NT;
+        const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+        if (rp.tn == 2) launch_wgrad_rows<2>(r, "conv_wgrad_bf16_rows_64x128", fl, by, s);
+        else launch_wgrad_rows<1>(r, "conv_wgrad_bf16_rows_64x64", fl, by, s);
+        wgrad_reduce(ws, rp.nsplit, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+        return;
+    }
     WgradPlanH pl = plan_wgrad_h(d);
     WgradArgsH a{};
     a.x = x; a.dy = dy; a.ws = ws;
