@@ -511,118 +511,164 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
 }
 
 // =================================================================================
-// Weight gradient of the 64-input-channel 3x3 layers (conv1_2, conv2_1): one workgroup owns a whole KERNEL ROW
-// (the three taps dw = -1, 0, +1).  These layers have so little arithmetic per staged byte (K tile of 64
-// channels) that the per-tap kernel above is bound by the tile DMA; here the dy tile is loaded once for three taps
-// and the three shifted x tiles collapse into ONE tile with a one-pixel halo, 136 rows instead of 384 per 64 pixels.
-// The k dimension walks row-aligned blocks of <= 64 pixels of one image row, so a shift by +-1 never leaves the
-// image row inside a block: the halo pixel is either a real neighbour or outside the image, and the DMA's zero
-// fill is the zero padding -- no per-pixel masking of MFMA operands.
+// Kernel-row weight gradient (3x3, stride 1, SAME): one workgroup owns a whole KERNEL ROW, the three taps
+// dw = -1, 0, +1.  The per-tap kernel above stages 2 tiles per tap; its 3x3 layers are bound by that tile DMA, not by
+// the matrix cores.  Here dy is staged once for three taps and the three shifted x tiles collapse into ONE tile with
+// a one-slot halo: 136 rows per 64 k-slots instead of 384.
+// The k dimension walks the image in PADDED raster order, (W + 2) slots per image row with an empty slot before and
+// after the W pixels.  A shift by +-1 from a pixel then lands on its real neighbour or on an empty slot, never in
+// another image row, and empty slots are simply not fetched (LDS-DMA zero fill, for x and for dy): the zero padding
+// costs no operand masking, and the price is W / (W + 2) of the k-slots doing work.
 // =================================================================================
 struct WgradRowsArgs {
     const bf16_t* x;
     const bf16_t* dy;
     float* ws;              // [nsplit][9*Ci*Co + Co]
     int B, H, W, Ci, Co;
-    int pad_h;              // kernel row kh reads image row oh + kh - pad_h
-    int nb, L;              // blocks per image row, pixels per block (<= 64)
-    int nblocks, bchunk, nsplit, NT;
+    int pad_h;              // kernel row kh reads image row y + kh - pad_h
+    int CT, NT;
+    long long nslots;       // B * H * (W + 2)
+    int schunk, nsplit;     // k-slots per split (multiple of 64)
 };
 
-template <int TN>
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs p) {
-    constexpr int BNT = 64 * TN, BP = 64, XROWS = 72;
-    constexpr int XROWB = 128, YROWB = BNT * 2;
+    constexpr int BKT = 64 * TM, BNT = 64 * TN, BP = 64, XROWS = 72;
+    constexpr int XROWB = BKT * 2, YROWB = BNT * 2;
+    constexpr int XCPR = BKT / 8, XRPP = 256 / XCPR, X_N = BP / XRPP;      // full staging passes over rows 0..63
+    constexpr int XTAIL_WAVES = 8 * XCPR / 64;                             // waves that stage rows 64..71
     constexpr int YCPR = BNT / 8, YRPP = 256 / YCPR, Y_N = BP / YRPP;
     constexpr int X_LDS = XROWS * XROWB, STAGE = X_LDS + BP * YROWB;
+    static_assert(TM * TN <= 2, "3 taps x TM x TN accumulator tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_split = 3 * p.NT;
+    const int per_split = 3 * p.CT * p.NT;
     const int split = wgid / per_split;
-    const int rem = wgid - split * per_split;
-    const int kh = rem / p.NT, nt = rem - kh * p.NT;
-    const int n0 = nt * BNT;
+    int rem = wgid - split * per_split;
+    const int nt = rem % p.NT;
+    rem /= p.NT;
+    const int ct = rem % p.CT;
+    const int kh = rem / p.CT;
+    const int c0 = ct * BKT, n0 = nt * BNT;
     const int dh = kh - p.pad_h;
-    const int blk0 = split * p.bchunk;
-    const int blk1 = min(p.nblocks, blk0 + p.bchunk);
-    const int niter = blk1 - blk0;
-    const bool do_bias = kh == 0;
+    const long long s0 = (long long)split * p.schunk;
+    const long long s1l = s0 + p.schunk < p.nslots ? s0 + p.schunk : p.nslots;
+    const int nvalid = (int)(s1l - s0);                     // slots of this split
+    const int niter = (nvalid + BP - 1) / BP;
+    const bool do_bias = kh == 0 && ct == 0;
 
-    auto yswz = [](int r) { return YCPR == 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
-    // x staging: 128-byte rows, 8 lanes per row; pass 0, 1 = rows 0..63, pass 2 = rows 64..71 (wave 0 only)
-    const int xr = tid >> 3, xs = tid & 7;
-    const int xchunk = xs ^ (((xr >> 1) & 1) * 4);            // rows +32 / +64 keep bit 1 of the row
-    const unsigned xcm = 0u - (unsigned)(xchunk * 8 < p.Ci);
-    const int yr = tid / YCPR, ys = tid % YCPR;
-    const int ychunk = ys ^ yswz(yr);
+    auto swz = [](int r, int cpr) { return cpr >= 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
+    const int WP = p.W + 2;
+    // slot walk: +64 slots per iteration = (adv_b, adv_y, adv_x) in the mixed radix (image, row, padded column)
+    const int adv_x = BP % WP, adv_t = BP / WP;
+    const int adv_y = adv_t % p.H;
+    const int qadv = adv_t * p.W + adv_x;                   // pixels the linear (b, y, x) index moves, before the carry fix
+
+    // ---- staging rows of this thread: x rows xr + XRPP j (slot s0 - 1 + row), the tail row 64 + .., dy rows yr + YRPP j
+    const int xr = tid / XCPR, xs = tid % XCPR, yr = tid / YCPR, ys = tid % YCPR;
+    const int xchunk = xs ^ swz(xr, XCPR), ychunk = ys ^ swz(yr, YCPR);
+    const int xtchunk = xs ^ swz(64 + xr, XCPR);
+    const unsigned xcm = 0u - (unsigned)(c0 + xchunk * 8 < p.Ci), xtcm = 0u - (unsigned)(c0 + xtchunk * 8 < p.Ci);
     const unsigned ycm = 0u - (unsigned)(n0 + ychunk * 8 < p.Co);
+    struct Walk { int xp, y, q; };                          // padded column, image row, linear pixel index (b*H + y)*W + xp - 1
+    auto walk_init = [&](long long slot) {
+        Walk w;
+        if (slot < 0) {                                     // slot -1 (halo of the very first tile): the empty slot that ends "row -1";
+            w.xp = WP - 1; w.y = p.H - 1; w.q = -p.W + WP - 2;   // floor division keeps the walk's q linear in the slot
+            return w;
+        }
+        w.xp = (int)(slot % WP);
+        const long long t = slot / WP;
+        w.y = (int)(t % p.H);
+        w.q = (int)(t * p.W) + w.xp - 1;
+        return w;
+    };
+    auto walk_step = [&](Walk& w) {
+        w.xp += adv_x;
+        const bool cx = w.xp >= WP;
+        w.xp -= cx ? WP : 0;
+        w.y += adv_y + (cx ? 1 : 0);
+        w.y -= w.y >= p.H ? p.H : 0;
+        w.q += qadv - (cx ? 2 : 0);
+    };
+    Walk xw[X_N], xtw, yw[Y_N];
+#pragma unroll
+    for (int j = 0; j < X_N; ++j) xw[j] = walk_init(s0 - 1 + xr + j * XRPP);
+    xtw = walk_init(s0 - 1 + 64 + xr);
+#pragma unroll
+    for (int j = 0; j < Y_N; ++j) yw[j] = walk_init(s0 + yr + j * YRPP);
+
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Ci * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Co * 2u), 0x00020000);
+    const int xconst = (dh * p.W) * p.Ci + c0, yconst = n0;
 
+    // x tile row `row` = slot (iteration base) - 1 + row; real iff it is a pixel column, the shifted image row exists and
+    // the slot belongs to this split's range (+ the one-slot halo on either side)
     auto issue = [&](int it, int stage) {
         unsigned char* Xs = smem + stage * STAGE + wave * 1024;
         unsigned char* Ys = smem + stage * STAGE + X_LDS + wave * 1024;
-        const int blk = blk0 + it;                        // uniform: block -> (image, row, block of the row)
-        const int bi = blk % p.nb;
-        const int t2 = blk / p.nb;
-        const int oh = t2 % p.H;
-        const int b = t2 / p.H;
-        const int ow0 = bi * p.L;
-        const int len = min(p.L, p.W - ow0);
-        const int sh = oh + dh;
-        const unsigned rowok = 0u - (unsigned)((unsigned)sh < (unsigned)p.H);
-        const int xbase = ((b * p.H + sh) * p.W + ow0 - 1) * p.Ci + xchunk * 8;       // element offset of tile row 0
-        const int ybase = ((b * p.H + oh) * p.W + ow0) * p.Co + n0 + ychunk * 8;
+        const int left = nvalid - it * BP;                 // slots of this tile inside the split
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = xr + 32 * j;                    // tile row r holds image column ow0 - 1 + r
-            const int ow = ow0 - 1 + r;
-            const unsigned mk = xcm & rowok & (0u - (unsigned)((unsigned)ow < (unsigned)p.W && r <= len + 1));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)(((unsigned)((xbase + r * p.Ci) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        for (int j = 0; j < X_N; ++j) {
+            const int row = xr + j * XRPP;
+            const bool ok = (unsigned)(xw[j].xp - 1) < (unsigned)p.W && (unsigned)(xw[j].y + dh) < (unsigned)p.H && row <= left + 1;
+            const unsigned mk = xcm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((xw[j].q * p.Ci + xconst + xchunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
+            walk_step(xw[j]);
         }
-        if (wave == 0) {
-            const int r = 64 + xr;
-            const int ow = ow0 - 1 + r;
-            const unsigned mk = xcm & rowok & (0u - (unsigned)((unsigned)ow < (unsigned)p.W && r <= len + 1));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + 2 * 4096), 16, (int)(((unsigned)((xbase + r * p.Ci) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        if (wave < XTAIL_WAVES) {
+            const int row = 64 + xr;
+            const bool ok = (unsigned)(xtw.xp - 1) < (unsigned)p.W && (unsigned)(xtw.y + dh) < (unsigned)p.H && row <= left + 1;
+            const unsigned mk = xtcm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((xtw.q * p.Ci + xconst + xtchunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + X_N * 4096), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
         }
+        walk_step(xtw);
 #pragma unroll
         for (int j = 0; j < Y_N; ++j) {
-            const int r = yr + j * YRPP;
-            const unsigned mk = ycm & (0u - (unsigned)(r < len));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)(((unsigned)((ybase + r * p.Co) * 2) & mk) | (OOBH & ~mk)), 0, 0, 0);
+            const int row = yr + j * YRPP;
+            const bool ok = (unsigned)(yw[j].xp - 1) < (unsigned)p.W && row < left;
+            const unsigned mk = ycm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((yw[j].q * p.Co + yconst + ychunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
+            walk_step(yw[j]);
         }
     };
 
-    f32x16 acc[3][TN];
+    f32x16 acc[3][TM][TN];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
     float bsum = 0.f;
 
-    const int wm = wave >> 1, wn = wave & 1;               // 2 x 2 waves: 32 input channels x 32*TN output channels each
+    const int wm = wave >> 1, wn = wave & 1;               // 2 x 2 waves: 32*TM input channels x 32*TN output channels each
     const int li = lane & 31, lh = lane >> 5;
     const int q = lane & 15, cb = (lane >> 4) & 1;
     const int prow = lh * 8 + (q >> 2);
-    int xa[3], ya[TN];
+    int xa[3][TM], ya[TN];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {                            // tap t = dw + 1 reads x tile rows j + t
-        const int r = prow + t;
-        const int ch = (wm * 32) / 8 + cb * 2 + ((q >> 1) & 1);
-        xa[t] = r * XROWB + ((ch ^ (((r >> 1) & 1) * 4)) * 16) + (q & 1) * 8;
-    }
+    for (int t = 0; t < 3; ++t)                              // tap t = dw + 1 reads x tile rows j + t
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int r = prow + t;
+            const int ch = (wm * 32 * TM + mi * 32) / 8 + cb * 2 + ((q >> 1) & 1);
+            xa[t][mi] = r * XROWB + ((ch ^ swz(r, XCPR)) * 16) + (q & 1) * 8;
+        }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int ch = (wn * 32 * TN + ni * 32) / 8 + cb * 2 + ((q >> 1) & 1);
-        ya[ni] = X_LDS + prow * YROWB + ((ch ^ yswz(prow)) * 16) + (q & 1) * 8;
+        ya[ni] = X_LDS + prow * YROWB + ((ch ^ swz(prow, YCPR)) * 16) + (q & 1) * 8;
     }
 
     auto compute = [&](int stage) {
@@ -634,24 +680,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
         };
 #pragma unroll
         for (int st = 0; st < BP / 16; ++st) {
-            s16x8 a[3], b[TN];
+            s16x8 a[3][TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[t] = tr8(xa[t] + st * 16 * XROWB, XROWB);
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) a[t][mi] = tr8(xa[t][mi] + st * 16 * XROWB, XROWB);
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) b[ni] = tr8(ya[ni] + st * 16 * YROWB, YROWB);
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, b[ni]),
-                                                                        acc[t][ni], 0, 0, 0);
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t][mi]),
+                                                                                __builtin_bit_cast(bf16x8, b[ni]), acc[t][mi][ni], 0, 0, 0);
         }
         if (do_bias && tid < BNT) {
             const unsigned char* Ys = S + X_LDS;
             float s = 0.f;
 #pragma unroll 8
             for (int r = 0; r < BP; ++r) {
-                const int slot = (tid >> 3) ^ yswz(r);
+                const int slot = (tid >> 3) ^ swz(r, YCPR);
                 s += bf2f(*reinterpret_cast<const unsigned short*>(Ys + r * YROWB + slot * 16 + (tid & 7) * 2));
             }
             bsum += s;
@@ -670,16 +720,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * 32 * TN + ni * 32 + li;
-            if (n >= p.Co) continue;
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ci >= p.Ci) continue;
-                slab[((size_t)(kh * 3 + t) * p.Ci + ci) * p.Co + n] = acc[t][ni][r];
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * 32 * TN + ni * 32 + li;
+                if (n >= p.Co) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = c0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (ci >= p.Ci) continue;
+                    slab[((size_t)(kh * 3 + t) * p.Ci + ci) * p.Co + n] = acc[t][mi][ni][r];
+                }
             }
-        }
     if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
 }
 
@@ -909,40 +961,46 @@ static void launch_wgrad_h(WgradArgsH& a, const WgradPlanH& pl, const char* labe
     HIP_OK(hipGetLastError());
 }
 
-// ---- kernel-row variant (64 input channels, 3x3, stride 1, SAME) -------------------------------------------
+// ---- kernel-row variant (3x3, stride 1, SAME) --------------------------------------------------------------
+// 0: off   1: the 64-input-channel layers (conv1_2, conv2_1)   2: every applicable layer
+static int rows_mode() {
+    static const int v = env_int("SSD_WGRAD_ROWS_BF16", 1);      // tuning / A-B switch
+    return v;
+}
 static bool rows_applicable(const ConvDesc& d) {
-    static const int on = env_int("SSD_WGRAD_ROWS_BF16", 1);      // A/B switch
-    return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo &&
-           d.Ci <= 64;
+    const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo;
+    if (!shape || rows_mode() == 0) return false;
+    return d.Ci <= 64 || rows_mode() >= 2;
 }
 struct RowsPlan {
-    int nb, L, nblocks, bchunk, nsplit, NT, tn;
+    int tm, tn, CT, NT, schunk, nsplit;
+    long long nslots;
 };
 static RowsPlan plan_rows(const ConvDesc& d) {
     RowsPlan p{};
-    p.nb = cdiv(d.Wo, 64);
-    p.L = cdiv(d.Wo, p.nb);
-    p.nblocks = d.B * d.Ho * p.nb;
-    p.tn = d.Co > 64 ? 2 : 1;
+    p.tm = d.Ci > 64 ? 2 : 1;
+    p.tn = (p.tm == 1 && d.Co > 64) ? 2 : 1;
+    p.CT = cdiv(d.Ci, 64 * p.tm);
     p.NT = cdiv(d.Co, 64 * p.tn);
-    int want = cdiv(1024, 3 * p.NT);
+    p.nslots = (long long)d.B * d.Ho * (d.Wo + 2);
+    int want = cdiv(1024, 3 * p.CT * p.NT);
     if (want > 256) want = 256;
-    const int maxs = cdiv(p.nblocks, 16);
+    const int maxs = cdiv(p.nslots, 64 * 16);
     p.nsplit = want > maxs ? maxs : want;
     if (p.nsplit < 1) p.nsplit = 1;
-    p.bchunk = cdiv(p.nblocks, p.nsplit);
-    p.nsplit = cdiv(p.nblocks, p.bchunk);
+    p.schunk = cdiv(cdiv(p.nslots, p.nsplit), 64) * 64;
+    p.nsplit = cdiv(p.nslots, p.schunk);
     return p;
 }
 
-template <int TN>
+template <int TM, int TN>
 static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(72 * 128 + 64 * 64 * TN * 2);
-    auto kern = conv_wgrad_bf16_rows_kernel<TN>;
+    constexpr size_t lds = 2 * (size_t)(72 * 128 * TM + 64 * 128 * TN);
+    auto kern = conv_wgrad_bf16_rows_kernel<TM, TN>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(a.nsplit * 3 * a.NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.nsplit * 3 * a.CT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -961,10 +1019,11 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
         WgradRowsArgs r{};
         r.x = x; r.dy = dy; r.ws = ws;
         r.B = d.B; r.H = d.Ho; r.W = d.Wo; r.Ci = d.Ci; r.Co = d.Co; r.pad_h = d.pad_h;
-        r.nb = rp.nb; r.L = rp.L; r.nblocks = rp.nblocks; r.bchunk = rp.bchunk; r.nsplit = rp.nsplit; r.NT = rp.NT;
+        r.CT = rp.CT; r.NT = rp.NT; r.nslots = rp.nslots; r.schunk = rp.schunk; r.nsplit = rp.nsplit;
         const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
-        if (rp.tn == 2) launch_wgrad_rows<2>(r, "conv_wgrad_bf16_rows_64x128", fl, by, s);
-        else launch_wgrad_rows<1>(r, "conv_wgrad_bf16_rows_64x64", fl, by, s);
+        if (rp.tm == 2) launch_wgrad_rows<2, 1>(r, "conv_wgrad_bf16_rows_128x64", fl, by, s);
+        else if (rp.tn == 2) launch_wgrad_rows<1, 2>(r, "conv_wgrad_bf16_rows_64x128", fl, by, s);
+        else launch_wgrad_rows<1, 1>(r, "conv_wgrad_bf16_rows_64x64", fl, by, s);
         wgrad_reduce(ws, rp.nsplit, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
         return;
     }
