@@ -36,7 +36,7 @@ PEAK_HBM = 8000.0           # GB/s spec
 
 # kernel label (event profiler) -> substring of the kernel symbol in rocprofv3 output
 def _gather(mode, wm, wn, tm, tn):
-    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d>' % (mode, wm, wn, tm, tn),            # default (LDS-DMA staging)
+    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d, false>' % (mode, wm, wn, tm, tn),     # default (LDS-DMA staging)
             'conv_gather_kernel<%d, %d, %d, %d, %d, false, false' % (mode, wm, wn, tm, tn)]    # SSD_GLDS=0
 
 
