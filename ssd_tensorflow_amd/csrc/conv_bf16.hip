@@ -64,6 +64,78 @@ __device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
     asm volatile("" ::: "memory");
 }
 
+// Epilogue of both gather kernels, through an fp32 LDS tile [BM][BN + 4]: full-line loads / stores, fused bias + relu
+// (forward) or accumulate + relu mask (data gradient), ONE rounding to bf16.  The caller has passed a barrier after its
+// last LDS read.
+template <int MODE, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned char* smem, const f32x16 (&acc)[TM][TN], int tid, int wm,
+                                                int wn, int li, int lh, int m0, int n0) {
+    constexpr int NTHR = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ml = wm * 32 * TM + mi * 32 + li;
+                const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
+                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) =
+                    f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            }
+    __syncthreads();
+    constexpr int TPR = BN / 8;               // threads per row, 8 channels each
+    constexpr int RPP = NTHR / TPR;           // rows per pass
+    const int cg = tid % TPR, r0 = tid / TPR;
+    const int n = n0 + cg * 8;
+    if (n >= p.DN) return;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias) ? p.bias[n + e] : 0.f;
+#pragma unroll 2
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int ml = r0 + ps * RPP;
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const size_t o = (size_t)m * p.DN + n;
+        if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += bv[e];
+                if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+        } else {
+            if (p.accum) {
+                const u32x4 old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += lo2f(old[e]);
+                    v[2 * e + 1] += hi2f(old[e]);
+                }
+            }
+            if (p.mask) {
+                const u32x4 y = *reinterpret_cast<const u32x4*>(p.mask + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = lo2f(y[e]) > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = hi2f(y[e]) > 0.f ? v[2 * e + 1] : 0.f;
+                }
+            }
+        }
+        if (p.out_f32) {
+            float* d = reinterpret_cast<float*>(p.dst) + o;
+            *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + o) =
+                u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
+    }
+}
+
 template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherArgsH p) {
     constexpr int NTHR = 64 * WM * WN;                // 4 or 8 waves
@@ -220,71 +292,147 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     }
     __syncthreads();
 
-    // ---- epilogue through an fp32 LDS tile [BM][LDC]: full-line loads / stores, fused bias+relu
-    // (forward) or accumulate + relu mask (data gradient), one rounding to bf16
-    float* Cs = reinterpret_cast<float*>(smem);
+    gather_epilogue<MODE, WM, WN, TM, TN>(p, smem, acc, tid, wm, wn, li, lh, m0, n0);
+}
+
+// =================================================================================
+// Kernel-row gather (3x3, stride 1, SAME, any dilation <= 8): one pipeline unit = one KERNEL ROW of one 64-channel
+// chunk, i.e. the three taps dw = -dil, 0, +dil.  The per-tap kernel above pays one DMA round trip (~2700 cycles,
+// issued -> landed) per 512 MFMA cycles; here a unit stages ONE activation tile with a dil-pixel halo on either side
+// (the three shifted tiles of a stride-1 row are the same pixels) plus the three filter tiles, and multiplies for
+// 1536 MFMA cycles: 21.7 KB instead of 32 KB staged per tap, a third of the barriers, the round trip amortised 3x.
+// No double buffering (the unit fills the LDS budget of a 2-workgroups-per-CU kernel); the second workgroup of the CU
+// computes while this one waits.  The halo tile is a run of CONSECUTIVE pixels of the NHWC tensor, loaded without
+// looking at image geometry; what is not a neighbour (next image row, padding) is zeroed per lane when the operand is
+// read (4 v_cndmask per fragment), from the same 9-bit tap masks the per-tap kernel uses for its DMA.
+// =================================================================================
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH p, int dil) {
+    constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int AROWS = 160;                         // 128 + 2 * dil rows, in whole 32-row staging passes
+    constexpr int A_N = AROWS / 32, B_N = BN / 32;
+    constexpr int A_BYTES = AROWS * 128, UNIT = A_BYTES + 3 * BN * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / p.NT, nt = wg - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.DN * p.SC * 2u), 0x00020000);
+    unsigned b_off[B_N], b_ok[B_N];
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+    for (int i = 0; i < B_N; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        b_ok[i] = 0u - (unsigned)(n < p.DN);
+        b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.SC + a_ck) * 2u;
+    }
+    const int nchunks = (p.SC + HBK - 1) / HBK;
+    const int nunits = nchunks * 3;
+
+    auto issue = [&](int unit) {
+        const int cc = unit / 3, kr = unit - cc * 3;
+        unsigned char* As = smem + wave * 1024;
+        unsigned char* Bs = smem + A_BYTES + wave * 1024;
+        const unsigned cmask = 0u - (unsigned)(cc * HBK + a_ck < p.SC);
+        // tile row r = source pixel (m0 - dil + r), shifted by the kernel row: consecutive pixels of the NHWC tensor
+        const int pix0 = m0 - dil + p.tap_dh[kr * 3] * p.SW;
+        const int total = (p.M / (p.DH * p.DW)) * p.SH * p.SW;
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+        for (int i = 0; i < A_N; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            const int px = pix0 + r;
+            const unsigned m = cmask & (0u - (unsigned)((unsigned)px < (unsigned)total && r < BM + 2 * dil));
+            const unsigned off = (unsigned)((px * p.SC + cc * HBK + a_ck) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)((off & m) | (OOBH & ~m)), 0, 0, 0);
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ml = wm * 32 * TM + mi * 32 + li;
-                const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
-                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) =
-                    f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-            }
-    __syncthreads();
-    constexpr int TPR = BN / 8;               // threads per row, 8 channels each
-    constexpr int RPP = NTHR / TPR;           // rows per pass
-    const int cg = tid % TPR, r0 = tid / TPR;
-    const int n = n0 + cg * 8;
-    if (n >= p.DN) return;
-    float bv[8];
+        for (int kc = 0; kc < 3; ++kc) {
+            const unsigned woff = (unsigned)(((kr * 3 + kc) * p.DN * p.SC + cc * HBK) * 2);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias) ? p.bias[n + e] : 0.f;
-#pragma unroll 2
-    for (int ps = 0; ps < BM / RPP; ++ps) {
-        const int ml = r0 + ps * RPP;
-        const int m = m0 + ml;
-        if (m >= p.M) break;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
-        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const size_t o = (size_t)m * p.DN + n;
-        if constexpr (MODE == MODE_FWD) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[e] += bv[e];
-                if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
-        } else {
-            if (p.accum) {
-                const u32x4 old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += lo2f(old[e]);
-                    v[2 * e + 1] += hi2f(old[e]);
-                }
-            }
-            if (p.mask) {
-                const u32x4 y = *reinterpret_cast<const u32x4*>(p.mask + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] = lo2f(y[e]) > 0.f ? v[2 * e] : 0.f;
-                    v[2 * e + 1] = hi2f(y[e]) > 0.f ? v[2 * e + 1] : 0.f;
-                }
+            for (int i = 0; i < B_N; ++i) {
+                const unsigned m = cmask & b_ok[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + kc * (BN * 128) + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOBH & ~m)), 0, 0, 0);
             }
         }
-        if (p.out_f32) {
-            float* d = reinterpret_cast<float*>(p.dst) + o;
-            *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + o) =
-                u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    // per fragment row (output pixel) of this lane: which of the 9 taps fall inside the image
+    unsigned fmsk[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * 32 * TM + mi * 32 + li;
+        const int mm = m < p.M ? m : 0;
+        const int ow = mm % p.DW;
+        const int t2 = mm / p.DW;
+        const int oh = t2 % p.DH;
+        unsigned mk = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int sh = oh + p.tap_dh[t], sw = ow + p.tap_dw[t];
+            if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
+        }
+        fmsk[mi] = m < p.M ? mk : 0u;
+    }
+    // fragment addresses: tile row R = (row of the pixel) + tap_dw + dil; slot (2 st + lh) ^ ((R>>1)&7)
+    int a_addr[3][TM];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int R = wm * 32 * TM + mi * 32 + li + p.tap_dw[kc] + dil;        // tap_dw of a kernel column is the same in every kernel row
+            a_addr[kc][mi] = R * 128 + ((lh ^ ((R >> 1) & 7)) * 16);
+        }
+    const int q0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int b_row = A_BYTES + (wn * 32 * TN + li) * 128 + q0;
+
+    for (int unit = 0; unit < nunits; ++unit) {
+        __syncthreads();                                  // every wave is done with the previous unit's tiles
+        issue(unit);
+        wait_tiles_and_sync<1>(0);
+        const int kr = unit % 3;
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const int t = kr * 3 + kc;
+            bool ok[TM];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) ok[mi] = (fmsk[mi] >> t) & 1u;
+#pragma unroll
+            for (int st = 0; st < HBK / 16; ++st) {
+                i32x4 a[TM];
+                bf16x8 b[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    a[mi] = *reinterpret_cast<const i32x4*>(smem + (a_addr[kc][mi] ^ (st * 32)));
+                    a[mi] = ok[mi] ? a[mi] : i32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    b[ni] = *reinterpret_cast<const bf16x8*>(smem + kc * (BN * 128) + ((b_row + ni * 4096) ^ (st * 32)));
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], __builtin_bit_cast(bf16x8, a[mi]), acc[mi][ni], 0, 0, 0);
+            }
         }
     }
+    __syncthreads();
+    gather_epilogue<MODE, WM, WN, TM, TN>(p, smem, acc, tid, wm, wn, li, lh, m0, n0);
 }
 
 // =================================================================================
@@ -875,6 +1023,28 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
     }
 }
 
+// ---- kernel-row gather dispatch ------------------------------------------------------------------------------
+// SSD_GATHER_ROWS_BF16: 0 off, 1 (default) forward everywhere + dgrad of the undilated layers (measured +2..9 %; the
+// dilated mod_conv6 dgrad measured -2 %), 2 everywhere.
+static bool gather_rows_applicable(const ConvDesc& d, bool dgrad) {
+    static const int on = env_int("SSD_GATHER_ROWS_BF16", 1);
+    if (on == 1 && dgrad && d.dil != 1) return false;
+    return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.dil >= 1 && d.dil <= 8 && d.pad_h == d.dil &&
+           d.pad_w == d.dil;
+}
+template <int MODE>
+static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr size_t unit = 160 * 128 + 3 * 128 * 128, ctile = (size_t)128 * 132 * 4;
+    constexpr size_t lds = unit > ctile ? unit : ctile;
+    auto kern = conv_gather_bf16_rows_kernel<MODE>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    a.NT = cdiv(a.DN, 128);
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 128) * a.NT), dim3(256), lds, s, a, dil);
+    HIP_OK(hipGetLastError());
+}
+
 void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
                    hipStream_t s) {
     check_desc_h(d);
@@ -890,6 +1060,10 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+    if (gather_rows_applicable(d, false) && d.Co >= 128) {
+        launch_gather_rows<MODE_FWD>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
+        return;
+    }
     launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD), a, fl, by, s);
 }
 
@@ -910,6 +1084,10 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
     const double fl = conv_flops(d), by = 2.0 * (conv_elems(d) + (mask ? (double)d.B * d.Hi * d.Wi * d.Ci : 0.0));
     if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
         launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true, 2>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
+        return;
+    }
+    if (gather_rows_applicable(d, true) && d.Ci >= 128) {
+        launch_gather_rows<MODE_DGRAD>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
         return;
     }
     launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD), a, fl, by, s);

@@ -19,9 +19,14 @@ def bench_bf16(name, hw, ci, co, k, s, d):
     co = (co + 7) // 8 * 8
     ph, pw, ho, wo = conv_geom(hw, hw, k, s, d, 'SAME')
     bf = torch.bfloat16
+    ZERO = os.environ.get('SSD_BENCH_ZERO') == '1'      # DVFS probe: all-zero operands draw less power
     x = torch.randn((B, hw, hw, ci), device='cuda').to(bf); w = torch.randn((k, k, ci, co), device='cuda') * 0.05
+    if ZERO:
+        x.zero_(); w.zero_()
     bias = torch.zeros(co, device='cuda'); y = torch.empty((B, ho, wo, co), device='cuda', dtype=bf)
     dy = torch.randn((B, ho, wo, co), device='cuda').to(bf)
+    if ZERO:
+        dy.zero_()
     dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(bias)
     wio = torch.empty((k * k, ci, co), device='cuda', dtype=bf); woi = torch.empty((k * k, co, ci), device='cuda', dtype=bf)
     check(lib.ssd_op_cast_filter(ptr(w), ptr(wio), ptr(woi), k * k, ci, co, None))
