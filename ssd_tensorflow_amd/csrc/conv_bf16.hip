@@ -21,6 +21,9 @@
 // (data gradient; the arena's own HWIO order).
 #include "conv.h"
 #include "conv_detail.h"
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0
+#endif
 #include "bf16.h"
 #include <algorithm>
 
@@ -480,7 +483,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     const int mend = min(p.M, mbeg + p.mchunk);
     const int niter = (mend - mbeg + BP - 1) / BP;
     const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+#if WGRAD_ABL == 1
+    const bool do_bias = false;
+#else
     const bool do_bias = (tap == 0 && ct == 0);
+#endif
 
     // chunk swizzle of a pixel row r: rows of 256 or 512 bytes p ^ 4*(r&3); 128-byte rows p ^ 4*((r>>1)&1)
     auto swz = [](int r, int cpr) { return cpr >= 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
@@ -633,14 +640,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     for (int it = 0; it < niter; ++it) {
         const int later = niter - 1 - it;
         wait_tiles_and_sync<X_N + Y_N>(later < NS - 2 ? later : NS - 2);
+#if WGRAD_ABL == 3
+        if (it + NS - 1 < niter && it < 1) issue(it + NS - 1, st_i);
+#else
         if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
+#endif
+#if WGRAD_ABL != 4
         compute(st_c);
+#endif
         st_c = st_c + 1 == NS ? 0 : st_c + 1;
         st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
 
     const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
     float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#if WGRAD_ABL == 2
+    if (p.M < 0)
+#endif
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -881,6 +897,231 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
                 }
             }
     if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+}
+
+// =================================================================================
+// Kernel-row weight gradient, 8 waves: 128 input channels x 128 output channels x the three taps of a kernel row per
+// workgroup (padded-raster k order as above), ONE workgroup per CU, an NS-deep ring of 34-KB stages.
+// Why: a CU's LDS-DMA path moves ~55 B/clk at best (tools/probes/dma_rate.hip) and every 1-KB piece costs its issuing
+// wave 60..185 cycles.  The 4-wave kernels above need 64 B/clk to keep the matrix cores busy (32 KB per 16 MFMAs per
+// wave, two workgroups per CU) and run at ~40 % of peak; this tile needs 22 B/clk (34 KB per 24 MFMAs per wave) and
+// 4..5 pieces per wave and stage instead of 8.  Each wave owns 32 input channels x 64 output channels x 3 taps
+// (6 accumulator tiles); the bias gradient rides on the matrix cores too (a ones operand against the dy fragments in
+// the two waves of the kh = 0, ct = 0 workgroups) instead of a scalar LDS sweep.
+// =================================================================================
+template <int L>
+__device__ __forceinline__ void wait_pieces(int ahead) {            // leave `ahead` stages of L pieces in flight
+    static_assert(2 * L <= 63, "vmcnt field");
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_rows8_kernel(WgradRowsArgs p) {
+    constexpr int BKT = 128, BNT = 128, BP = 64, XROWS = 72, ROWB = 256, CPR = 16;
+    constexpr int RPP = 512 / CPR;                              // 32 pixel rows per staging pass of the workgroup
+    constexpr int X_N = BP / RPP, Y_N = BP / RPP;               // 2 + 2 full passes; rows 64..71 of x: waves 0 and 1
+    constexpr int X_LDS = XROWS * ROWB, STAGE = X_LDS + BP * ROWB;
+    static_assert(NS >= 2 && NS <= 4 && NS * STAGE <= 160 * 1024, "ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_split = 3 * p.CT * p.NT;
+    const int split = wgid / per_split;
+    int rem = wgid - split * per_split;
+    const int nt = rem % p.NT;
+    rem /= p.NT;
+    const int ct = rem % p.CT;
+    const int kh = rem / p.CT;
+    const int c0 = ct * BKT, n0 = nt * BNT;
+    const int dh = kh - p.pad_h;
+    const long long s0 = (long long)split * p.schunk;
+    const long long s1l = s0 + p.schunk < p.nslots ? s0 + p.schunk : p.nslots;
+    const int nvalid = (int)(s1l - s0);
+    const int niter = (nvalid + BP - 1) / BP;
+    const bool do_bias = kh == 0 && ct == 0;
+
+    const int WP = p.W + 2;
+    const int adv_x = BP % WP, adv_t = BP / WP;
+    const int adv_y = adv_t % p.H;
+    const int qadv = adv_t * p.W + adv_x;
+
+    // staging: thread -> (pixel row sr of a pass, 16-byte slot); both tiles have 256-byte rows, swizzle p ^ 4 (r & 3)
+    const int sr = tid >> 4, ss = tid & 15;
+    const int chunk = ss ^ ((sr & 3) * 4);                    // RPP and 64 are multiples of 4: one source chunk per thread
+    const unsigned xcm = 0u - (unsigned)(c0 + chunk * 8 < p.Ci), ycm = 0u - (unsigned)(n0 + chunk * 8 < p.Co);
+    struct Walk { int xp, y, q; };
+    auto walk_init = [&](long long slot) {
+        Walk w;
+        if (slot < 0) {
+            w.xp = WP - 1; w.y = p.H - 1; w.q = -p.W + WP - 2;
+            return w;
+        }
+        w.xp = (int)(slot % WP);
+        const long long t = slot / WP;
+        w.y = (int)(t % p.H);
+        w.q = (int)(t * p.W) + w.xp - 1;
+        return w;
+    };
+    auto walk_step = [&](Walk& w) {
+        w.xp += adv_x;
+        const bool cx = w.xp >= WP;
+        w.xp -= cx ? WP : 0;
+        w.y += adv_y + (cx ? 1 : 0);
+        w.y -= w.y >= p.H ? p.H : 0;
+        w.q += qadv - (cx ? 2 : 0);
+    };
+    Walk xw[X_N], xtw, yw[Y_N];
+#pragma unroll
+    for (int j = 0; j < X_N; ++j) xw[j] = walk_init(s0 - 1 + sr + j * RPP);
+    xtw = walk_init(s0 - 1 + 64 + sr);
+#pragma unroll
+    for (int j = 0; j < Y_N; ++j) yw[j] = walk_init(s0 + sr + j * RPP);
+
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Ci * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Co * 2u), 0x00020000);
+    const int xconst = (dh * p.W) * p.Ci + c0 + chunk * 8, yconst = n0 + chunk * 8;
+
+    auto issue = [&](int it, int stage) {
+        unsigned char* Xs = smem + stage * STAGE + wave * 1024;
+        unsigned char* Ys = Xs + X_LDS;
+        const int left = nvalid - it * BP;
+#pragma unroll
+        for (int j = 0; j < X_N; ++j) {
+            const int row = sr + j * RPP;
+            const bool ok = (unsigned)(xw[j].xp - 1) < (unsigned)p.W && (unsigned)(xw[j].y + dh) < (unsigned)p.H && row <= left + 1;
+            const unsigned mk = xcm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((xw[j].q * p.Ci + xconst) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * (RPP * ROWB)), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
+            walk_step(xw[j]);
+        }
+        if (wave < 2) {                                    // rows 64..71 (the halo needs 64 and 65)
+            const int row = 64 + sr;
+            const bool ok = (unsigned)(xtw.xp - 1) < (unsigned)p.W && (unsigned)(xtw.y + dh) < (unsigned)p.H && row <= left + 1;
+            const unsigned mk = xcm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((xtw.q * p.Ci + xconst) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + X_N * (RPP * ROWB)), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
+            walk_step(xtw);
+        }
+#pragma unroll
+        for (int j = 0; j < Y_N; ++j) {
+            const int row = sr + j * RPP;
+            const bool ok = (unsigned)(yw[j].xp - 1) < (unsigned)p.W && row < left;
+            const unsigned mk = ycm & (0u - (unsigned)ok);
+            const unsigned off = (unsigned)((yw[j].q * p.Co + yconst) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * (RPP * ROWB)), 16, (int)((off & mk) | (OOBH & ~mk)), 0, 0, 0);
+            walk_step(yw[j]);
+        }
+    };
+
+    f32x16 acc[3][2], accb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t][0][r] = acc[t][1][r] = 0.f;
+        accb[0][r] = accb[1][r] = 0.f;
+    }
+
+    const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves: 32 input channels x 64 output channels each
+    const bool bias_wave = do_bias && wm == 0;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = lane & 15, cb = (lane >> 4) & 1;
+    const int prow = lh * 8 + (q >> 2);
+    int xa[3], ya[2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                           // tap t = dw + 1 reads x tile rows j + t
+        const int r = prow + t;
+        const int ch = wm * 4 + cb * 2 + ((q >> 1) & 1);
+        xa[t] = r * ROWB + ((ch ^ ((r & 3) * 4)) * 16) + (q & 1) * 8;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int ch = wn * 8 + ni * 4 + cb * 2 + ((q >> 1) & 1);
+        ya[ni] = X_LDS + prow * ROWB + ((ch ^ ((prow & 3) * 4)) * 16) + (q & 1) * 8;
+    }
+    s16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;   // bf16 1.0
+
+    auto compute = [&](int stage) {
+        const unsigned char* S = smem + stage * STAGE;
+        s16x8 a[2][3], b[2][2];
+        auto tr8 = [&](int off) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off + 4 * ROWB));
+            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto frags = [&](int st) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[st & 1][t] = tr8(xa[t] + st * 16 * ROWB);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[st & 1][ni] = tr8(ya[ni] + st * 16 * ROWB);
+        };
+        frags(0);
+#pragma unroll
+        for (int st = 0; st < BP / 16; ++st) {
+            if (st + 1 < BP / 16) frags(st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[t][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[st & 1][t]),
+                                                                        __builtin_bit_cast(bf16x8, b[st & 1][ni]), acc[t][ni], 0, 0, 0);
+            if (bias_wave) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    accb[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, b[st & 1][ni]),
+                                                                      accb[ni], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < niter) issue(t, t);
+    int st_c = 0, st_i = NS - 1;
+    for (int it = 0; it < niter; ++it) {
+        const int later = niter - 1 - it;
+        const int ahead = later < NS - 2 ? later : NS - 2;
+        if (wave < 2) wait_pieces<X_N + 1 + Y_N>(ahead);
+        else wait_pieces<X_N + Y_N>(ahead);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
+        compute(st_c);
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+        st_i = st_i + 1 == NS ? 0 : st_i + 1;
+    }
+
+    const size_t wcount = (size_t)9 * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)split * (wcount + p.Co);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wn * 64 + ni * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci >= p.Ci) continue;
+                slab[((size_t)(kh * 3 + t) * p.Ci + ci) * p.Co + n] = acc[t][ni][r];
+            }
+        }
+    if (bias_wave && lh == 0) {                              // every row of ones^T dy is the column sum: row 0 lives in r = 0 of lanes 0..31
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wn * 64 + ni * 32 + li;
+            if (n < p.Co) slab[wcount + n] = accb[ni][0];
+        }
+    }
 }
 
 // =================================================================================
@@ -1171,6 +1412,41 @@ static RowsPlan plan_rows(const ConvDesc& d) {
     return p;
 }
 
+// 8-wave variant: SSD_WGRAD_ROWS8_BF16 = 0 off, else the ring depth (2..4) for the layers with >= 128 input channels
+static int rows8_mode() {
+    static const int v = env_int("SSD_WGRAD_ROWS8_BF16", 2);     // tuning / A-B switch (measured: 2, 3 and 4 stages tie)
+    return v;
+}
+static bool rows8_applicable(const ConvDesc& d) {
+    const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo;
+    return shape && rows8_mode() >= 2 && d.Ci >= 128 && rows_mode() != 2;
+}
+// one workgroup per CU and a single round: the fewest pixel splits (= the least fp32 slab traffic) that fill the chip
+static RowsPlan plan_rows8(const ConvDesc& d) {
+    RowsPlan p{};
+    p.tm = 2; p.tn = 2;
+    p.CT = cdiv(d.Ci, 128);
+    p.NT = cdiv(d.Co, 128);
+    p.nslots = (long long)d.B * d.Ho * (d.Wo + 2);
+    const int jobs = 3 * p.CT * p.NT;
+    int want = jobs >= 256 ? 1 : 256 / jobs;
+    const int maxs = (int)std::max<long long>(1, p.nslots / (64 * 8));
+    p.nsplit = want > maxs ? maxs : want;
+    p.schunk = cdiv(cdiv(p.nslots, p.nsplit), 64) * 64;
+    p.nsplit = cdiv(p.nslots, p.schunk);
+    return p;
+}
+template <int NS>
+static void launch_wgrad_rows8(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr size_t lds = (size_t)NS * (72 * 256 + 64 * 256);
+    auto kern = conv_wgrad_bf16_rows8_kernel<NS>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(a.nsplit * 3 * a.CT * a.NT), dim3(512), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
+
 template <int TM, int TN>
 static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(72 * 128 * TM + 64 * 128 * TN);
@@ -1186,12 +1462,27 @@ size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
     const size_t per = (size_t)d.KH * d.KW * d.Ci * d.Co + d.Co;
     size_t n = (size_t)plan_wgrad_h(d).nsplit * per;
     if (rows_applicable(d)) n = std::max(n, (size_t)plan_rows(d).nsplit * per);
+    if (rows8_applicable(d)) n = std::max(n, (size_t)plan_rows8(d).nsplit * per);
     return n;
 }
 
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s) {
     check_desc_h(d);
+    if (rows8_applicable(d)) {
+        const RowsPlan rp = plan_rows8(d);
+        WgradRowsArgs r{};
+        r.x = x; r.dy = dy; r.ws = ws;
+        r.B = d.B; r.H = d.Ho; r.W = d.Wo; r.Ci = d.Ci; r.Co = d.Co; r.pad_h = d.pad_h;
+        r.CT = rp.CT; r.NT = rp.NT; r.nslots = rp.nslots; r.schunk = rp.schunk; r.nsplit = rp.nsplit;
+        const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+        const char* label = "conv_wgrad_bf16_rows8_128x128";
+        if (rows8_mode() == 2) launch_wgrad_rows8<2>(r, label, fl, by, s);
+        else if (rows8_mode() == 4) launch_wgrad_rows8<4>(r, label, fl, by, s);
+        else launch_wgrad_rows8<3>(r, label, fl, by, s);
+        wgrad_reduce(ws, rp.nsplit, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+        return;
+    }
     if (rows_applicable(d)) {
         const RowsPlan rp = plan_rows(d);
         WgradRowsArgs r{};
