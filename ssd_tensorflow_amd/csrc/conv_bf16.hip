@@ -21,8 +21,8 @@
 // (data gradient; the arena's own HWIO order).
 #include "conv.h"
 #include "conv_detail.h"
-#ifndef WGRAD_ABL
-#define WGRAD_ABL 0
+#ifndef GATHER_PF
+#define GATHER_PF 2
 #endif
 #include "bf16.h"
 #include <algorithm>
@@ -254,28 +254,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 
     auto compute = [&](int stage) {
         const unsigned char* S = smem + stage * STAGE;
-        // fragments of k-step st+1 are read while the MFMAs of step st run (two register sets)
-        bf16x8 a[2][TM], b[2][TN];
+        // fragments of k-steps st+1 .. st+PF-1 are read while the MFMAs of step st run (PF register sets)
+        constexpr int PF = GATHER_PF, KS = HBK / 16;
+        bf16x8 a[PF][TM], b[PF][TN];
         auto frags = [&](int st) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
-                a[st & 1][mi] = *reinterpret_cast<const bf16x8*>(S + ((a_row + mi * 4096) ^ (st * 32)));
+                a[st % PF][mi] = *reinterpret_cast<const bf16x8*>(S + ((a_row + mi * 4096) ^ (st * 32)));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                b[st & 1][ni] = *reinterpret_cast<const bf16x8*>(S + ((b_row + ni * 4096) ^ (st * 32)));
+                b[st % PF][ni] = *reinterpret_cast<const bf16x8*>(S + ((b_row + ni * 4096) ^ (st * 32)));
         };
-        frags(0);
 #pragma unroll
-        for (int st = 0; st < HBK / 16; ++st) {
-            if (st + 1 < HBK / 16) frags(st + 1);
-            // keep the order written here: left alone, the scheduler folds both register sets into one and every
+        for (int st = 0; st < PF - 1 && st < KS; ++st) frags(st);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            if (st + PF - 1 < KS) frags(st + PF - 1);
+            // keep the order written here: left alone, the scheduler folds the register sets into one and every
             // k-step then starts parked on its own LDS reads (SQ_WAIT_ANY was 34 % of the wave cycles)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[st & 1][ni], a[st & 1][mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[st % PF][ni], a[st % PF][mi], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -324,44 +326,50 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
     const int m0 = mt * BM, n0 = nt * BN;
     const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
 
+    // DMA addressing with (almost) no vector arithmetic in the loop: the per-thread part of every offset is a constant
+    // VGPR, what changes from unit to unit (pixel base, tap, channel chunk) goes into the instruction's SCALAR offset.
+    // The scalar part must not be negative, so the activation descriptor starts `bias` bytes before the tensor (the
+    // first tile's halo reaches that far back); nothing is fetched from there, rows outside the tensor are steered to
+    // the out-of-range offset.  SC is a multiple of 64 here (host check): no channel-chunk mask.
+    const int total = (p.M / (p.DH * p.DW)) * p.SH * p.SW;
+    const int bias_px = dil + dil * p.SW;
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 2u), 0x00020000);
+        const_cast<bf16_t*>(p.src) - (size_t)bias_px * p.SC, 0, (unsigned)(((size_t)total + bias_px) * p.SC * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.DN * p.SC * 2u), 0x00020000);
-    unsigned b_off[B_N], b_ok[B_N];
+    unsigned a_vo[A_N], b_vo[B_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        a_vo[i] = r < BM + 2 * dil ? (unsigned)((r * p.SC + a_ck) * 2) : OOBH;       // rows past the halo are never read
+    }
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;
-        b_ok[i] = 0u - (unsigned)(n < p.DN);
-        b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.SC + a_ck) * 2u;
+        b_vo[i] = n < p.DN ? (unsigned)((n * p.SC + a_ck) * 2) : OOBH;
     }
-    const int nchunks = (p.SC + HBK - 1) / HBK;
+    const int nchunks = p.SC / HBK;
     const int nunits = nchunks * 3;
 
     auto issue = [&](int unit) {
         const int cc = unit / 3, kr = unit - cc * 3;
         unsigned char* As = smem + wave * 1024;
         unsigned char* Bs = smem + A_BYTES + wave * 1024;
-        const unsigned cmask = 0u - (unsigned)(cc * HBK + a_ck < p.SC);
         // tile row r = source pixel (m0 - dil + r), shifted by the kernel row: consecutive pixels of the NHWC tensor
         const int pix0 = m0 - dil + p.tap_dh[kr * 3] * p.SW;
-        const int total = (p.M / (p.DH * p.DW)) * p.SH * p.SW;
+        const int a_so = ((pix0 + bias_px) * p.SC + cc * HBK) * 2;
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
-            const int r = (tid >> 3) + 32 * i;
-            const int px = pix0 + r;
-            const unsigned m = cmask & (0u - (unsigned)((unsigned)px < (unsigned)total && r < BM + 2 * dil));
-            const unsigned off = (unsigned)((px * p.SC + cc * HBK + a_ck) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)((off & m) | (OOBH & ~m)), 0, 0, 0);
+            const int px = pix0 + (tid >> 3) + 32 * i;
+            const unsigned vo = (unsigned)px < (unsigned)total ? a_vo[i] : OOBH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)vo, a_so, 0, 0);
         }
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc) {
-            const unsigned woff = (unsigned)(((kr * 3 + kc) * p.DN * p.SC + cc * HBK) * 2);
+            const int b_so = ((kr * 3 + kc) * p.DN * p.SC + cc * HBK) * 2;
 #pragma unroll
-            for (int i = 0; i < B_N; ++i) {
-                const unsigned m = cmask & b_ok[i];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + kc * (BN * 128) + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOBH & ~m)), 0, 0, 0);
-            }
+            for (int i = 0; i < B_N; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + kc * (BN * 128) + i * 4096), 16, (int)b_vo[i], b_so, 0, 0);
         }
     };
 
@@ -408,30 +416,34 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
         issue(unit);
         wait_tiles_and_sync<1>(0);
         const int kr = unit % 3;
+        // 12 k-steps (3 taps x 4): fragments of the next PF-1 steps are in flight while a step multiplies
+        constexpr int PF = GATHER_PF, KS = 3 * (HBK / 16);
+        i32x4 a[PF][TM];
+        bf16x8 b[PF][TN];
+        auto frags = [&](int ks) {
+            const int kc = ks >> 2, st = ks & 3;
 #pragma unroll
-        for (int kc = 0; kc < 3; ++kc) {
-            const int t = kr * 3 + kc;
-            bool ok[TM];
+            for (int mi = 0; mi < TM; ++mi) a[ks % PF][mi] = *reinterpret_cast<const i32x4*>(smem + (a_addr[kc][mi] ^ (st * 32)));
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) ok[mi] = (fmsk[mi] >> t) & 1u;
+            for (int ni = 0; ni < TN; ++ni)
+                b[ks % PF][ni] = *reinterpret_cast<const bf16x8*>(smem + kc * (BN * 128) + ((b_row + ni * 4096) ^ (st * 32)));
+        };
 #pragma unroll
-            for (int st = 0; st < HBK / 16; ++st) {
-                i32x4 a[TM];
-                bf16x8 b[TN];
+        for (int ks = 0; ks < PF - 1; ++ks) frags(ks);
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    a[mi] = *reinterpret_cast<const i32x4*>(smem + (a_addr[kc][mi] ^ (st * 32)));
-                    a[mi] = ok[mi] ? a[mi] : i32x4{0, 0, 0, 0};
-                }
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF - 1 < KS) frags(ks + PF - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int t = kr * 3 + (ks >> 2);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                i32x4 am = a[ks % PF][mi];
+                am = ((fmsk[mi] >> t) & 1u) ? am : i32x4{0, 0, 0, 0};      // (a wave-uniform skip of the 4 v_cndmask measured -5 %: the branch breaks the MFMA stream)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    b[ni] = *reinterpret_cast<const bf16x8*>(smem + kc * (BN * 128) + ((b_row + ni * 4096) ^ (st * 32)));
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], __builtin_bit_cast(bf16x8, a[mi]), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks % PF][ni], __builtin_bit_cast(bf16x8, am), acc[mi][ni], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -483,11 +495,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     const int mend = min(p.M, mbeg + p.mchunk);
     const int niter = (mend - mbeg + BP - 1) / BP;
     const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
-#if WGRAD_ABL == 1
-    const bool do_bias = false;
-#else
     const bool do_bias = (tap == 0 && ct == 0);
-#endif
 
     // chunk swizzle of a pixel row r: rows of 256 or 512 bytes p ^ 4*(r&3); 128-byte rows p ^ 4*((r>>1)&1)
     auto swz = [](int r, int cpr) { return cpr >= 16 ? (r & 3) * 4 : ((r >> 1) & 1) * 4; };
@@ -640,23 +648,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     for (int it = 0; it < niter; ++it) {
         const int later = niter - 1 - it;
         wait_tiles_and_sync<X_N + Y_N>(later < NS - 2 ? later : NS - 2);
-#if WGRAD_ABL == 3
-        if (it + NS - 1 < niter && it < 1) issue(it + NS - 1, st_i);
-#else
         if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
-#endif
-#if WGRAD_ABL != 4
         compute(st_c);
-#endif
         st_c = st_c + 1 == NS ? 0 : st_c + 1;
         st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
 
     const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
     float* slab = p.ws + (size_t)split * (wcount + p.Co);
-#if WGRAD_ABL == 2
-    if (p.M < 0)
-#endif
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -1270,8 +1269,9 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
 static bool gather_rows_applicable(const ConvDesc& d, bool dgrad) {
     static const int on = env_int("SSD_GATHER_ROWS_BF16", 1);
     if (on == 1 && dgrad && d.dil != 1) return false;
-    return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.dil >= 1 && d.dil <= 8 && d.pad_h == d.dil &&
-           d.pad_w == d.dil;
+    const int sc = dgrad ? d.Co : d.Ci;            // channels of the gathered tensor: whole 64-channel chunks only
+    return on && sc % 64 == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.dil >= 1 && d.dil <= 8 &&
+           d.pad_h == d.dil && d.pad_w == d.dil;
 }
 template <int MODE>
 static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, double flops, double bytes, hipStream_t s) {
