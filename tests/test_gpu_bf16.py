@@ -66,6 +66,9 @@ CONV_CASES = [
     ('head 4 types N=104 f32 out', 2, 38, 38, 512, 104, 3, 1, 1, 'SAME', False, True),
     ('ragged M, 1 image', 1, 13, 7, 128, 128, 3, 1, 1, 'SAME', True, False),
     ('wide rows 70x70 (incremental pixel walk)', 1, 70, 70, 64, 128, 3, 1, 1, 'SAME', True, False),
+    # the 8-wave kernel-row weight gradient: several ragged pixel splits; channel tiles that are not whole (192 = 128 + 64, 136 = 128 + 8)
+    ('rows8 wgrad 5 ragged splits 128->128', 2, 40, 33, 128, 128, 3, 1, 1, 'SAME', True, False),
+    ('rows8 wgrad partial tiles 192->136', 1, 9, 11, 192, 136, 3, 1, 1, 'SAME', True, False),
 ]
 
 
