@@ -65,6 +65,8 @@ for name, hw, ci, co, k, s, d in LAYERS:
     ph, pw, ho, wo = conv_geom(hw, hw, k, s, d, 'SAME')
     x = torch.randn((B, hw, hw, ci), device='cuda'); w = torch.randn((k, k, ci, co), device='cuda') * 0.05
     bias = torch.zeros(co, device='cuda'); y = torch.empty((B, ho, wo, co), device='cuda'); dy = torch.randn_like(y)
+    if os.environ.get('SSD_BENCH_ZERO') == '1':
+        x.zero_(); w.zero_(); dy.zero_()
     dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(bias)
     geom = (B, hw, hw, ci, ho, wo, co, k, k, s, d, ph, pw)
     ws = torch.empty((lib.ssd_op_conv2d_wgrad_ws_floats(*geom),), device='cuda')
