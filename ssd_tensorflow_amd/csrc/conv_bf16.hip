@@ -70,36 +70,44 @@ __device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
 // Epilogue of both gather kernels, through an fp32 LDS tile [BM][BN + 4]: full-line loads / stores, fused bias + relu
 // (forward) or accumulate + relu mask (data gradient), ONE rounding to bf16.  The caller has passed a barrier after its
 // last LDS read.
-template <int MODE, int WM, int WN, int TM, int TN>
+// HALVES = 2: the C tile holds half of every wave's rows at a time (a 256-row tile through 66 KB of LDS);
+// rows_valid: tile rows that belong to this workgroup (the kernel-row 256-pixel tile owns 256 - 2 dil of its rows).
+template <int MODE, int WM, int WN, int TM, int TN, int HALVES = 1>
 __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned char* smem, const f32x16 (&acc)[TM][TN], int tid, int wm,
-                                                int wn, int li, int lh, int m0, int n0) {
-    constexpr int NTHR = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, LDC = BN + 4;
+                                                int wn, int li, int lh, int m0, int n0, int rows_valid = 32 * TM * WM) {
+    constexpr int NTHR = 64 * WM * WN, TMH = TM / HALVES, BMH = 32 * TMH * WM, BN = 32 * TN * WN, LDC = BN + 4;
+    static_assert(TM % HALVES == 0, "whole accumulator tiles per pass");
     float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ml = wm * 32 * TM + mi * 32 + li;
-                const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
-                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) =
-                    f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-            }
-    __syncthreads();
     constexpr int TPR = BN / 8;               // threads per row, 8 channels each
     constexpr int RPP = NTHR / TPR;           // rows per pass
     const int cg = tid % TPR, r0 = tid / TPR;
     const int n = n0 + cg * 8;
-    if (n >= p.DN) return;
+    const bool ncol = n < p.DN;
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias) ? p.bias[n + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias && ncol) ? p.bias[n + e] : 0.f;
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    if (h) __syncthreads();                   // the previous pass has been read out
+#pragma unroll
+    for (int mi = 0; mi < TMH; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ml = wm * 32 * TMH + mi * 32 + li;
+                const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
+                const f32x16& c = acc[h * TMH + mi][ni];
+                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+            }
+    __syncthreads();
 #pragma unroll 2
-    for (int ps = 0; ps < BM / RPP; ++ps) {
+    for (int ps = 0; ps < BMH / RPP; ++ps) {
         const int ml = r0 + ps * RPP;
-        const int m = m0 + ml;
-        if (m >= p.M) break;
+        // C-tile row -> tile row: wave row block ml / (32 TMH), pass h inside the wave's 32 TM rows
+        const int tr = HALVES == 1 ? ml : (ml / (32 * TMH)) * (32 * TM) + h * (32 * TMH) + ml % (32 * TMH);
+        const int m = m0 + tr;
+        if (!ncol || tr >= rows_valid || m >= p.M) continue;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
         float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -137,6 +145,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                 u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
         }
     }
+  }
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS>
@@ -311,11 +320,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 // looking at image geometry; what is not a neighbour (next image row, padding) is zeroed per lane when the operand is
 // read (4 v_cndmask per fragment), from the same 9-bit tap masks the per-tap kernel uses for its DMA.
 // =================================================================================
-template <int MODE>
+// TM = 4: 256-row tiles.  What a wave pays per DMA piece (60..185 cycles of its own issue time) is the same for every
+// tile, so pieces per MFMA is the figure of merit: 17 per 48 MFMAs and wave with 128 rows, 20 per 96 with 256.  The
+// activation tile is then exactly 256 rows = 32 KB, i.e. a workgroup owns 256 - 2 dil - 1 output pixels (halo + the empty row), so that two workgroups still fit a CU (2 x 80 KB); the fp32 epilogue tile goes through
+// LDS in two halves.  Used where the tiles fill the chip at least twice (conv2_2, conv3_x).
+template <int MODE, int TM>
 __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH p, int dil) {
-    constexpr int WM = 2, WN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
-    constexpr int AROWS = 160;                         // 128 + 2 * dil rows, in whole 32-row staging passes
+    constexpr int WM = 2, WN = 2, TN = 2, BM = 64 * TM, BN = 128;
+    constexpr int AROWS = TM == 2 ? 160 : 256;         // 128 + 2 * dil rows in whole 32-row staging passes | 256 rows = 253 + 2 (dil = 1) + 1 empty
     constexpr int A_N = AROWS / 32, B_N = BN / 32;
+    constexpr int ZROW = (AROWS - 1) * 128;            // a tile row that is always zero (past the halo)
+    static_assert(TM == 2 || TM == 4, "128- or 256-row tiles");
     constexpr int A_BYTES = AROWS * 128, UNIT = A_BYTES + 3 * BN * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -323,7 +338,8 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int bmv = TM == 2 ? BM : AROWS - 2 * dil - 1;    // output pixels this workgroup owns (the tile's last row stays empty, see ZROW)
+    const int m0 = mt * bmv, n0 = nt * BN;
     const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
 
     // DMA addressing with (almost) no vector arithmetic in the loop: the per-thread part of every offset is a constant
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int r = (tid >> 3) + 32 * i;
-        a_vo[i] = r < BM + 2 * dil ? (unsigned)((r * p.SC + a_ck) * 2) : OOBH;       // rows past the halo are never read
+        a_vo[i] = r < bmv + 2 * dil ? (unsigned)((r * p.SC + a_ck) * 2) : OOBH;      // rows past the halo: zero-filled, the last one serves as ZROW
     }
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
             const int sh = oh + p.tap_dh[t], sw = ow + p.tap_dw[t];
             if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
         }
-        fmsk[mi] = m < p.M ? mk : 0u;
+        fmsk[mi] = (m < p.M && wm * 32 * TM + mi * 32 + li < bmv) ? mk : 0u;
     }
     // fragment addresses: tile row R = (row of the pixel) + tap_dw + dil; slot (2 st + lh) ^ ((R>>1)&7)
     int a_addr[3][TM];
@@ -416,14 +432,22 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
         issue(unit);
         wait_tiles_and_sync<1>(0);
         const int kr = unit % 3;
+        // Zero padding without touching the operands: a lane whose pixel has no neighbour under tap (kr, kc) reads the
+        // tile's LAST row instead, which no pixel maps to and the DMA zero-fills with every unit (its offset is out of
+        // range).  One address select per fragment and tap replaces 4 v_cndmask per fragment and k-step; the lanes that
+        // share the empty row broadcast.  (The k-step XOR moves inside that 128-byte row.)
+        int ua[3][TM];
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) ua[kc][mi] = ((fmsk[mi] >> (kr * 3 + kc)) & 1u) ? a_addr[kc][mi] : ZROW;
         // 12 k-steps (3 taps x 4): fragments of the next PF-1 steps are in flight while a step multiplies
         constexpr int PF = GATHER_PF, KS = 3 * (HBK / 16);
-        i32x4 a[PF][TM];
-        bf16x8 b[PF][TN];
+        bf16x8 a[PF][TM], b[PF][TN];
         auto frags = [&](int ks) {
             const int kc = ks >> 2, st = ks & 3;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) a[ks % PF][mi] = *reinterpret_cast<const i32x4*>(smem + (a_addr[kc][mi] ^ (st * 32)));
+            for (int mi = 0; mi < TM; ++mi) a[ks % PF][mi] = *reinterpret_cast<const bf16x8*>(smem + (ua[kc][mi] ^ (st * 32)));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
                 b[ks % PF][ni] = *reinterpret_cast<const bf16x8*>(smem + kc * (BN * 128) + ((b_row + ni * 4096) ^ (st * 32)));
@@ -434,20 +458,16 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + PF - 1 < KS) frags(ks + PF - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int t = kr * 3 + (ks >> 2);
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                i32x4 am = a[ks % PF][mi];
-                am = ((fmsk[mi] >> t) & 1u) ? am : i32x4{0, 0, 0, 0};      // (a wave-uniform skip of the 4 v_cndmask measured -5 %: the branch breaks the MFMA stream)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks % PF][ni], __builtin_bit_cast(bf16x8, am), acc[mi][ni], 0, 0, 0);
-            }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks % PF][ni], a[ks % PF][mi], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
-    gather_epilogue<MODE, WM, WN, TM, TN>(p, smem, acc, tid, wm, wn, li, lh, m0, n0);
+    gather_epilogue<MODE, WM, WN, TM, TN, TM / 2>(p, smem, acc, tid, wm, wn, li, lh, m0, n0, bmv);
 }
 
 // =================================================================================
@@ -1273,17 +1293,23 @@ static bool gather_rows_applicable(const ConvDesc& d, bool dgrad) {
     return on && sc % 64 == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.dil >= 1 && d.dil <= 8 &&
            d.pad_h == d.dil && d.pad_w == d.dil;
 }
-template <int MODE>
+template <int MODE, int TM>
 static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, double flops, double bytes, hipStream_t s) {
-    constexpr size_t unit = 160 * 128 + 3 * 128 * 128, ctile = (size_t)128 * 132 * 4;
+    constexpr size_t unit = (TM == 2 ? 160 : 256) * 128 + 3 * 128 * 128, ctile = (size_t)128 * 132 * 4;
     constexpr size_t lds = unit > ctile ? unit : ctile;
-    auto kern = conv_gather_bf16_rows_kernel<MODE>;
+    auto kern = conv_gather_bf16_rows_kernel<MODE, TM>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     a.NT = cdiv(a.DN, 128);
+    const int bmv = TM == 2 ? 128 : 256 - 2 * dil - 1;
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 128) * a.NT), dim3(256), lds, s, a, dil);
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, bmv) * a.NT), dim3(256), lds, s, a, dil);
     HIP_OK(hipGetLastError());
+}
+// 256-row tiles where they fill the chip (512 workgroup slots) at least twice; dil = 1 only (the tile owns 256 - 2 dil rows)
+static bool gather_rows256(const ConvDesc& d, int M, int N) {
+    static const int on = env_int("SSD_GATHER_ROWS256_BF16", 1);      // A/B switch; 2 = every eligible layer (tests)
+    return on && d.dil == 1 && (on == 2 || cdiv(M, 253) * cdiv(N, 128) >= 1024);
 }
 
 void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
@@ -1302,7 +1328,8 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
         }
     const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
     if (gather_rows_applicable(d, false) && d.Co >= 128) {
-        launch_gather_rows<MODE_FWD>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
+        if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
+        else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
         return;
     }
     launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD), a, fl, by, s);
@@ -1328,7 +1355,8 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
         return;
     }
     if (gather_rows_applicable(d, true) && d.Ci >= 128) {
-        launch_gather_rows<MODE_DGRAD>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
+        if (gather_rows256(d, a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 4>(a, d.dil, "conv_dgrad_bf16_rows_256x128", fl, by, s);
+        else launch_gather_rows<MODE_DGRAD, 2>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
         return;
     }
     launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD), a, fl, by, s);

@@ -162,6 +162,21 @@ def test_conv_bf16_full_size_layer():
     assert max_rel(bhost(gx_), xt.grad.permute(0, 2, 3, 1).numpy()) < TOL_BF
 
 
+
+def test_conv_bf16_256_row_tiles_forced():
+    """The 256-row kernel-row gather is picked only where its tiles fill the chip twice (batch-32 conv2_2 / conv3_x);
+    SSD_GATHER_ROWS256_BF16=2 selects it for every eligible layer.  The library reads the switch once per process:
+    the same conv cases run again in a child process with it set."""
+    import os, subprocess, sys
+    if os.environ.get('SSD_GATHER_ROWS256_BF16') == '2':
+        pytest.skip('already the forced configuration')
+    env = dict(os.environ, SSD_GATHER_ROWS256_BF16='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_conv_bf16_fwd_dgrad_wgrad',
+                        '-p', 'no:cacheprovider'], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 FIRST_CASES = [('conv1_1 37x41 b2', 2, 37, 41), ('conv1_1 300x300 b1', 1, 300, 300), ('conv1_1 5x3 b3', 3, 5, 3),
                ('conv1_1 64x64 b2 (whole tiles)', 2, 64, 64)]
 

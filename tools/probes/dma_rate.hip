@@ -21,14 +21,17 @@ __device__ __forceinline__ void wait_keep(int keep_stages) {      // leave keep_
 }
 
 // MODE 0: buffer_load_dwordx4 ... lds     MODE 1: buffer_load_dwordx4 to VGPRs (xor-folded so they are not dead)
-template <int MODE, int P>
+// SEG: contiguous bytes per tile row inside a piece (1024 = fully contiguous piece; 128 / 64 = conv tile rows at a 1-KB pitch)
+template <int MODE, int P, int SEG = 1024>
 __global__ void stream_kernel(const char* src, unsigned span, int iters, int depth, unsigned long long* clk, int* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nw = blockDim.x >> 6;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, span, 0x00020000);
     // every wave walks its own 1-KiB pieces through the span; workgroups start at different places
-    unsigned off = (unsigned)(((blockIdx.x * nw + wave) * P * 1024u * 7u) % span) + lane * 16u;
+    constexpr unsigned LPR = SEG / 16;                      // lanes per row
+    const unsigned lane_off = SEG == 1024 ? lane * 16u : (lane / LPR) * 1024u + (lane % LPR) * 16u;      // row pitch 1 KB
+    unsigned off = (unsigned)(((blockIdx.x * nw + wave) * P * 1024u * 7u) % span) + lane_off;
     const unsigned step = (unsigned)(nw * P * 1024u * 13u) % span;
     i32x4 fold = {0, 0, 0, 0};
     __syncthreads();
@@ -37,7 +40,7 @@ __global__ void stream_kernel(const char* src, unsigned span, int iters, int dep
         unsigned char* stage = smem + (it % (depth + 1)) * (nw * P * 1024) + wave * P * 1024;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            unsigned o = off + j * 1024u;
+            unsigned o = off + j * (SEG == 1024 ? 1024u : SEG);          // strided mode: the next piece takes the next SEG bytes of the same rows
             o -= o >= span ? span : 0u;
             if (MODE == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(stage + j * 1024), 16, (int)o, 0, 0, 0);
             else {
@@ -60,12 +63,12 @@ __global__ void stream_kernel(const char* src, unsigned span, int iters, int dep
     if (MODE == 1 && (fold[0] ^ fold[1] ^ fold[2] ^ fold[3]) == 0x12345678) sink[0] = 1;
 }
 
-template <int MODE, int P>
+template <int MODE, int P, int SEG = 1024>
 static void run(const char* src, unsigned span, int grid, int waves, int depth, unsigned long long* dclk, int* sink) {
     const int iters = 400;
     const size_t lds = (size_t)(depth + 1) * waves * P * 1024;
     if (lds > 160 * 1024) return;
-    auto k = stream_kernel<MODE, P>;
+    auto k = stream_kernel<MODE, P, SEG>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // pad the LDS request so that exactly one workgroup fits a CU: `grid` workgroups = `grid` CUs (up to 256), 512 = two rounds
     const size_t lds_req = std::max(lds, (size_t)96 * 1024);
@@ -86,7 +89,7 @@ static void run(const char* src, unsigned span, int grid, int waves, int depth, 
     // s_memtime / readcyclecounter tick = 100 MHz constant clock on gfx9: convert with the event time instead
     const int cus = std::min(grid, 256), rounds = (grid + 255) / 256;
     const double gbs_cu = bytes * rounds / (ms * 1e-3) / 1e9;                 // per CU
-    printf("%-5s P=%d grid=%3d waves=%d depth=%d  %8.3f ms  %7.1f GB/s/CU  %6.1f B/clk/CU@2.4GHz  chip %6.2f TB/s\n", MODE ? "vgpr" : "lds", P, grid,
+    printf("seg=%4d %-5s P=%d grid=%3d waves=%d depth=%d  %8.3f ms  %7.1f GB/s/CU  %6.1f B/clk/CU@2.4GHz  chip %6.2f TB/s\n", SEG, MODE ? "vgpr" : "lds", P, grid,
            waves, depth, ms, gbs_cu, gbs_cu / 2.4, gbs_cu * cus / 1e3);
 }
 
@@ -108,5 +111,12 @@ int main() {
         for (int waves : {4, 8, 16}) run<1, 4>(src, span, grid, waves, 0, dclk, sink);
     for (int grid : {32, 256})
         for (int waves : {4, 8}) run<1, 8>(src, span, grid, waves, 0, dclk, sink);
+    // conv-tile shaped pieces: 8 rows x 128 B and 16 rows x 64 B per 1-KB piece, rows 1 KB apart
+    for (int waves : {4, 8}) {
+        run<0, 4, 128>(src, span, 256, waves, 1, dclk, sink);
+        run<0, 4, 64>(src, span, 256, waves, 1, dclk, sink);
+        run<0, 8, 128>(src, span, 256, waves, 1, dclk, sink);
+        run<0, 8, 64>(src, span, 256, waves, 1, dclk, sink);
+    }
     return 0;
 }
