@@ -471,6 +471,168 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 }
 
 // =================================================================================
+// 64 -> 64 channels, 3x3, stride 1 (conv1_2, forward and data gradient): a PERSISTENT kernel with the whole filter
+// resident in LDS.  With K = 64 per tap and N = 64 the per-tap kernel stages 40 KB per 8 MFMAs per wave (it needs
+// 80 B/clk of LDS-DMA, the CU delivers ~55) and a workgroup lives for 9 iterations, each a full DMA round trip.
+// Here one 8-wave workgroup per CU loads the 9 x 64 x 64 filter once (72 KB), then walks its share of the pixel tiles:
+// per kernel row ONE 256-row activation tile (253 pixels + halo + the always-empty row 255, see ZROW above), double
+// buffered, feeds three taps: 32 KB per 24 MFMAs per wave = 21 B/clk, 4 pieces per wave and unit, no filter traffic.
+// Wave w owns pixel rows 32 w .. 32 w + 31 of the tile x all 64 channels (2 accumulator tiles); the results leave
+// straight from the accumulators (4 consecutive channels of one pixel per register quad = one 8-byte store).
+// =================================================================================
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles) {
+    constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
+    constexpr int ZROW = (AROWS - 1) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+
+    const int total = (p.M / (p.DH * p.DW)) * p.SH * p.SW;
+    const int bias_px = 1 + p.SW;
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.src) - (size_t)bias_px * 64, 0, (unsigned)(((size_t)total + bias_px) * 64 * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.wgt), 0, (unsigned)(9u * 64u * 64u * 2u), 0x00020000);
+
+    // ---- the filter, once: tap t = rows [64 n][64 k] of 128 bytes, one 1-KB piece per wave and tap
+    {
+        const unsigned vo = (unsigned)(((tid >> 3) * 64 + a_ck) * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(smem + t * B_TAP + wave * 1024), 16, (int)vo, t * (64 * 64 * 2), 0, 0);
+    }
+    unsigned a_vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + 64 * i;
+        a_vo[i] = r < AROWS - 1 ? (unsigned)((r * 64 + a_ck) * 2) : OOBH;          // row 255 stays empty
+    }
+    // unit = (tile, kernel row); its activation tile: row r = pixel m0 - 1 + r of the image row shifted by the kernel row
+    auto issue = [&](int tile, int kr, int buf) {
+        unsigned char* As = smem + A_BASE + buf * A_BYTES + wave * 1024;
+        const int pix0 = tile * BMV - 1 + p.tap_dh[kr * 3] * p.SW;
+        const int a_so = (pix0 + bias_px) * (64 * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = pix0 + (tid >> 3) + 64 * i;
+            const unsigned vo = (unsigned)px < (unsigned)total ? a_vo[i] : OOBH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 8192), 16, (int)vo, a_so, 0, 0);
+        }
+    };
+
+    // fragment addresses: activation row R = 32 wave + li + tap_dw + 1; filter rows n = 32 ni + li
+    int a_addr[3], b_addr[2];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+        const int R = wave * 32 + li + p.tap_dw[kc] + 1;
+        a_addr[kc] = R * 128 + ((lh ^ ((R >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = ni * 32 + li;
+        b_addr[ni] = n * 128 + ((lh ^ ((n >> 1) & 7)) * 16);
+    }
+    float bv[2][4][4];                                   // forward: bias of this lane's channels 32 ni + 8 g + 4 lh + e
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[ni][g][e] = (MODE == MODE_FWD && p.bias) ? p.bias[ni * 32 + 8 * g + 4 * lh + e] : 0.f;
+
+    int tile = blockIdx.x, gunit = 0;
+    if (tile < ntiles) issue(tile, 0, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BMV;
+        const int rr = wave * 32 + li, m = m0 + rr;
+        unsigned fmsk = 0;
+        if (rr < BMV && m < p.M) {
+            const int ow = m % p.DW, oh = (m / p.DW) % p.DH;
+            for (int t = 0; t < 9; ++t) {
+                const int sh = oh + p.tap_dh[t], sw = ow + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) fmsk |= 1u << t;
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+
+        // data gradient: the relu mask / the values to accumulate onto are fetched while the last kernel row multiplies
+        // (one workgroup per CU: nothing else would hide that round trip)
+        u32x2 pre_mask[2][4], pre_old[2][4];
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr, ++gunit) {
+            wait_tiles_and_sync<1>(0);                    // this unit's tile (and, the first time, the filter) has landed
+            if (MODE == MODE_DGRAD && kr == 2 && rr < BMV && m < p.M) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const size_t o = (size_t)m * 64 + ni * 32 + 8 * g + 4 * lh;
+                        if (p.mask) pre_mask[ni][g] = *reinterpret_cast<const u32x2*>(p.mask + o);
+                        if (p.accum) pre_old[ni][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
+                    }
+            }
+            if (kr < 2) issue(tile, kr + 1, (gunit + 1) & 1);
+            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0, (gunit + 1) & 1);
+            const unsigned char* A = smem + A_BASE + (gunit & 1) * A_BYTES;
+            int ua[3];
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) ua[kc] = ((fmsk >> (kr * 3 + kc)) & 1u) ? a_addr[kc] : ZROW;
+            bf16x8 a[2], b[2][2];
+            auto frags = [&](int ks) {                   // k-step ks: tap column ks >> 2, 16-channel slice ks & 3
+                const int kc = ks >> 2, st = ks & 3;
+                a[ks & 1] = *reinterpret_cast<const bf16x8*>(A + (ua[kc] ^ (st * 32)));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    b[ks & 1][ni] = *reinterpret_cast<const bf16x8*>(smem + (kr * 3 + kc) * B_TAP + (b_addr[ni] ^ (st * 32)));
+            };
+            frags(0);
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                if (ks + 1 < 12) frags(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][ni], a[ks & 1], acc[ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- results: pixel m, channels 32 ni + 8 g + 4 lh + (0..3)
+        if (rr < BMV && m < p.M) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
+                    const size_t o = (size_t)m * 64 + ni * 32 + 8 * g + 4 * lh;
+                    if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += bv[ni][g][e];
+                            if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                    } else {
+                        if (p.accum) {
+                            const u32x2 old = pre_old[ni][g];
+                            v[0] += lo2f(old[0]); v[1] += hi2f(old[0]); v[2] += lo2f(old[1]); v[3] += hi2f(old[1]);
+                        }
+                        if (p.mask) {
+                            const u32x2 y = pre_mask[ni][g];
+                            v[0] = lo2f(y[0]) > 0.f ? v[0] : 0.f; v[1] = hi2f(y[0]) > 0.f ? v[1] : 0.f;
+                            v[2] = lo2f(y[1]) > 0.f ? v[2] : 0.f; v[3] = hi2f(y[1]) > 0.f ? v[3] : 0.f;
+                        }
+                    }
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.dst) + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                }
+        }
+    }
+}
+
+// =================================================================================
 // weight gradient:  dW[(tap, c)][n] = sum_m x[pix(m, tap)][c] * dy[m][n]      (fp32 slabs, split-M)
 // One workgroup owns (tap, channel tile, n tile, pixel split); 64 pixels per iteration.  Both
 // tiles keep their global pixel-major rows in LDS; ds_read_b64_tr_b16 transposes on the way out.
@@ -1293,6 +1455,25 @@ static bool gather_rows_applicable(const ConvDesc& d, bool dgrad) {
     return on && sc % 64 == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.dil >= 1 && d.dil <= 8 &&
            d.pad_h == d.dil && d.pad_w == d.dil;
 }
+// conv1_2-shaped layers (64 -> 64, 3x3, stride 1, SAME, bf16 out), large enough to give every CU several tiles
+static bool gather_c64_applicable(const ConvDesc& d, bool y_f32) {
+    static const int on = env_int("SSD_C64_BF16", 1);      // A/B switch; 2 = also small layers (tests)
+    const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo &&
+                       d.Ci == 64 && d.Co == 64 && !y_f32;
+    return on && shape && (on == 2 || (long long)d.B * d.Ho * d.Wo >= 253LL * 256 * 4);
+}
+template <int MODE>
+static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128;
+    auto kern = conv_gather_bf16_c64_kernel<MODE>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    const int ntiles = cdiv(a.M, 253);
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles);
+    HIP_OK(hipGetLastError());
+}
+
 template <int MODE, int TM>
 static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr size_t unit = (TM == 2 ? 160 : 256) * 128 + 3 * 128 * 128, ctile = (size_t)128 * 132 * 4;
@@ -1327,6 +1508,10 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
         }
     const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
+    if (gather_c64_applicable(d, y_f32)) {
+        launch_gather_c64<MODE_FWD>(a, "conv_fwd_bf16_c64", fl, by, s);
+        return;
+    }
     if (gather_rows_applicable(d, false) && d.Co >= 128) {
         if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
         else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
@@ -1352,6 +1537,10 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
     const double fl = conv_flops(d), by = 2.0 * (conv_elems(d) + (mask ? (double)d.B * d.Hi * d.Wi * d.Ci : 0.0));
     if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
         launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true, 2>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
+        return;
+    }
+    if (gather_c64_applicable(d, false)) {
+        launch_gather_c64<MODE_DGRAD>(a, "conv_dgrad_bf16_c64", fl, by, s);
         return;
     }
     if (gather_rows_applicable(d, true) && d.Ci >= 128) {

@@ -163,17 +163,18 @@ def test_conv_bf16_full_size_layer():
 
 
 
-def test_conv_bf16_256_row_tiles_forced():
-    """The 256-row kernel-row gather is picked only where its tiles fill the chip twice (batch-32 conv2_2 / conv3_x);
-    SSD_GATHER_ROWS256_BF16=2 selects it for every eligible layer.  The library reads the switch once per process:
-    the same conv cases run again in a child process with it set."""
+def test_conv_bf16_large_layer_kernels_forced():
+    """Two kernels are picked only at batch-32 sizes: the 256-row kernel-row gather (conv2_2 / conv3_x, where its tiles
+    fill the chip twice) and the persistent 64 -> 64 kernel with the resident filter (conv1_2, >= 4 tiles per CU).
+    SSD_GATHER_ROWS256_BF16=2 / SSD_C64_BF16=2 select them for every eligible layer.  The library reads the switches once
+    per process: the conv cases (and the full-size conv1_2 image) run again in a child process with them set."""
     import os, subprocess, sys
     if os.environ.get('SSD_GATHER_ROWS256_BF16') == '2':
         pytest.skip('already the forced configuration')
-    env = dict(os.environ, SSD_GATHER_ROWS256_BF16='2')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_conv_bf16_fwd_dgrad_wgrad',
-                        '-p', 'no:cacheprovider'], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, SSD_GATHER_ROWS256_BF16='2', SSD_C64_BF16='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
+                        'test_conv_bf16_fwd_dgrad_wgrad or test_conv_bf16_full_size_layer', '-p', 'no:cacheprovider'], env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
