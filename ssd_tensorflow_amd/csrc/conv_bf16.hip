@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
         unsigned char* Bs = smem + A_BYTES + wave * 1024;
         // tile row r = source pixel (m0 - dil + r), shifted by the kernel row: consecutive pixels of the NHWC tensor
         const int pix0 = m0 - dil + p.tap_dh[kr * 3] * p.SW;
-        const int a_so = ((pix0 + bias_px) * p.SC + cc * HBK) * 2;
+        const int a_so = (int)(((unsigned)(pix0 + bias_px) * (unsigned)p.SC + (unsigned)(cc * HBK)) * 2u);      // < 4 GB (size guard): unsigned arithmetic
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             const int px = pix0 + (tid >> 3) + 32 * i;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
         }
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc) {
-            const int b_so = ((kr * 3 + kc) * p.DN * p.SC + cc * HBK) * 2;
+            const int b_so = (int)(((unsigned)((kr * 3 + kc) * p.DN) * (unsigned)p.SC + (unsigned)(cc * HBK)) * 2u);
 #pragma unroll
             for (int i = 0; i < B_N; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + kc * (BN * 128) + i * 4096), 16, (int)b_vo[i], b_so, 0, 0);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
     auto issue = [&](int tile, int kr, int buf) {
         unsigned char* As = smem + A_BASE + buf * A_BYTES + wave * 1024;
         const int pix0 = tile * BMV - 1 + p.tap_dh[kr * 3] * p.SW;
-        const int a_so = (pix0 + bias_px) * (64 * 2);
+        const int a_so = (int)((unsigned)(pix0 + bias_px) * 128u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = pix0 + (tid >> 3) + 64 * i;
