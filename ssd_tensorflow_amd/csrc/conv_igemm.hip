@@ -1162,8 +1162,24 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     int want = cdiv(1536, p.tiles);
     if (want > 256) want = 256;          // the reduce pass reads every slab: keep it short
     int maxs = cdiv(M, 256);
-    p.nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);
-    if (p.nsplit < 1) p.nsplit = 1;
+    want = want < 1 ? 1 : (want > maxs ? maxs : want);
+    // Round quantisation: the grid runs in rounds of `slots` resident workgroups (LDS-limited: 2 per CU with
+    // 128x128 tiles, 3 with 128x64 / 64x128, 4 with 64x64).  Among the split counts near `want`, take the one
+    // whose last round is fullest (conv4_x at batch 32: 6 splits = 2.25 rounds -> 8 splits = 3.0 rounds).
+    static const int tune = env_int("SSD_WGRAD_ROUNDS", 1);      // A/B switch
+    if (tune && !p.smallc && p.tiles * want > 256) {
+        const int slots = 256 * (p.cfg == 0 ? 2 : (p.cfg == 1 ? 4 : 3));
+        int best = want;
+        double best_fill = 0.0;
+        const int lo = std::max(1, want - want / 3), hi = std::min(maxs, want + (want + 1) / 2);
+        for (int ns = lo; ns <= hi; ++ns) {
+            const int wgs = p.tiles * ns;
+            const double fill = (double)wgs / ((double)cdiv(wgs, slots) * slots);
+            if (fill > best_fill + 0.02) { best_fill = fill; best = ns; }
+        }
+        want = best;
+    }
+    p.nsplit = want;
     p.mchunk = cdiv(cdiv(M, p.nsplit), 32) * 32;
     p.nsplit = cdiv(M, p.mchunk);
     return p;
