@@ -385,8 +385,16 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
         }
         a_msk[i] = mk;
     }
+    // The tap / channel-chunk part of every offset is uniform: it goes into the DMA instruction's SCALAR offset and the
+    // per-lane part (a_off, b_off) stays a constant VGPR that is only swapped for the out-of-range value where the tap
+    // falls into the padding.  The scalar part must not be negative, so the activation descriptor starts `tap_bias`
+    // bytes before the tensor (the most negative tap offset); nothing is fetched from there.
+    int tap_min = 0;
+    for (int t = 0; t < p.ntaps; ++t) tap_min = min(tap_min, (p.tap_dh[t] * p.SW + p.tap_dw[t]) * p.SC);
+    const unsigned tap_bias = (unsigned)(-tap_min) * 4u;
+    const size_t src_bytes = (size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u;
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u), 0x00020000);
+        reinterpret_cast<char*>(const_cast<float*>(p.src)) - (STRIDED ? 0u : tap_bias), 0, (unsigned)(src_bytes + (STRIDED ? 0u : tap_bias)), 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.wci * p.wco * 4u), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -427,10 +435,11 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)((off & m) | (OOB & ~m)), 0, 0, 0);
             }
         } else {
+            const int a_so = (int)(toff + tap_bias);
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
-                const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)(((a_off[i] + toff) & m) | (OOB & ~m)), 0, 0, 0);
+                const bool ok = ((a_msk[i] >> tap) & 1u) != 0u && cmask != 0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)(ok ? a_off[i] : OOB), a_so, 0, 0);
             }
         }
         if constexpr (MODE == MODE_FWD) {
@@ -438,15 +447,15 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
                 const int kr = tid / B_CPR + B_RPP * i;
-                const unsigned m = b_ok[i] & (0u - (unsigned)(cc * BK + kr < p.SC));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOB & ~m)), 0, 0, 0);
+                const bool ok = b_ok[i] != 0u && cc * BK + kr < p.SC;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(ok ? b_off[i] : OOB), (int)woff, 0, 0);
             }
         } else {
             const unsigned woff = (unsigned)(tap * p.wci * p.wco + cc * BK) * 4u;
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
-                const unsigned m = b_ok[i] & cmask;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(((b_off[i] + woff) & m) | (OOB & ~m)), 0, 0, 0);
+                const bool ok = b_ok[i] != 0u && cmask != 0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(ok ? b_off[i] : OOB), (int)woff, 0, 0);
             }
         }
     };
