@@ -12,7 +12,7 @@ LAYERS = [('conv1_2', 300, 64, 64, 3, 1, 1), ('conv2_2', 150, 128, 128, 3, 1, 1)
           ('mod_conv7', 19, 1024, 1024, 1, 1, 1), ('head1', 19, 1024, 152, 3, 1, 1), ('head0', 38, 512, 100, 3, 1, 1)]
 only = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] != 'all' else None
 BF16 = len(sys.argv) > 2 and sys.argv[2] == 'bf16'
-B = 32
+B = int(os.environ.get("SSD_BENCH_B", "32"))      # batch (SSD_BENCH_B: quantisation / tail experiments)
 
 
 def bench_bf16(name, hw, ci, co, k, s, d):
