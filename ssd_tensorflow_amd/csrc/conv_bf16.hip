@@ -1619,8 +1619,9 @@ static RowsPlan plan_rows(const ConvDesc& d) {
     p.CT = cdiv(d.Ci, 64 * p.tm);
     p.NT = cdiv(d.Co, 64 * p.tn);
     p.nslots = (long long)d.B * d.Ho * (d.Wo + 2);
-    int want = cdiv(1024, 3 * p.CT * p.NT);
-    if (want > 256) want = 256;
+    static const int target = env_int("SSD_WGRAD_ROWS_WGS_BF16", 2048);      // tuning override (conv1_2: 768 workgroups 0.42 ms, >= 1024 0.38 ms)
+    int want = cdiv(target, 3 * p.CT * p.NT);
+    if (want > 1024) want = 1024;
     const int maxs = cdiv(p.nslots, 64 * 16);
     p.nsplit = want > maxs ? maxs : want;
     if (p.nsplit < 1) p.nsplit = 1;
