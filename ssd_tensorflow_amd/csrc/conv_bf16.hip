@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void wait_pieces(int ahead) {            // leave `ah
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NS>
+template <int NS, bool STAGGER = true>
 __global__ __launch_bounds__(512) void conv_wgrad_bf16_rows8_kernel(WgradRowsArgs p) {
     constexpr int BKT = 128, BNT = 128, BP = 64, XROWS = 72, ROWB = 256, CPR = 16;
     constexpr int RPP = 512 / CPR;                              // 32 pixel rows per staging pass of the workgroup
@@ -1275,8 +1275,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_rows8_kernel(WgradRowsArg
         else wait_pieces<X_N + Y_N>(ahead);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
+        // The issue phase (address walk + 4..5 DMA pieces, ~1200 cycles) is as long as the 24 MFMAs of a stage, and
+        // with one workgroup per CU all 8 waves would be in it at the same time.  With a ring of >= 3 stages the target
+        // buffer is free for the whole iteration, so waves 4..7 (the SIMD partners of waves 0..3) multiply first and
+        // issue afterwards: on every SIMD one wave feeds the matrix pipe while the other one issues.
+        const bool late = NS >= 3 && STAGGER && wave >= 4;
+        if (!late && it + NS - 1 < niter) issue(it + NS - 1, st_i);
         compute(st_c);
+        if (late && it + NS - 1 < niter) issue(it + NS - 1, st_i);
         st_c = st_c + 1 == NS ? 0 : st_c + 1;
         st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
@@ -1632,7 +1638,7 @@ static RowsPlan plan_rows(const ConvDesc& d) {
 
 // 8-wave variant: SSD_WGRAD_ROWS8_BF16 = 0 off, else the ring depth (2..4) for the layers with >= 128 input channels
 static int rows8_mode() {
-    static const int v = env_int("SSD_WGRAD_ROWS8_BF16", 2);     // tuning / A-B switch (measured: 2, 3 and 4 stages tie)
+    static const int v = env_int("SSD_WGRAD_ROWS8_BF16", 4);     // tuning / A-B switch (staggered issue needs >= 3 stages; 4 measured best)
     return v;
 }
 static bool rows8_applicable(const ConvDesc& d) {
@@ -1654,10 +1660,10 @@ static RowsPlan plan_rows8(const ConvDesc& d) {
     p.nsplit = cdiv(p.nslots, p.schunk);
     return p;
 }
-template <int NS>
+template <int NS, bool STAGGER = true>
 static void launch_wgrad_rows8(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * (72 * 256 + 64 * 256);
-    auto kern = conv_wgrad_bf16_rows8_kernel<NS>;
+    auto kern = conv_wgrad_bf16_rows8_kernel<NS, STAGGER>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
@@ -1695,9 +1701,12 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
         r.CT = rp.CT; r.NT = rp.NT; r.nslots = rp.nslots; r.schunk = rp.schunk; r.nsplit = rp.nsplit;
         const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
         const char* label = "conv_wgrad_bf16_rows8_128x128";
+        static const int stagger = env_int("SSD_WGRAD_ROWS8_STAGGER", 1);      // A/B switch
         if (rows8_mode() == 2) launch_wgrad_rows8<2>(r, label, fl, by, s);
-        else if (rows8_mode() == 4) launch_wgrad_rows8<4>(r, label, fl, by, s);
-        else launch_wgrad_rows8<3>(r, label, fl, by, s);
+        else if (rows8_mode() == 4 && stagger) launch_wgrad_rows8<4, true>(r, label, fl, by, s);
+        else if (rows8_mode() == 4) launch_wgrad_rows8<4, false>(r, label, fl, by, s);
+        else if (stagger) launch_wgrad_rows8<3, true>(r, label, fl, by, s);
+        else launch_wgrad_rows8<3, false>(r, label, fl, by, s);
         wgrad_reduce(ws, rp.nsplit, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
         return;
     }
