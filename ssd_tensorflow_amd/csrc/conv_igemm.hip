@@ -45,6 +45,16 @@ struct GatherArgs {
     int relu, accum;
     int NT;                 // number of n tiles
     int tap_dh[9], tap_dw[9];
+    // parity classes of a strided data gradient (LDS-DMA kernel only): the gathered taps are a subset of the filter's
+    // (tap_w = filter tap of gathered tap k, wtaps = taps of the filter), and the M "virtual" pixels (b, a, c) of the
+    // class are the real pixels (b, out_mul a + out_ph, out_mul c + out_pw) of an ODH x ODW image.  out_mul = 1: off.
+    int tap_w[9], wtaps;
+    int out_mul, out_ph, out_pw, ODH, ODW;
+    // all classes in ONE launch (the classes are latency-bound on their own: a few workgroups each): class c owns the
+    // workgroups [cls_wg0[c], cls_wg0[c + 1]) and replaces M / DH / DW / ntaps / taps / out_ph / out_pw by its own
+    int nclass;
+    int cls_wg0[5], cls_M[4], cls_DH[4], cls_DW[4], cls_ntaps[4], cls_ph[4], cls_pw[4];
+    int cls_dh[4][9], cls_dw[4][9], cls_w[4][9];
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -341,9 +351,25 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 
 // STRIDED: data gradient of a stride-2^k convolution (conv8_2, conv9_2): source pixel = (oh + dh) / stride when that
 // division is exact; the validity of a (row, tap) pair is recomputed per iteration with shifts and masks.
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false>
-__global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false>
+__global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
+    const GatherArgs& p = pp;
+    int wg_first = 0, wg_count = gridDim.x;
+    int P_M = pp.M, P_DH = pp.DH, P_DW = pp.DW, P_ntaps = pp.ntaps, P_out_ph = pp.out_ph, P_out_pw = pp.out_pw;
+    const int* P_tap_dh = pp.tap_dh;
+    const int* P_tap_dw = pp.tap_dw;
+    const int* P_tap_w = pp.tap_w;
+    if (PARITY) {                                      // parity classes of a strided data gradient, one launch
+        int c = 0;
+        for (int k = 1; k < pp.nclass; ++k)
+            if ((int)blockIdx.x >= pp.cls_wg0[k]) c = k;
+        wg_first = pp.cls_wg0[c]; wg_count = pp.cls_wg0[c + 1] - wg_first;
+        P_M = pp.cls_M[c]; P_DH = pp.cls_DH[c]; P_DW = pp.cls_DW[c]; P_ntaps = pp.cls_ntaps[c];
+        P_out_ph = pp.cls_ph[c]; P_out_pw = pp.cls_pw[c];
+        P_tap_dh = pp.cls_dh[c]; P_tap_dw = pp.cls_dw[c]; P_tap_w = pp.cls_w[c];
+    }
     constexpr int A_N = BM / 32;                      // DMA instructions per thread: A tile (8 rows x 128 B per wave-instruction)
     constexpr int B_CPR = BN / 4;                     // forward: 16-byte chunks per k-row of the filter tile
     constexpr int B_RPP = 256 / B_CPR;                // forward: k-rows per pass
@@ -357,7 +383,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(blockIdx.x - wg_first, wg_count);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -368,18 +394,18 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
-        const int mm = m < p.M ? m : 0;
-        const int ow = mm % p.DW;
-        const int t2 = mm / p.DW;
-        const int oh = t2 % p.DH;
-        const int b = t2 / p.DH;
-        const int rh = m < p.M ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
+        const int mm = m < P_M ? m : 0;
+        const int ow = mm % P_DW;
+        const int t2 = mm / P_DW;
+        const int oh = t2 % P_DH;
+        const int b = t2 / P_DH;
+        const int rh = m < P_M ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
         a_off[i] = (unsigned)((b * p.SH * p.SW + rh * p.SW + rw) * p.SC + a_c4) * 4u;
         s_b[i] = b * p.SH * p.SW; s_h[i] = rh; s_w[i] = rw;
         unsigned mk = 0;
         if constexpr (!STRIDED) {
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int sh = rh + p.tap_dh[t], sw = rw + p.tap_dw[t];
+            for (int t = 0; t < P_ntaps; ++t) {
+                const int sh = rh + P_tap_dh[t], sw = rw + P_tap_dw[t];
                 if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
             }
         }
@@ -390,13 +416,13 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
     // falls into the padding.  The scalar part must not be negative, so the activation descriptor starts `tap_bias`
     // bytes before the tensor (the most negative tap offset); nothing is fetched from there.
     int tap_min = 0;
-    for (int t = 0; t < p.ntaps; ++t) tap_min = min(tap_min, (p.tap_dh[t] * p.SW + p.tap_dw[t]) * p.SC);
+    for (int t = 0; t < P_ntaps; ++t) tap_min = min(tap_min, (P_tap_dh[t] * p.SW + P_tap_dw[t]) * p.SC);
     const unsigned tap_bias = (unsigned)(-tap_min) * 4u;
-    const size_t src_bytes = (size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 4u;
+    const size_t src_bytes = (size_t)(P_M / (P_DH * P_DW)) * p.SH * p.SW * p.SC * 4u;
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(const_cast<float*>(p.src)) - (STRIDED ? 0u : tap_bias), 0, (unsigned)(src_bytes + (STRIDED ? 0u : tap_bias)), 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.wci * p.wco * 4u), 0x00020000);
+        const_cast<float*>(p.wgt), 0, (unsigned)((size_t)p.wtaps * p.wci * p.wco * 4u), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
     // filter tile addressing that does not change over the k loop
     unsigned b_off[B_N], b_ok[B_N];
@@ -414,17 +440,17 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
     }
 
     const int nchunks = (p.SC + BK - 1) / BK;
-    const int nk = nchunks * p.ntaps;
+    const int nk = nchunks * P_ntaps;
 
     auto issue = [&](int kiter, int stage) {
-        const int cc = kiter / p.ntaps;
-        const int tap = kiter - cc * p.ntaps;
+        const int cc = kiter / P_ntaps;
+        const int tap = kiter - cc * P_ntaps;
         unsigned char* As = lds + stage * STAGE + wave * 1024;
         unsigned char* Bs = lds + stage * STAGE + A_BYTES + wave * 1024;
-        const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * BK) * 4);
+        const unsigned toff = (unsigned)(((P_tap_dh[tap] * p.SW + P_tap_dw[tap]) * p.SC + cc * BK) * 4);
         const unsigned cmask = 0u - (unsigned)(cc * BK + a_c4 < p.SC);
         if constexpr (STRIDED) {
-            const int dh = p.tap_dh[tap], dw = p.tap_dw[tap], lowbits = p.div - 1;
+            const int dh = P_tap_dh[tap], dw = P_tap_dw[tap], lowbits = p.div - 1;
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 const int sh = s_h[i] + dh, sw = s_w[i] + dw;
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
             }
         }
         if constexpr (MODE == MODE_FWD) {
-            const unsigned woff = (unsigned)((tap * p.wci + cc * BK) * p.wco) * 4u;
+            const unsigned woff = (unsigned)((P_tap_w[tap] * p.wci + cc * BK) * p.wco) * 4u;
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
                 const int kr = tid / B_CPR + B_RPP * i;
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + i * 4096), 16, (int)(ok ? b_off[i] : OOB), (int)woff, 0, 0);
             }
         } else {
-            const unsigned woff = (unsigned)(tap * p.wci * p.wco + cc * BK) * 4u;
+            const unsigned woff = (unsigned)(P_tap_w[tap] * p.wci * p.wco + cc * BK) * 4u;
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
                 const bool ok = b_ok[i] != 0u && cmask != 0u;
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
     };
 
     // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
-    issue(0, 0);
+    if (nk > 0) issue(0, 0);
     for (int k = 0; k < nk; ++k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -524,8 +550,14 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                const size_t o = (size_t)m * p.DN + n;
+                if (m >= P_M) continue;
+                size_t pix = (size_t)m;
+                if (PARITY) {                           // parity class: virtual pixel (b, a, c) -> real pixel
+                    const int c = m % P_DW, t2 = m / P_DW;
+                    const int a = t2 % P_DH, b = t2 / P_DH;
+                    pix = ((size_t)b * p.ODH + a * p.out_mul + P_out_ph) * p.ODW + c * p.out_mul + P_out_pw;
+                }
+                const size_t o = pix * p.DN + n;
                 float v = acc[mi][ni][r];
                 if constexpr (MODE == MODE_FWD) {
                     v += bv;
@@ -999,17 +1031,17 @@ static void check_desc(const ConvDesc& d) {
                 "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false>
-static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false>
+static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED>;
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -1058,10 +1090,12 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
     a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
     a.ntaps = d.KH * d.KW; a.mul = d.stride; a.div = 1;
     a.wci = d.Ci; a.wco = d.Co; a.relu = relu; a.accum = 0;
+    a.wtaps = a.ntaps; a.out_mul = 1; a.out_ph = a.out_pw = 0; a.ODH = a.DH; a.ODW = a.DW;
     for (int kh = 0; kh < d.KH; ++kh)
         for (int kw = 0; kw < d.KW; ++kw) {
             a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
             a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+            a.tap_w[kh * d.KW + kw] = kh * d.KW + kw;
         }
     const bool smallc = d.Ci % 4 != 0;
     const double fl = conv_flops(d), by = conv_bytes(d);
@@ -1112,14 +1146,55 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     a.SH = d.Ho; a.SW = d.Wo; a.SC = d.Co;
     a.ntaps = d.KH * d.KW; a.mul = 1; a.div = d.stride;
     a.wci = d.Ci; a.wco = d.Co; a.relu = 0; a.accum = accumulate;
+    a.wtaps = a.ntaps; a.out_mul = 1; a.out_ph = a.out_pw = 0; a.ODH = a.DH; a.ODW = a.DW;
     for (int kh = 0; kh < d.KH; ++kh)
         for (int kw = 0; kw < d.KW; ++kw) {
             a.tap_dh[kh * d.KW + kw] = d.pad_h - kh * d.dil;
             a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
+            a.tap_w[kh * d.KW + kw] = kh * d.KW + kw;
         }
     const double fl = conv_flops(d), by = conv_bytes(d) + (mask ? 4.0 * d.B * d.Hi * d.Wi * d.Ci : 0.0);
     const int cfg = pick_tile(a.M, a.DN, MODE_DGRAD);
-    if (d.stride > 1 && use_dma() && (d.stride & (d.stride - 1)) == 0) {      // conv8_2, conv9_2, vgg512 conv10_2
+    static const int parity = env_int("SSD_DGRAD_PARITY", 1);      // A/B switch
+    if (d.stride > 1 && use_dma() && parity && d.Co % 4 == 0) {
+        // Strided data gradient by parity classes (conv8_2, conv9_2, vgg512 conv10_2).  An input pixel (ih, iw) only
+        // meets the taps with (ih + pad - kh dil) divisible by the stride: gathering all taps for every pixel wastes
+        // (stride^2 - 1) / stride^2 of the MFMAs on zero rows.  Per class (ih mod s, iw mod s) the pixels form a dense
+        // (Hi/s x Wi/s) grid on which the remaining taps are a plain stride-1 gather of dy: one launch per class of the
+        // unstrided kernel, with the filter tap and the real output pixel looked up through tap_w / out_*.
+        const int sdiv = d.stride;
+        SSD_REQUIRE(sdiv == 2, "conv_dgrad: parity classes are laid out for stride 2");
+        GatherArgs c = a;
+        c.div = 1; c.mul = 1; c.out_mul = sdiv; c.ODH = d.Hi; c.ODW = d.Wi;
+        const int tile128 = pick_tile((long long)a.M / 4, a.DN, MODE_DGRAD) <= 1;
+        const int bm = tile128 ? 128 : 64, NT = cdiv(a.DN, 128);
+        c.nclass = 0;
+        c.cls_wg0[0] = 0;
+        for (int ph = 0; ph < sdiv; ++ph)
+            for (int pw = 0; pw < sdiv; ++pw) {
+                const int k = c.nclass;
+                c.cls_DH[k] = (d.Hi - ph + sdiv - 1) / sdiv; c.cls_DW[k] = (d.Wi - pw + sdiv - 1) / sdiv;
+                if (c.cls_DH[k] <= 0 || c.cls_DW[k] <= 0) continue;
+                c.cls_M[k] = d.B * c.cls_DH[k] * c.cls_DW[k];
+                c.cls_ph[k] = ph; c.cls_pw[k] = pw;
+                int nt = 0;
+                for (int kh = 0; kh < d.KH; ++kh)
+                    for (int kw = 0; kw < d.KW; ++kw) {
+                        const int nh = ph + d.pad_h - kh * d.dil, nw = pw + d.pad_w - kw * d.dil;
+                        if (nh % sdiv != 0 || nw % sdiv != 0) continue;       // (C++ % keeps the sign: 0 stays 0)
+                        c.cls_dh[k][nt] = nh / sdiv; c.cls_dw[k][nt] = nw / sdiv; c.cls_w[k][nt] = kh * d.KW + kw;
+                        ++nt;
+                    }
+                c.cls_ntaps[k] = nt;
+                c.cls_wg0[k + 1] = c.cls_wg0[k] + cdiv(c.cls_M[k], bm) * NT;
+                ++c.nclass;
+            }
+        // single-class fields = class 0 (the kernel patches them per workgroup when nclass > 1)
+        c.M = c.cls_M[0]; c.DH = c.cls_DH[0]; c.DW = c.cls_DW[0]; c.ntaps = c.cls_ntaps[0]; c.out_ph = c.cls_ph[0]; c.out_pw = c.cls_pw[0];
+        for (int t = 0; t < 9; ++t) { c.tap_dh[t] = c.cls_dh[0][t]; c.tap_dw[t] = c.cls_dw[0][t]; c.tap_w[t] = c.cls_w[0][t]; }
+        if (tile128) launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2, false, true>(c, "conv_dgrad_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
+        else launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2, false, true>(c, "conv_dgrad_parity_64x128", fl, by, s, c.cls_wg0[c.nclass]);
+    } else if (d.stride > 1 && use_dma() && (d.stride & (d.stride - 1)) == 0) {      // the all-taps strided kernel (SSD_DGRAD_PARITY=0)
         if (cfg == 0 || cfg == 1) launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2, true>(a, "conv_dgrad_strided_64x128", fl, by, s);
     } else if (d.stride > 1) {

@@ -9,7 +9,11 @@ from gpu_util import lib, check, ptr, conv_geom
 
 LAYERS = [('conv1_2', 300, 64, 64, 3, 1, 1), ('conv2_2', 150, 128, 128, 3, 1, 1), ('conv3_2', 75, 256, 256, 3, 1, 1),
           ('conv4_2', 38, 512, 512, 3, 1, 1), ('conv5_2', 19, 512, 512, 3, 1, 1), ('mod_conv6', 19, 512, 1024, 3, 1, 6),
-          ('mod_conv7', 19, 1024, 1024, 1, 1, 1), ('head1', 19, 1024, 152, 3, 1, 1), ('head0', 38, 512, 100, 3, 1, 1)]
+          ('mod_conv7', 19, 1024, 1024, 1, 1, 1), ('head1', 19, 1024, 152, 3, 1, 1), ('head0', 38, 512, 100, 3, 1, 1),
+          # the small tail of the network (latency-bound: a handful of workgroups each)
+          ('conv8_1', 19, 1024, 256, 1, 1, 1), ('conv8_2', 19, 256, 512, 3, 2, 1), ('conv9_1', 10, 512, 128, 1, 1, 1),
+          ('conv9_2', 10, 128, 256, 3, 2, 1), ('conv10_1', 5, 256, 128, 1, 1, 1), ('conv10_2', 5, 128, 256, 3, 1, 1),
+          ('head2', 10, 512, 152, 3, 1, 1), ('head3', 5, 256, 152, 3, 1, 1)]
 only = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] != 'all' else None
 BF16 = len(sys.argv) > 2 and sys.argv[2] == 'bf16'
 B = int(os.environ.get("SSD_BENCH_B", "32"))      # batch (SSD_BENCH_B: quantisation / tail experiments)
