@@ -50,7 +50,14 @@ struct GatherArgsH {
     int relu, accum, out_f32;
     int NT;
     int tap_dh[9], tap_dw[9];
+    // parity classes of a strided data gradient (per-tap kernel, PARITY instantiation; see conv_igemm.hip): class c owns
+    // the workgroups [cls_wg0[c], cls_wg0[c + 1]), gathers cls_ntaps[c] of the filter's `wtaps` taps (cls_w = filter tap)
+    // on its own dense pixel grid cls_DH x cls_DW and writes the real pixels (b, 2 a + ph, 2 c + pw) of an ODH x ODW image
+    int wtaps, nclass, ODH, ODW;
+    int cls_wg0[5], cls_M[4], cls_DH[4], cls_DW[4], cls_ntaps[4], cls_ph[4], cls_pw[4];
+    int cls_dh[4][9], cls_dw[4][9], cls_w[4][9];
 };
+struct OutMap { int M, DH, DW, ph, pw, ODH, ODW; };      // parity class: virtual pixel (b, a, c) -> real pixel (b, 2 a + ph, 2 c + pw)
 
 // Pipeline step: wait until all but the `ahead` most recent tiles of this lane's LDS-DMA have landed
 // (L DMA instructions per tile; vmcnt retires loads in order), then the workgroup barrier publishes them.
@@ -72,9 +79,10 @@ __device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
 // last LDS read.
 // HALVES = 2: the C tile holds half of every wave's rows at a time (a 256-row tile through 66 KB of LDS);
 // rows_valid: tile rows that belong to this workgroup (the kernel-row 256-pixel tile owns 256 - 2 dil of its rows).
-template <int MODE, int WM, int WN, int TM, int TN, int HALVES = 1>
+template <int MODE, int WM, int WN, int TM, int TN, int HALVES = 1, bool PARITY = false>
 __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned char* smem, const f32x16 (&acc)[TM][TN], int tid, int wm,
-                                                int wn, int li, int lh, int m0, int n0, int rows_valid = 32 * TM * WM) {
+                                                int wn, int li, int lh, int m0, int n0, int rows_valid = 32 * TM * WM,
+                                                const OutMap* om = nullptr) {
     constexpr int NTHR = 64 * WM * WN, TMH = TM / HALVES, BMH = 32 * TMH * WM, BN = 32 * TN * WN, LDC = BN + 4;
     static_assert(TM % HALVES == 0, "whole accumulator tiles per pass");
     float* Cs = reinterpret_cast<float*>(smem);
@@ -107,11 +115,17 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
         // C-tile row -> tile row: wave row block ml / (32 TMH), pass h inside the wave's 32 TM rows
         const int tr = HALVES == 1 ? ml : (ml / (32 * TMH)) * (32 * TM) + h * (32 * TMH) + ml % (32 * TMH);
         const int m = m0 + tr;
-        if (!ncol || tr >= rows_valid || m >= p.M) continue;
+        if (!ncol || tr >= rows_valid || m >= (PARITY ? om->M : p.M)) continue;
+        size_t pix = (size_t)m;
+        if constexpr (PARITY) {
+            const int c = m % om->DW, t2 = m / om->DW;
+            const int a = t2 % om->DH, b = t2 / om->DH;
+            pix = ((size_t)b * om->ODH + 2 * a + om->ph) * om->ODW + 2 * c + om->pw;
+        }
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
         float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const size_t o = (size_t)m * p.DN + n;
+        const size_t o = pix * p.DN + n;
         if constexpr (MODE == MODE_FWD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -148,8 +162,25 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
   }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherArgsH p) {
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS, bool PARITY = false>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherArgsH pp) {
+    // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
+    const GatherArgsH& p = pp;
+    int wg_first = 0, wg_count = gridDim.x;
+    int P_M = pp.M, P_DH = pp.DH, P_DW = pp.DW, P_ntaps = pp.ntaps;
+    const int* P_tap_dh = pp.tap_dh;
+    const int* P_tap_dw = pp.tap_dw;
+    const int* P_tap_w = nullptr;                       // filter tap of gathered tap k (identity unless PARITY)
+    OutMap om{};
+    if constexpr (PARITY) {                             // parity classes of a strided data gradient, one launch
+        int c = 0;
+        for (int k = 1; k < pp.nclass; ++k)
+            if ((int)blockIdx.x >= pp.cls_wg0[k]) c = k;
+        wg_first = pp.cls_wg0[c]; wg_count = pp.cls_wg0[c + 1] - wg_first;
+        P_M = pp.cls_M[c]; P_DH = pp.cls_DH[c]; P_DW = pp.cls_DW[c]; P_ntaps = pp.cls_ntaps[c];
+        P_tap_dh = pp.cls_dh[c]; P_tap_dw = pp.cls_dw[c]; P_tap_w = pp.cls_w[c];
+        om = OutMap{P_M, P_DH, P_DW, pp.cls_ph[c], pp.cls_pw[c], pp.ODH, pp.ODW};
+    }
     constexpr int NTHR = 64 * WM * WN;                // 4 or 8 waves
     constexpr int RPP_S = NTHR / 8;                   // tile rows one staging pass of the workgroup covers
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -163,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // scalar: LDS-DMA bases stay in SGPRs
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(blockIdx.x - wg_first, wg_count);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -174,19 +205,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int m = m0 + (tid >> 3) + RPP_S * i;
-        const int mm = m < p.M ? m : 0;
-        const int ow = mm % p.DW;
-        const int t2 = mm / p.DW;
-        const int oh = t2 % p.DH;
-        const int b = t2 / p.DH;
+        const int mm = m < P_M ? m : 0;
+        const int ow = mm % P_DW;
+        const int t2 = mm / P_DW;
+        const int oh = t2 % P_DH;
+        const int b = t2 / P_DH;
         rb[i] = b * p.SH * p.SW;
-        rh[i] = m < p.M ? oh * p.mul : -(1 << 20);
+        rh[i] = m < P_M ? oh * p.mul : -(1 << 20);
         rw[i] = ow * p.mul;
         a_off[i] = (unsigned)((rb[i] + rh[i] * p.SW + rw[i]) * p.SC + a_ck) * 2u;
         unsigned mk = 0;
         if constexpr (!STRIDED) {
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int sh = rh[i] + p.tap_dh[t], sw = rw[i] + p.tap_dw[t];
+            for (int t = 0; t < P_ntaps; ++t) {
+                const int sh = rh[i] + P_tap_dh[t], sw = rw[i] + P_tap_dw[t];
                 if ((unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW) mk |= 1u << t;
             }
         }
@@ -200,21 +231,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
         b_off[i] = (unsigned)((n < p.DN ? n : 0) * p.SC + a_ck) * 2u;
     }
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.src), 0, (unsigned)((size_t)(p.M / (p.DH * p.DW)) * p.SH * p.SW * p.SC * 2u), 0x00020000);
+        const_cast<bf16_t*>(p.src), 0, (unsigned)((size_t)(P_M / (P_DH * P_DW)) * p.SH * p.SW * p.SC * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)p.ntaps * p.DN * p.SC * 2u), 0x00020000);
+        const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)(PARITY ? pp.wtaps : P_ntaps) * p.DN * p.SC * 2u), 0x00020000);
 
     const int nchunks = (p.SC + HBK - 1) / HBK;
-    const int nk = nchunks * p.ntaps;
+    const int nk = nchunks * P_ntaps;
 
     auto issue = [&](int kiter, int stage) {
-        const int cc = kiter / p.ntaps;
-        const int tap = kiter - cc * p.ntaps;
+        const int cc = kiter / P_ntaps;
+        const int tap = kiter - cc * P_ntaps;
         unsigned char* As = smem + stage * STAGE + wave * 1024;       // wave-uniform: 8 rows x 128 B per DMA
         unsigned char* Bs = As + BM * 128;
         const unsigned cmask = 0u - (unsigned)(cc * HBK + a_ck < p.SC);
         if constexpr (!STRIDED) {
-            const unsigned toff = (unsigned)(((p.tap_dh[tap] * p.SW + p.tap_dw[tap]) * p.SC + cc * HBK) * 2);
+            const unsigned toff = (unsigned)(((P_tap_dh[tap] * p.SW + P_tap_dw[tap]) * p.SC + cc * HBK) * 2);
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 const unsigned m = (0u - ((a_msk[i] >> tap) & 1u)) & cmask;
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * (RPP_S * 128)), 16, off, 0, 0, 0);
             }
         } else {
-            const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+            const int dh = P_tap_dh[tap], dw = P_tap_dw[tap];
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 int sh = rh[i] + dh, sw = rw[i] + dw;
@@ -235,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * (RPP_S * 128)), 16, off, 0, 0, 0);
             }
         }
-        const unsigned woff = (unsigned)((tap * p.DN * p.SC + cc * HBK) * 2);
+        const unsigned woff = (unsigned)(((PARITY ? P_tap_w[tap] : tap) * p.DN * p.SC + cc * HBK) * 2);
 #pragma unroll
         for (int i = 0; i < B_N; ++i) {
             const unsigned m = cmask & b_ok[i];
@@ -306,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     }
     __syncthreads();
 
-    gather_epilogue<MODE, WM, WN, TM, TN>(p, smem, acc, tid, wm, wn, li, lh, m0, n0);
+    gather_epilogue<MODE, WM, WN, TM, TN, 1, PARITY>(p, smem, acc, tid, wm, wn, li, lh, m0, n0, 32 * TM * WM, &om);
 }
 
 // =================================================================================
@@ -1382,19 +1413,19 @@ void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t
 // =================================================================================
 // host launchers
 // =================================================================================
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS = 2>
-static void launch_gather_h(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s) {
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS = 2, bool PARITY = false>
+static void launch_gather_h(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t stages = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = stages > ctile ? stages : ctile;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED, NS>;
+    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED, NS, PARITY>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(64 * WM * WN), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -1541,7 +1572,37 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
             a.tap_dw[kh * d.KW + kw] = d.pad_w - kw * d.dil;
         }
     const double fl = conv_flops(d), by = 2.0 * (conv_elems(d) + (mask ? (double)d.B * d.Hi * d.Wi * d.Ci : 0.0));
-    if (d.stride > 1) {       // tiny layers only (conv8_2, conv9_2, vgg512 conv10_2)
+    static const int parity = env_int("SSD_DGRAD_PARITY", 1);      // A/B switch (shared with the fp32 path)
+    if (d.stride == 2 && parity) {       // conv8_2, conv9_2, vgg512 conv10_2: parity classes, one launch (see conv_igemm.hip)
+        GatherArgsH c = a;
+        c.div = 1; c.mul = 1; c.wtaps = a.ntaps; c.ODH = d.Hi; c.ODW = d.Wi;
+        const int NT = cdiv(a.DN, 128);
+        c.nclass = 0;
+        c.cls_wg0[0] = 0;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                const int k = c.nclass;
+                c.cls_DH[k] = (d.Hi - ph + 1) / 2; c.cls_DW[k] = (d.Wi - pw + 1) / 2;
+                if (c.cls_DH[k] <= 0 || c.cls_DW[k] <= 0) continue;
+                c.cls_M[k] = d.B * c.cls_DH[k] * c.cls_DW[k];
+                c.cls_ph[k] = ph; c.cls_pw[k] = pw;
+                int nt = 0;
+                for (int kh = 0; kh < d.KH; ++kh)
+                    for (int kw = 0; kw < d.KW; ++kw) {
+                        const int nh = ph + d.pad_h - kh * d.dil, nw = pw + d.pad_w - kw * d.dil;
+                        if (nh % 2 != 0 || nw % 2 != 0) continue;
+                        c.cls_dh[k][nt] = nh / 2; c.cls_dw[k][nt] = nw / 2; c.cls_w[k][nt] = kh * d.KW + kw;
+                        ++nt;
+                    }
+                c.cls_ntaps[k] = nt;
+                c.cls_wg0[k + 1] = c.cls_wg0[k] + cdiv(c.cls_M[k], 128) * NT;
+                ++c.nclass;
+            }
+        c.M = c.cls_M[0]; c.DH = c.cls_DH[0]; c.DW = c.cls_DW[0]; c.ntaps = c.cls_ntaps[0];
+        launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false, 2, true>(c, "conv_dgrad_bf16_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
+        return;
+    }
+    if (d.stride > 1) {       // the all-taps strided kernel (other strides, SSD_DGRAD_PARITY=0)
         launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true, 2>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
         return;
     }
