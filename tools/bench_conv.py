@@ -27,10 +27,15 @@ def bench_bf16(name, hw, ci, co, k, s, d):
     x = torch.randn((B, hw, hw, ci), device='cuda').to(bf); w = torch.randn((k, k, ci, co), device='cuda') * 0.05
     if ZERO:
         x.zero_(); w.zero_()
+    RELU = os.environ.get('SSD_BENCH_RELU') == '1'      # operands like the real step's: post-relu activations, masked gradients
+    if RELU:
+        x = torch.relu(x)
     bias = torch.zeros(co, device='cuda'); y = torch.empty((B, ho, wo, co), device='cuda', dtype=bf)
     dy = torch.randn((B, ho, wo, co), device='cuda').to(bf)
     if ZERO:
         dy.zero_()
+    if RELU:
+        dy = (dy.float() * (torch.rand_like(dy.float()) > 0.5)).to(bf)
     dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(bias)
     wio = torch.empty((k * k, ci, co), device='cuda', dtype=bf); woi = torch.empty((k * k, co, ci), device='cuda', dtype=bf)
     check(lib.ssd_op_cast_filter(ptr(w), ptr(wio), ptr(woi), k * k, ci, co, None))
