@@ -34,54 +34,72 @@ PEAK_BF16_MFMA = 2500.0     # TFLOP/s dense bf16 (2.5 PFLOP/s), same guide
 PEAK_HBM = 8000.0           # GB/s spec
 
 
-# kernel label (event profiler) -> substring of the kernel symbol in rocprofv3 output
+# kernel label (event profiler) -> PREFIX of the demangled kernel symbol in rocprofv3 output.  Only the leading
+# template arguments that select the tile are spelled out, so a kernel that gains a trailing template parameter
+# still matches (r01's table carried the full argument list and went stale).
 def _gather(mode, wm, wn, tm, tn):
-    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d, false>' % (mode, wm, wn, tm, tn),     # default (LDS-DMA staging)
-            'conv_gather_kernel<%d, %d, %d, %d, %d, false, false' % (mode, wm, wn, tm, tn)]    # SSD_GLDS=0
+    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn),     # default (LDS-DMA staging)
+            'conv_gather_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn)]         # SSD_GLDS=0
 
 
-# profiler label -> kernel symbol(s) in the rocprofv3 --pmc passes
+def _wgrad(wm, wn, tm, tn):
+    t = '%d, %d, %d, %d' % (wm, wn, tm, tn)
+    return ['conv_wgrad_kernel<' + t + ',', 'conv_wgrad_kernel<' + t + '>', 'conv_wgrad_dma_kernel<' + t + '>', 'conv_wgrad_dma_kernel<' + t + ',']
+
+
+def _gbf(mode, wm, wn, tm, tn):
+    return ['conv_gather_bf16_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn)]
+
+
+def _wbf(wm, wn, tm, tn):
+    return ['conv_wgrad_bf16_kernel<%d, %d, %d, %d,' % (wm, wn, tm, tn), 'conv_wgrad_bf16_kernel<%d, %d, %d, %d>' % (wm, wn, tm, tn)]
+
+
 KERNEL_SYMBOLS = {
     'conv_fwd_128x128': _gather(0, 2, 2, 2, 2), 'conv_fwd_128x64': _gather(0, 4, 1, 1, 2),
     'conv_fwd_64x128': _gather(0, 2, 2, 1, 2), 'conv_fwd_64x64': _gather(0, 2, 2, 1, 1),
     'conv_dgrad_128x128': _gather(1, 2, 2, 2, 2), 'conv_dgrad_128x64': _gather(1, 4, 1, 1, 2),
     'conv_dgrad_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_64x64': _gather(1, 2, 2, 1, 1),
-    'conv_wgrad_128x128': ['conv_wgrad_kernel<2, 2, 2, 2, false', 'conv_wgrad_dma_kernel<2, 2, 2, 2>'],
-    'conv_wgrad_64x64': ['conv_wgrad_dma_kernel<2, 2, 1, 1>', 'conv_wgrad_kernel<2, 2, 1, 1, false'],
-    'conv_wgrad_64x128': ['conv_wgrad_dma_kernel<2, 2, 1, 2>', 'conv_wgrad_kernel<2, 2, 1, 2, false'],
-    'conv_wgrad_128x64': ['conv_wgrad_kernel<2, 2, 2, 1, false', 'conv_wgrad_dma_kernel<2, 2, 2, 1>'],
-    'detect_scan': ['detect_scan_kernel'],
-    'conv_fwd_bf16_128x128': ['conv_gather_bf16_kernel<0, 2, 2, 2, 2, false, 2>'], 'conv_fwd_bf16_128x64': ['conv_gather_bf16_kernel<0, 4, 1, 1, 2, false, 2>'],
-    'conv_fwd_bf16_64x128': ['conv_gather_bf16_kernel<0, 2, 2, 1, 2, false, 2>'], 'conv_fwd_bf16_256x64_8w': ['conv_gather_bf16_kernel<0, 8, 1, 1, 2, false, 2>'],
-    'conv_dgrad_bf16_128x128': ['conv_gather_bf16_kernel<1, 2, 2, 2, 2, false, 2>'], 'conv_dgrad_bf16_128x64': ['conv_gather_bf16_kernel<1, 4, 1, 1, 2, false, 2>'],
-    'conv_dgrad_bf16_64x128': ['conv_gather_bf16_kernel<1, 2, 2, 1, 2, false, 2>'], 'conv_dgrad_bf16_256x64_8w': ['conv_gather_bf16_kernel<1, 8, 1, 1, 2, false, 2>'],
-    'conv_wgrad_bf16_128x128': ['conv_wgrad_bf16_kernel<2, 2, 2, 2, 2>'], 'conv_wgrad_bf16_64x64': ['conv_wgrad_bf16_kernel<2, 2, 1, 1, 2>'],
-    'conv_wgrad_bf16_64x128': ['conv_wgrad_bf16_kernel<2, 2, 1, 2, 2>'], 'conv_wgrad_bf16_rows_64x64': ['conv_wgrad_bf16_rows_kernel<1>'],
-    'conv_wgrad_bf16_rows_64x128': ['conv_wgrad_bf16_rows_kernel<2>'], 'conv_wgrad_bf16_128x64': ['conv_wgrad_bf16_kernel<2, 2, 2, 1, 2>'],
+    'conv_wgrad_128x128': _wgrad(2, 2, 2, 2), 'conv_wgrad_64x64': _wgrad(2, 2, 1, 1),
+    'conv_wgrad_64x128': _wgrad(2, 2, 1, 2), 'conv_wgrad_128x64': _wgrad(2, 2, 2, 1),
+    'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'],
+    'multibox_loss': ['heads_kernel<true>'], 'multibox_loss_grad': ['loss_grad_kernel<'], 'heads_result': ['heads_kernel<false>'],
+    'conv_fwd_bf16_128x128': _gbf(0, 2, 2, 2, 2), 'conv_fwd_bf16_128x64': _gbf(0, 4, 1, 1, 2),
+    'conv_fwd_bf16_64x128': _gbf(0, 2, 2, 1, 2), 'conv_fwd_bf16_256x64_8w': _gbf(0, 8, 1, 1, 2),
+    'conv_dgrad_bf16_128x128': _gbf(1, 2, 2, 2, 2), 'conv_dgrad_bf16_128x64': _gbf(1, 4, 1, 1, 2),
+    'conv_dgrad_bf16_64x128': _gbf(1, 2, 2, 1, 2), 'conv_dgrad_bf16_256x64_8w': _gbf(1, 8, 1, 1, 2),
+    'conv_wgrad_bf16_128x128': _wbf(2, 2, 2, 2), 'conv_wgrad_bf16_64x64': _wbf(2, 2, 1, 1),
+    'conv_wgrad_bf16_64x128': _wbf(2, 2, 1, 2), 'conv_wgrad_bf16_128x64': _wbf(2, 2, 2, 1),
+    'conv_wgrad_bf16_rows_64x64': ['conv_wgrad_bf16_rows_kernel<1'], 'conv_wgrad_bf16_rows_64x128': ['conv_wgrad_bf16_rows_kernel<2'],
     'conv_wgrad_bf16_rows8_128x128': ['conv_wgrad_bf16_rows8_kernel<'],
-    'conv_fwd_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<0, 2>'], 'conv_dgrad_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2>'],
-    'conv_fwd_bf16_c64': ['conv_gather_bf16_c64_kernel<0>'], 'conv_dgrad_bf16_c64': ['conv_gather_bf16_c64_kernel<1>'],
-    'conv_fwd_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<0, 4>'], 'conv_dgrad_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<1, 4>'],
+    'conv_fwd_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<0, 2'], 'conv_dgrad_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2'],
+    'conv_fwd_bf16_c64': ['conv_gather_bf16_c64_kernel<0'], 'conv_dgrad_bf16_c64': ['conv_gather_bf16_c64_kernel<1'],
+    'conv_fwd_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<0, 4'], 'conv_dgrad_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<1, 4'],
 }
 
 
-def pmc_traffic(label, dtype='f32'):
-    """HBM bytes per launch of `label`'s kernel from the newest committed rocprofv3 --pmc passes of that dtype
-    (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt; separate passes, KB units, FETCH_SIZE
+def pmc_traffic(label, dtype='f32', mode='train'):
+    """HBM bytes per launch of `label`'s kernel from the newest committed rocprofv3 --pmc passes of that
+    configuration (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt; separate passes, KB units, FETCH_SIZE
     doubled on gfx950 as MI355X_MICROARCH.md prescribes).  None when no pass is committed."""
     import glob
     syms = KERNEL_SYMBOLS.get(label)
-    pick = (lambda n: 'bf16' in os.path.basename(n)) if dtype == 'bf16' else (lambda n: 'bf16' not in os.path.basename(n))
+
+    def pick(n):
+        n = os.path.basename(n)
+        return ('bf16' in n) == (dtype == 'bf16') and ('decode' in n) == (mode == 'decode')
     f = sorted(n for n in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_FETCH_SIZE.txt')) if pick(n))
     w = sorted(n for n in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_WRITE_SIZE.txt')) if pick(n))
     if not syms or not f or not w:
         return None, None
 
     def avg(path):
+        tot = cnt = 0.0
         for line in open(path):
-            if any(sym in line for sym in syms):
-                return float(line.split('avg=')[1].split()[0])
-        return None
+            if any(sym in line for sym in syms):        # a label may cover several instantiations (e.g. a trailing flag)
+                n = float(line.split('launches=')[1].split()[0])
+                tot += float(line.split('avg=')[1].split()[0]) * n; cnt += n
+        return tot / cnt if cnt else None
     fa, wa = avg(f[-1]), avg(w[-1])
     if fa is None or wa is None:
         return None, None
@@ -196,58 +214,39 @@ def bench_augment(args, rank, world, local):
             'cpu_baseline': cpu}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--preset', default='vgg300')
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment'])
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                    help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
-    ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
-    ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
-    ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
-    ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
-    ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
-    args = ap.parse_args()
+EXPECT_PATH = os.path.join(ROOT, 'tests', 'golden', 'bench_expect.json')
 
+
+def expected_losses(preset, batch, dtype):
+    """Step-0 losses of the benchmark's own inputs (rank 0: images / boxes from default_rng(1234), library weights
+    from seed 42) computed by the CPU oracle in the build container (tools/make_bench_expect.py); None if that
+    configuration was not generated.  bf16 runs are checked against the fp32 values with a bf16-sized tolerance."""
+    try:
+        table = json.load(open(EXPECT_PATH))
+    except OSError:
+        return None, None
+    e = table.get(f'{preset}_b{batch}')
+    return (e, 1e-3 if dtype == 'f32' else 3e-2) if e else (None, None)
+
+
+def run_config(a, rank, world, local):
+    """One benchmark configuration -> the JSON-able result dict (rank 0; None elsewhere).
+    a: namespace with mode, preset, batch, dtype, steps, warmup, bucket_mb, no_overlap, per_layer, no_kernel_events,
+    no_cpu_baseline, zero_input, allow_fallback."""
     import torch
     import torch.distributed as dist
     from ssd_tensorflow_amd._lib import lib, check
     from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
     from ssd_tensorflow_amd import parallel
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
-    if args.same_device:
-        local = 0
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(args.backend)
-
-    if args.mode == 'augment':
-        return bench_augment(args, rank, world, local)
-    b = args.batch
-    bucket = int(args.bucket_mb * 1e6 / 4)
+    b = a.batch
+    bucket = int(a.bucket_mb * 1e6 / 4)
     state = {'bucket': bucket}
     sess = Session(local)
-    net = SSDVGG(sess, args.preset)
-    training = args.mode == 'train'
-    net.build_from_vgg(None, 20, max_batch=b, training=training, seed=42, dtype=args.dtype)
-    peak_mfma = PEAK_BF16_MFMA if args.dtype == 'bf16' else PEAK_FP32_MFMA
+    net = SSDVGG(sess, a.preset)
+    training = a.mode == 'train'
+    net.build_from_vgg(None, 20, max_batch=b, training=training, seed=42, dtype=a.dtype)
+    peak_mfma = PEAK_BF16_MFMA if a.dtype == 'bf16' else PEAK_FP32_MFMA
     if world > 1:      # identical replicas
         dist.broadcast(net.params_flat, 0)
     if training:
@@ -258,16 +257,29 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     H, W = net.preset.image_size.h, net.preset.image_size.w
     x = torch.from_numpy(rng.integers(0, 256, (b, H, W, 3)).astype(np.float32)).cuda()
-    if args.zero_input:
+    if a.zero_input:
         x.zero_()
     A, nv = net.preset.num_anchors, 25
     y = torch.empty((b, A, nv), dtype=torch.float32, device='cuda')
     gt, cls, offs = synth_gt(rng, b)
-    check(lib.ssd_encode_labels_dev(args.preset.encode(), 20, local, gt.ctypes.data, cls.ctypes.data, offs.ctypes.data, b,
+    check(lib.ssd_encode_labels_dev(a.preset.encode(), 20, local, gt.ctypes.data, cls.ctypes.data, offs.ctypes.data, b,
                                     y.data_ptr(), None))
     torch.cuda.synchronize()
 
-    if args.mode == 'decode':
+    # parity guard of the benchmarked configuration itself: the step-0 losses of these very inputs must be the CPU
+    # oracle's (stored by tools/make_bench_expect.py); a mismatch makes the run invalid, so it is fatal
+    losses_check = None
+    if training and rank == 0 and not a.zero_input:
+        want, tol = expected_losses(a.preset, b, a.dtype)
+        if want is not None:
+            net.eval_step_dev(x, y)
+            got = net.get_losses()
+            worst = max(abs(got[k] - want[k]) / abs(want[k]) for k in want)
+            losses_check = dict(step0=got, oracle=want, max_rel_err=worst, tol=tol, ok=bool(worst < tol))
+            if not losses_check['ok']:
+                raise SystemExit(f'[bench] step-0 losses differ from the oracle: {got} vs {want} (rel {worst:.3e} >= {tol})')
+
+    if a.mode == 'decode':
         # BASELINE config 5 / SURVEY 8d: softmax of N(0,1) logits, +4 on background, +8 on 300 random
         # (anchor, class) pairs per image; loc ~ N(0, 0.5): ~300 detections per image at thr 0.5
         g = torch.Generator(device='cuda'); g.manual_seed(1234 + rank)
@@ -279,50 +291,66 @@ def main():
         check(lib.ssd_set_result_dev(net._h, pred.data_ptr(), b))
         torch.cuda.synchronize()
 
+    pend = {'t': None}
+
     def step():
-        if args.mode == 'decode':
-            dets = net.detect_last(b, 0.5, None, 200)
+        if a.mode == 'decode':
+            # the inference loop's pattern (infer.py): launch batch k, collect batch k-1 (its small output has
+            # already been copied to pinned host memory behind the kernels)
+            t = net.detect_last_launch(b, 0.5, None, 200)
+            if pend['t'] is not None:
+                pend['t'].get()
+            pend['t'] = t
             return
-        if args.mode == 'train':
+        if a.mode == 'train':
             # N > 1: bucketed all-reduce (sum over ranks, RCCL over xGMI) overlapped with backward
             parallel.train_step_dp(net, x, y, world, state['bucket'])
-        elif args.mode == 'infer':
+        elif a.mode == 'infer':
             net.infer_dev(x)
         else:
             net.infer_dev(x)
             net.detect_last(b, 0.5, None, 200)
 
-    if args.no_overlap and args.mode == 'train':
+    def drain():
+        if pend['t'] is not None:
+            pend['t'].get(); pend['t'] = None
+
+    if a.no_overlap and a.mode == 'train':
         check(lib.ssd_set_overlap(net._h, 0))
     allreduce_mode = 'none' if world == 1 else ('bucketed, overlapped with backward' if bucket > 0 else 'single, after backward')
-    if world > 1 and args.mode == 'train' and bucket > 0:
-        # the overlapped path is exercised once up front; if the collective library rejects it on every
-        # rank alike, fall back to ONE all-reduce after backward rather than losing the run
+    if world > 1 and a.mode == 'train' and bucket > 0:
+        # the overlapped path is exercised once up front.  A failure is fatal: a scaling line produced by a
+        # silently downgraded collective would read like a measurement of the shipped path.  --allow-fallback
+        # downgrades to ONE all-reduce after backward instead (and says so in config.allreduce).
         try:
             step()
             torch.cuda.synchronize()
         except Exception as e:      # noqa: BLE001
+            if not a.allow_fallback:
+                raise
             if rank == 0:
                 print(f'[bench] bucketed all-reduce failed ({type(e).__name__}: {e}); falling back to a single all-reduce', file=sys.stderr)
             state['bucket'] = 0
-            allreduce_mode = 'single, after backward (fallback)'
-    for _ in range(args.warmup):
+            allreduce_mode = 'single, after backward (FALLBACK: the bucketed path failed)'
+    for _ in range(a.warmup):
         step()
-    use_events = not args.no_kernel_events
+    drain()
+    use_events = not a.no_kernel_events
     # In training the weight gradients run on a side stream next to the data gradients, so kernels of
     # the timed region overlap and a per-launch event interval is not one kernel's own duration.  The
     # timed region therefore runs WITHOUT per-launch events; the roofline block comes from an equal
     # number of serialized steps (one kernel at a time, events on the launching stream) right after it.
-    serialize_for_events = use_events and args.mode == 'train' and not args.no_overlap
+    serialize_for_events = use_events and a.mode == 'train' and not a.no_overlap
     if use_events and not serialize_for_events:
-        check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
+        check(lib.ssd_profile_enable(net._h, 2 if a.per_layer else 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(a.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -332,22 +360,25 @@ def main():
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # replicas must still agree after K data-parallel steps
         chk = net.params_flat[::4099].double().sum().reshape(1)
         lo = chk.clone(); hi = chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_agree = float(hi - lo) == 0.0
-        if not replicas_agree and rank == 0:      # reported, not fatal: the scaling line is still worth having
-            print(f'[bench] WARNING: replicas diverged after {args.steps} data-parallel steps (checksum spread {float(hi - lo):.3e})', file=sys.stderr)
+        if not replicas_agree and a.mode == 'train':
+            msg = f'[bench] replicas diverged after {a.steps} data-parallel steps (checksum spread {float(hi - lo):.3e})'
+            if not a.allow_fallback:
+                raise SystemExit(msg)
+            if rank == 0:
+                print(msg + ' -- reported, not fatal (--allow-fallback)', file=sys.stderr)
         dt = float(t.item())
 
     roofline = None
     kernels = {}
     if serialize_for_events:
         check(lib.ssd_set_overlap(net._h, 0))
-        check(lib.ssd_profile_enable(net._h, 2 if args.per_layer else 1))
+        check(lib.ssd_profile_enable(net._h, 2 if a.per_layer else 1))
         torch.cuda.synchronize()
-        for _ in range(args.steps):
+        for _ in range(a.steps):
             step()
         torch.cuda.synchronize()
     if use_events:
@@ -357,73 +388,161 @@ def main():
             if not line:
                 continue
             k, cnt, ms, fl, by = line.split('\t')
-            if args.per_layer:
+            if a.per_layer:
                 if rank == 0:
                     tf = float(fl) / (float(ms) * 1e-3) / 1e12 if float(ms) > 0 else 0
-                    print(f'{k:<48s} n={int(cnt) // args.steps:3d}  {float(ms) / args.steps:8.3f} ms/step  {tf:7.1f} TF/s  '
+                    print(f'{k:<48s} n={int(cnt) // a.steps:3d}  {float(ms) / a.steps:8.3f} ms/step  {tf:7.1f} TF/s  '
                           f'{float(by) / (float(ms) * 1e-3) / 1e9 if float(ms) > 0 else 0:8.1f} GB/s', file=sys.stderr)
                 k = k.split(':')[0]
             d0 = kernels.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d0['launches'] += int(cnt); d0['ms'] += float(ms); d0['flops'] += float(fl); d0['bytes'] += float(by)
         check(lib.ssd_profile_enable(net._h, 0))
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]['ms'])
-            if args.mode == 'decode' and 'detect_scan' in kernels:
-                dom = 'detect_scan'       # the HBM-bound pass (every [A,25] row read once); detect_image works on candidates only
+            dom = max(kernels, key=lambda k: kernels[k]['ms'])      # dominant = most time, whatever it is
             d = kernels[dom]
             if d['flops'] > 0:
                 ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
                 roofline = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=peak_mfma, unit='TFLOP/s',
                                 frac=round(ach / peak_mfma, 4), traffic=None,
-                                launches_per_step=d['launches'] // args.steps,
+                                launches_per_step=d['launches'] // a.steps,
                                 avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
                                 flops_per_launch=d['flops'] / d['launches'],
-                                measured='HIP events per launch, %d serialized steps after the timed region' % args.steps
+                                measured='HIP events per launch, %d serialized steps after the timed region' % a.steps
                                 if serialize_for_events else 'HIP events per launch over the timed region')
             else:
-                ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-                roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM, unit='GB/s',
+                # an HBM-bound pass: algorithmic bytes of the WHOLE pass (every [A, C+5] row once for
+                # decode + NMS) over the summed duration of all its kernels -- the candidate kernels move few bytes
+                # but take time, so pricing one hand-picked kernel would flatter the pass
+                if a.mode == 'decode':
+                    by = sum(v['bytes'] for v in kernels.values()); ms = sum(v['ms'] for v in kernels.values())
+                    name = ' + '.join(sorted(kernels, key=lambda k: -kernels[k]['ms']))
+                    launches = kernels[dom]['launches']
+                else:
+                    by, ms, name, launches = d['bytes'], d['ms'], dom, d['launches']
+                ach = by / (ms * 1e-3) / 1e9
+                roofline = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=PEAK_HBM, unit='GB/s',
                                 frac=round(ach / PEAK_HBM, 4), traffic=None,
-                                launches_per_step=d['launches'] // args.steps,
-                                avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
-                                bytes_per_launch=d['bytes'] / d['launches'])
+                                launches_per_step=launches // a.steps,
+                                avg_launch_us=round(ms * 1e3 / launches, 2),
+                                bytes_per_launch=by / launches, dominant_by_time=dom)
 
+    out = None
     if rank == 0:
-        imgs = b * world * args.steps
+        imgs = b * world * a.steps
         value = imgs / dt
-        flops_img = FLOPS_FWD_BWD[args.preset] if args.mode == 'train' else FLOPS_FWD[args.preset]
+        flops_img = FLOPS_FWD_BWD[a.preset] if a.mode == 'train' else FLOPS_FWD[a.preset]
+        cfg_no = {('train', 'vgg300', 'f32'): 1, ('train', 'vgg300', 'bf16'): 2, ('train', 'vgg512', 'f32'): 3,
+                  ('train', 'vgg512', 'bf16'): 3, ('decode', 'vgg300', 'f32'): 4, ('detect', 'vgg300', 'f32'): 4}.get((a.mode, a.preset, a.dtype))
+        what = {'train': 'training step (forward + multibox loss + backward + momentum update)', 'infer': 'inference forward',
+                'detect': 'inference forward + decode + per-class NMS', 'decode': 'decode + per-class NMS of resident predictions'}[a.mode]
         out = {
-            'metric': 'images/sec (fwd+bwd) %s batch%d' % (args.preset, b) if args.mode == 'train'
-                      else 'images/sec (decode + per-class NMS of [b,A,25] predictions) %s batch%d' % (args.preset, b) if args.mode == 'decode'
-                      else 'images/sec (%s) %s batch%d' % (args.mode, args.preset, b),
-            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.preset} {args.mode} step, {b} images/GPU x {world} GPU, synthetic '
-                                   f'{H}x{W} BGR 0..255 + GPU-encoded labels, Xavier-init weights (BASELINE.json configs[%d])' % (2 if args.dtype == 'bf16' else 1),
+            'metric': 'images/sec (fwd+bwd) %s batch%d' % (a.preset, b) if a.mode == 'train'
+                      else 'images/sec (decode + per-class NMS of [b,A,25] predictions) %s batch%d' % (a.preset, b) if a.mode == 'decode'
+                      else 'images/sec (%s) %s batch%d' % (a.mode, a.preset, b),
+            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'{a.preset} {what}, {b} images/GPU x {world} GPU, synthetic {H}x{W} BGR 0..255, '
+                                   + ('GPU-encoded labels, Xavier-init weights' if a.mode != 'decode' else 'synthetic predictions (~300 detections/image at 0.5), outputs collected on the host')
+                                   + (f' (BASELINE.json configs[{cfg_no}]' + (', per-GPU share' if cfg_no in (2, 3) and world == 1 else '') + ')' if cfg_no is not None else ' (not a BASELINE.json config)'),
                        'global_batch': b * world, 'parallelism': f'dp{world}', 'allreduce': allreduce_mode,
                        'replicas_agree': replicas_agree},
-            'model_tflops': round(value * flops_img / 1e12, 2) if args.mode != 'decode' else None,
-            'model_mfma_frac': round(value * flops_img / 1e12 / (peak_mfma * world), 4) if args.mode != 'decode' else None,
+            'model_tflops': round(value * flops_img / 1e12, 2) if a.mode != 'decode' else None,
+            'model_mfma_frac': round(value * flops_img / 1e12 / (peak_mfma * world), 4) if a.mode != 'decode' else None,
             'roofline': roofline,
         }
         if roofline is not None and world == 1:
-            tr, src = pmc_traffic(roofline['kernel'], args.dtype)
+            tr, src = pmc_traffic(roofline.get('dominant_by_time', roofline['kernel']), a.dtype, a.mode)
             if tr is not None:
                 roofline['traffic'] = tr
                 roofline['traffic_source'] = src
         if use_events:
             tot = sum(k['ms'] for k in kernels.values())
-            out['kernel_ms_per_step'] = {k: round(v['ms'] / args.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}
-            out['kernel_ms_sum_per_step'] = round(tot / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline and args.mode == 'train':
-            out['cpu_baseline'] = cpu_baseline(args.preset)
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / a.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}
+            out['kernel_ms_sum_per_step'] = round(tot / a.steps, 4)
+        if world == 1 and not a.no_cpu_baseline and a.mode == 'train':
+            out['cpu_baseline'] = cpu_baseline(a.preset)
         else:
             out['cpu_baseline'] = None
-        if args.mode == 'train':
+        if a.mode == 'train':
             out['losses_last_step'] = net.get_losses()
-        print(json.dumps(out), flush=True)
+            out['losses_check'] = losses_check
     sess.close()
+    del net, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+# configurations BASELINE.json names beside the headline; timed by the default invocation with a few steps each so
+# that they are driver-run numbers (the headline `value` stays configs[1])
+SECONDARY = [
+    ('bf16', dict(mode='train', preset='vgg300', batch=32, dtype='bf16', steps=5, warmup=2)),
+    ('vgg512_b16', dict(mode='train', preset='vgg512', batch=16, dtype='f32', steps=3, warmup=1)),
+    ('vgg512_b16_bf16', dict(mode='train', preset='vgg512', batch=16, dtype='bf16', steps=5, warmup=2)),
+    ('infer_b128', dict(mode='infer', preset='vgg300', batch=128, dtype='f32', steps=3, warmup=1)),
+    ('decode_b128', dict(mode='decode', preset='vgg300', batch=128, dtype='f32', steps=20, warmup=3)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--preset', default='vgg300')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configurations (bf16, vgg512, infer, decode blocks)')
+    ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
+    ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
+    ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    ap.add_argument('--allow-fallback', action='store_true', help='N > 1: downgrade a failing bucketed all-reduce to a single one / report diverged replicas instead of aborting')
+    ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
+    ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ssd_tensorflow_amd import _lib
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
+    if args.same_device:
+        local = 0
+    torch.cuda.set_device(local)
+    _lib.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend)
+
+    if args.mode == 'augment':
+        return bench_augment(args, rank, world, local)
+    out = run_config(args, rank, world, local)
+    headline = (args.mode, args.preset, args.batch, args.dtype) == ('train', 'vgg300', 32, 'f32')
+    if headline and world == 1 and not args.no_secondary and not args.zero_input and not args.per_layer:
+        for name, cfg in SECONDARY:
+            sub = argparse.Namespace(**{**vars(args), **cfg, 'no_cpu_baseline': True, 'per_layer': False})
+            try:
+                r = run_config(sub, rank, world, local)
+                out[name] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config',
+                                               'model_tflops', 'model_mfma_frac', 'roofline', 'kernel_ms_sum_per_step', 'losses_check')
+                             if k in r}
+            except (Exception, SystemExit) as e:      # noqa: BLE001 -- a secondary block never costs the headline line
+                out[name] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -284,6 +284,48 @@ def nms_class(box, thr_num=9, thr_den=20):
     return keep
 
 
+def nms_list(recs, thr):
+    """non_maximum_suppression (ssdutils.py:232-307) on a list of (confidence, (xmin, xmax, ymin, ymax)) records,
+    the coordinates being what prop2abs gives for the boxes on the 1000 grid (ssdutils.py:243-249).  Returns the
+    picked positions in pick order (descending confidence).  Suppression is intersection / union > thr as numpy
+    divides two int64 arrays (f64).  Equal confidences: the reference pops the LAST of np.argsort, whose order among
+    ties is unspecified (unstable sort); here the earlier record goes first."""
+    n = len(recs)
+    if n == 0:
+        return []
+    conf = np.array([r[0] for r in recs], np.float32)
+    b = np.array([r[1] for r in recs], np.int64).reshape(n, 4)
+    area = (b[:, 1] - b[:, 0] + 1) * (b[:, 3] - b[:, 2] + 1)
+    order = sorted(range(n), key=lambda i: (-float(conf[i]), i))
+    alive = np.ones(n, bool)
+    pick = []
+    for pos, i in enumerate(order):
+        if not alive[i]:
+            continue
+        pick.append(i)
+        rest = np.array([j for j in order[pos + 1:] if alive[j]], np.int64)
+        if rest.size == 0:
+            continue
+        w = np.maximum(0, np.minimum(b[i, 1], b[rest, 1]) - np.maximum(b[i, 0], b[rest, 0]) + 1)
+        h = np.maximum(0, np.minimum(b[i, 3], b[rest, 3]) - np.maximum(b[i, 2], b[rest, 2]) + 1)
+        inter = w * h
+        union = area[i] + area[rest] - inter
+        alive[rest[inter / union > thr]] = False
+    return pick
+
+
+def suppress_list(recs, thr=0.45):
+    """suppress_overlaps (ssdutils.py:310-318) on (confidence, labelid, (xmin, xmax, ymin, ymax)) records: classes in
+    first-appearance order of the list (defaultdict), nms_list per class.  Returns positions into recs."""
+    groups = {}
+    for i, r in enumerate(recs):
+        groups.setdefault(r[1], []).append(i)
+    out = []
+    for members in groups.values():
+        out.extend(members[k] for k in nms_list([(recs[i][0], recs[i][2]) for i in members], thr))
+    return out
+
+
 def suppress(det, max_out=None):
     """suppress_overlaps (ssdutils.py:310-318) on a decode() result: classes in
     first-appearance order, each class's keeps in descending confidence; then

@@ -112,6 +112,35 @@ def init_params(preset, num_classes=20, seed=42, bias_scale=0.0, alive=False):
     return out
 
 
+def init_params_lib(preset, num_classes=20, seed=42):
+    """The weights libssdvgg_hip.so itself starts from (csrc/net.hip Net::init_weights: Xavier-uniform filters drawn
+    from a splitmix64 stream in arena order, zero biases, scale 20) restated in numpy, so that the oracle can be run
+    on exactly the benchmark's configuration.  tests/test_gpu_model.py checks it bit for bit against the library."""
+    shapes = param_shapes(preset, num_classes)
+    out = {}
+    state = (np.uint64(seed) * np.uint64(0x2545F4914F6CDD1D) + np.uint64(1))
+    gold = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over='ignore'):
+        for name, shp in shapes.items():
+            if name.endswith('/filter'):
+                kh, kw, ci, co = shp
+                n = kh * kw * ci * co
+                s = state + gold * np.arange(1, n + 1, dtype=np.uint64)
+                state = s[-1]
+                z = s.copy()
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                z ^= z >> np.uint64(31)
+                u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+                lim = math.sqrt(6.0 / (float(kh * kw * ci) + float(kh * kw * co)))
+                out[name] = ((u * 2.0 - 1.0) * lim).astype(np.float32).reshape(shp)
+            elif name.endswith('/scale'):
+                out[name] = np.full(shp, 20.0, np.float32)
+            else:
+                out[name] = np.zeros(shp, np.float32)
+    return out
+
+
 def graph(preset):
     """The layer graph as data, for layer-local checks: list of ops
     ('conv', name, input, k, stride, padding, dilation) | ('pool', name, input, k, stride) |

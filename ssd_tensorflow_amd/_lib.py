@@ -81,6 +81,8 @@ SIGNATURES = {
     'ssd_backward_begin_dev': (i32, [handle, vp, i32]),
     'ssd_backward_next_dev': (i32, [handle, sz, i32, C.POINTER(sz), C.POINTER(sz), p_i32]),
     'ssd_set_wgrad_stream': (i32, [handle, vp]),
+    'ssd_set_loss_normalizer': (i32, [handle, f32]),
+    'ssd_null_gradients_dev': (i32, [handle]),
     'ssd_train_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_eval_step_dev': (i32, [handle, vp, vp, i32]),
     'ssd_infer_dev': (i32, [handle, vp, i32]),
@@ -90,6 +92,9 @@ SIGNATURES = {
     'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'ssd_detect_last_dev': (i32, [handle, i32, f32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    'ssd_detect_fetch': (i32, [handle, i32, vp, vp, vp, vp, vp]),
+    'ssd_nms_boxes': (i32, [i32, i32, vp, vp, vp, C.c_double, vp, p_i32]),
     'ssd_set_overlap': (i32, [handle, i32]),
     'ssd_profile_enable': (i32, [handle, i32]),
     'ssd_profile_report': (i32, [handle, C.c_char_p, sz]),
@@ -118,6 +123,21 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)        # AttributeError here = the .so does not export a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+# GPU ordinal of the free functions (anchors, label encoding, decode + NMS, AP).  One per process, like the
+# handle-owning SSDVGG's Session.device; a multi-GPU driver sets it once to its LOCAL_RANK (train.py does).
+# Every C entry point makes its GPU current for the call only and restores the caller's device.
+_device = 0
+
+
+def set_device(device):
+    global _device
+    _device = int(device)
+
+
+def device():
+    return _device
 
 
 def last_error():

@@ -4,11 +4,11 @@ from collections import defaultdict
 
 import numpy as np
 
+from . import _lib
 from ._lib import lib, check, np_ptr
 from .utils import Size, prop2abs
 
 IMG_SIZE = Size(1000, 1000)
-_DEVICE = 0
 
 
 def APs2mAP(aps):
@@ -59,7 +59,7 @@ class APCalculator:
         gb = np.ascontiguousarray(gb, np.float64).reshape(-1, 4)
         gk = np.ascontiguousarray(gk, np.int32); gs = np.ascontiguousarray(gs, np.int32)
         ap = np.zeros(ncls, np.float64); present = np.zeros(ncls, np.int32)
-        check(lib.ssd_average_precision(_DEVICE, len(dc), np_ptr(db), np_ptr(dc), np_ptr(dk), np_ptr(ds), len(gk), np_ptr(gb),
+        check(lib.ssd_average_precision(_lib.device(), len(dc), np_ptr(db), np_ptr(dc), np_ptr(dk), np_ptr(ds), len(gk), np_ptr(gb),
                                         np_ptr(gk), np_ptr(gs), ncls, float(self.minoverlap), np_ptr(ap), np_ptr(present)))
         return {label: float(ap[k]) for label, k in label_id.items() if present[k]}
 

@@ -4,6 +4,9 @@
 #include "augment.h"
 #include "metrics.h"
 #include <vector>
+#include <map>
+#include <mutex>
+#include <algorithm>
 
 namespace ssd {
 static thread_local std::string g_err;
@@ -66,6 +69,11 @@ static Net& N(ssd_handle h) {
     if (!h || !h->net) fail("null handle");
     return *h->net;
 }
+// handle-based entry points: the handle's GPU is current for the call, the caller's device is restored on return
+#define API_BEGIN_NET(h) \
+    try {                \
+        Net& n = N(h);   \
+        DeviceGuard dev_guard_(n.device());
 
 namespace {
 struct DevBuf {
@@ -74,6 +82,23 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     template <typename T> T* as() { return (T*)p; }
 };
+}  // namespace
+
+// Label encoding is called once per training batch: the anchor tables of a (preset, device) pair and a small
+// growable scratch per device are kept for the life of the process instead of six hipMalloc / hipFree pairs
+// (each one a device synchronisation) per call.
+namespace {
+struct EncodeCache {
+    struct Anchors { double* anc = nullptr; int* aabs = nullptr; };
+    struct Scratch { char* p = nullptr; size_t bytes = 0; };
+    std::mutex mu;
+    std::map<std::pair<std::string, int>, Anchors> anchors;
+    std::map<int, Scratch> scratch;
+};
+EncodeCache& encode_cache() {
+    static EncodeCache* c = new EncodeCache();      // leaked on purpose: no HIP calls in static destructors
+    return *c;
+}
 }  // namespace
 
 extern "C" {
@@ -109,7 +134,7 @@ int ssd_anchors_dev(const char* preset, double* anchors_dev, int* anchors_abs_de
 
 static void anchors_host(const char* preset, int device, double* out, int* out_abs) {
     const Preset& p = get_preset(preset);
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard dev_guard_(device);
     const size_t A = p.num_anchors;
     DevBuf a(A * 4 * sizeof(double)), b(A * 4 * sizeof(int));
     anchors_device(p, a.as<double>(), b.as<int>(), nullptr);
@@ -133,7 +158,7 @@ int ssd_jaccard_overlap(int device, const double* box, const double* boxes, int 
     API_BEGIN
     SSD_REQUIRE(n >= 0, "n must be >= 0");
     if (n > 0) {
-        HIP_OK(hipSetDevice(device));
+        DeviceGuard dev_guard_(device);
         DevBuf db(4 * sizeof(double)), da((size_t)n * 4 * sizeof(double)), di((size_t)n * sizeof(double));
         HIP_OK(hipMemcpy(db.p, box, 4 * sizeof(double), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(da.p, boxes, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice));
@@ -148,28 +173,46 @@ static void encode_labels_impl(const char* preset, int num_classes, int device, 
     const Preset& p = get_preset(preset);
     SSD_REQUIRE(b >= 1, "batch must be >= 1");
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27");
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard dev_guard_(device);
     const int ntot = offsets[b];
     SSD_REQUIRE(offsets[0] == 0 && ntot >= 0, "gt_offsets must start at 0 and be non-decreasing");
     for (int i = 0; i < ntot; ++i)
         SSD_REQUIRE(cls[i] >= 0 && cls[i] < num_classes, "gt_cls[%d] = %d outside 0..%d", i, cls[i], num_classes - 1);
     const size_t A = p.num_anchors;
-    DevBuf anc(A * 4 * sizeof(double)), aabs(A * 4 * sizeof(int));
-    DevBuf dgt((size_t)(ntot ? ntot : 1) * 4 * sizeof(double)), dcls((size_t)(ntot ? ntot : 1) * sizeof(int));
-    DevBuf doff((size_t)(b + 1) * sizeof(int)), ws(encode_labels_ws_bytes(ntot));
-    anchors_device(p, anc.as<double>(), aabs.as<int>(), s);
-    if (ntot) {
-        HIP_OK(hipMemcpyAsync(dgt.p, gt, (size_t)ntot * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dcls.p, cls, (size_t)ntot * sizeof(int), hipMemcpyHostToDevice, s));
+    EncodeCache& ec = encode_cache();
+    std::lock_guard<std::mutex> lock(ec.mu);
+    EncodeCache::Anchors& an = ec.anchors[{p.name, device}];
+    if (!an.anc) {
+        HIP_OK(hipMalloc((void**)&an.anc, A * 4 * sizeof(double)));
+        HIP_OK(hipMalloc((void**)&an.aabs, A * 4 * sizeof(int)));
+        anchors_device(p, an.anc, an.aabs, nullptr);
+        HIP_OK(hipDeviceSynchronize());
     }
-    HIP_OK(hipMemcpyAsync(doff.p, offsets, (size_t)(b + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    const size_t nt = ntot ? ntot : 1;
     const size_t n = (size_t)b * A * (num_classes + 5);
-    DevBuf tmp(vec_dev ? 16 : n * sizeof(float));
-    float* out = vec_dev ? vec_dev : tmp.as<float>();
-    encode_labels(p, num_classes, anc.as<double>(), aabs.as<int>(), dgt.as<double>(), dcls.as<int>(), doff.as<int>(), b, ntot,
-                  out, ws.p, s);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_gt = 0, o_cls = o_gt + up(nt * 4 * sizeof(double)), o_off = o_cls + up(nt * sizeof(int)),
+                 o_ws = o_off + up((size_t)(b + 1) * sizeof(int)), o_tmp = o_ws + up(encode_labels_ws_bytes(ntot)),
+                 need = o_tmp + (vec_dev ? 0 : n * sizeof(float));
+    EncodeCache::Scratch& sc = ec.scratch[device];
+    if (need > sc.bytes) {
+        if (sc.p) HIP_OK(hipFree(sc.p));
+        sc.p = nullptr; sc.bytes = 0;
+        HIP_OK(hipMalloc((void**)&sc.p, need));
+        sc.bytes = need;
+    }
+    double* dgt = (double*)(sc.p + o_gt);
+    int* dcls = (int*)(sc.p + o_cls);
+    int* doff = (int*)(sc.p + o_off);
+    if (ntot) {
+        HIP_OK(hipMemcpyAsync(dgt, gt, (size_t)ntot * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(dcls, cls, (size_t)ntot * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    HIP_OK(hipMemcpyAsync(doff, offsets, (size_t)(b + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    float* out = vec_dev ? vec_dev : (float*)(sc.p + o_tmp);
+    encode_labels(p, num_classes, an.anc, an.aabs, dgt, dcls, doff, b, ntot, out, sc.p + o_ws, s);
     if (vec_host) HIP_OK(hipMemcpyAsync(vec_host, out, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));     // temporaries die here
+    HIP_OK(hipStreamSynchronize(s));     // the shared scratch is free for the next call
 }
 
 int ssd_encode_labels(const char* preset, int num_classes, int device, const double* gt_boxes, const int* gt_cls,
@@ -211,7 +254,7 @@ int ssd_decode_nms(const char* preset, int num_classes, int device, const float*
     API_BEGIN
     const Preset& p = get_preset(preset);
     SSD_REQUIRE(b >= 1 && out_cap >= 1, "batch and out_cap must be >= 1");
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard dev_guard_(device);
     const size_t A = p.num_anchors, nv = num_classes + 5, n = (size_t)b * out_cap;
     DevBuf anc(A * 4 * sizeof(double)), dpred((size_t)b * A * nv * sizeof(float)), ws(detect_ws_bytes(b, (int)A));
     DevBuf dcount((size_t)b * 4), dconf(n * 4), dcls(n * 4), didx(n * 4), dbox(n * 16);
@@ -227,13 +270,42 @@ int ssd_decode_nms(const char* preset, int num_classes, int device, const float*
     API_END
 }
 
+int ssd_nms_boxes(int device, int n, const int* box_abs, const float* conf, const int* group, double iou_thr, int* keep_out,
+                  int* n_keep) {
+    API_BEGIN
+    SSD_REQUIRE(n >= 0 && n <= 65535, "ssd_nms_boxes: 0..65535 boxes (got %d)", n);
+    SSD_REQUIRE(n_keep != nullptr, "n_keep is null");
+    *n_keep = 0;
+    if (n > 0) {
+        SSD_REQUIRE(box_abs && conf && keep_out, "null argument");
+        int ngroups = 1;
+        if (group)
+            for (int i = 0; i < n; ++i) {
+                SSD_REQUIRE(group[i] >= 0 && group[i] < 65535, "group[%d] = %d outside 0..65534", i, group[i]);
+                ngroups = std::max(ngroups, group[i] + 1);
+            }
+        DeviceGuard dev_guard_(device);
+        DevBuf dbox((size_t)n * 16), dconf((size_t)n * 4), dgrp((size_t)n * 4), dkeep((size_t)n * 4 + 4), ws(nms_boxes_ws_bytes(n, ngroups));
+        HIP_OK(hipMemcpy(dbox.p, box_abs, (size_t)n * 16, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dconf.p, conf, (size_t)n * 4, hipMemcpyHostToDevice));
+        if (group) HIP_OK(hipMemcpy(dgrp.p, group, (size_t)n * 4, hipMemcpyHostToDevice));
+        else HIP_OK(hipMemset(dgrp.p, 0, (size_t)n * 4));
+        nms_boxes_device(n, ngroups, dbox.as<int>(), dconf.as<float>(), dgrp.as<int>(), iou_thr, dkeep.as<int>(), ws.p, nullptr);
+        std::vector<int> tmp((size_t)n + 1);
+        HIP_OK(hipMemcpy(tmp.data(), dkeep.p, (size_t)n * 4 + 4, hipMemcpyDeviceToHost));
+        *n_keep = tmp[0];
+        for (int i = 0; i < tmp[0]; ++i) keep_out[i] = tmp[1 + i];
+    }
+    API_END
+}
+
 int ssd_average_precision(int device, int n_det, const float* det_box, const float* det_conf, const int* det_cls,
                           const int* det_sample, int n_gt, const double* gt_box, const int* gt_cls, const int* gt_sample,
                           int num_classes, double minoverlap, double* ap_out, int* present_out) {
     API_BEGIN
     SSD_REQUIRE(num_classes >= 1 && n_det >= 0 && n_gt >= 0, "bad sizes");
     for (int g = 1; g < n_gt; ++g) SSD_REQUIRE(gt_sample[g] >= gt_sample[g - 1], "ground truth must be grouped by ascending sample id");
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard dev_guard_(device);
     int n2 = 1;
     while (n2 < n_det) n2 <<= 1;
     const size_t nd = n_det ? n_det : 1, ng = n_gt ? n_gt : 1;
@@ -283,6 +355,7 @@ int ssd_create(const char* preset, int num_classes, int max_batch, int device, i
     API_BEGIN
     SSD_REQUIRE(out != nullptr, "out handle pointer is null");
     *out = nullptr;
+    DeviceGuard dev_guard_(device);
     Net* n = new Net(preset, num_classes, max_batch, device, training != 0, seed, ext_params_dev, ext_grads_dev,
                      ext_momentum_dev);
     SSD_REQUIRE(n->nparams() == Net::arena_floats(preset, num_classes), "arena size mismatch");
@@ -295,6 +368,7 @@ int ssd_create_dtype(const char* preset, int num_classes, int max_batch, int dev
     API_BEGIN
     SSD_REQUIRE(out != nullptr, "out handle pointer is null");
     *out = nullptr;
+    DeviceGuard dev_guard_(device);
     Net* n = new Net(preset, num_classes, max_batch, device, training != 0, seed, ext_params_dev, ext_grads_dev,
                      ext_momentum_dev, dtype);
     SSD_REQUIRE(n->nparams() == Net::arena_floats(preset, num_classes), "arena size mismatch");
@@ -303,9 +377,9 @@ int ssd_create_dtype(const char* preset, int num_classes, int max_batch, int dev
 }
 
 int ssd_get_dtype(ssd_handle h, int* dtype) {
-    API_BEGIN
+    API_BEGIN_NET(h)
     SSD_REQUIRE(h != nullptr && dtype != nullptr, "null argument");
-    *dtype = h->net->dtype();
+    *dtype = n.dtype();
     API_END
 }
 
@@ -319,8 +393,8 @@ int ssd_destroy(ssd_handle h) {
 }
 
 int ssd_set_stream(ssd_handle h, void* stream) {
-    API_BEGIN
-    N(h).set_stream((hipStream_t)stream);
+    API_BEGIN_NET(h)
+    n.set_stream((hipStream_t)stream);
     API_END
 }
 
@@ -334,8 +408,8 @@ int ssd_num_variables(ssd_handle h) {
 }
 
 int ssd_variable_info(ssd_handle h, int i, char* name, int name_cap, int* ndim, int shape[4]) {
-    API_BEGIN
-    const auto& vars = N(h).variables();
+    API_BEGIN_NET(h)
+    const auto& vars = n.variables();
     SSD_REQUIRE(i >= 0 && i < (int)vars.size(), "variable index %d outside 0..%zu", i, vars.size() - 1);
     const Variable& v = vars[i];
     if (name && name_cap > 0) snprintf(name, name_cap, "%s", v.name.c_str());
@@ -345,126 +419,133 @@ int ssd_variable_info(ssd_handle h, int i, char* name, int name_cap, int* ndim, 
 }
 
 int ssd_load_variable(ssd_handle h, const char* name, const float* data, size_t count) {
-    API_BEGIN
-    N(h).load_variable(name, data, count, 0);
+    API_BEGIN_NET(h)
+    n.load_variable(name, data, count, 0);
     API_END
 }
 int ssd_save_variable(ssd_handle h, const char* name, float* data, size_t count) {
-    API_BEGIN
-    N(h).save_variable(name, data, count, 0);
+    API_BEGIN_NET(h)
+    n.save_variable(name, data, count, 0);
     API_END
 }
 int ssd_save_gradient(ssd_handle h, const char* name, float* data, size_t count) {
-    API_BEGIN
-    N(h).save_variable(name, data, count, 1);
+    API_BEGIN_NET(h)
+    n.save_variable(name, data, count, 1);
     API_END
 }
 int ssd_save_momentum(ssd_handle h, const char* name, float* data, size_t count) {
-    API_BEGIN
-    N(h).save_variable(name, data, count, 2);
+    API_BEGIN_NET(h)
+    n.save_variable(name, data, count, 2);
     API_END
 }
 int ssd_load_momentum(ssd_handle h, const char* name, const float* data, size_t count) {
-    API_BEGIN
-    N(h).load_variable(name, data, count, 2);
+    API_BEGIN_NET(h)
+    n.load_variable(name, data, count, 2);
     API_END
 }
 
 int ssd_set_optimizer(ssd_handle h, const float* lr_values, const long long* lr_boundaries, int n_values, float momentum,
                       float weight_decay) {
-    API_BEGIN
-    N(h).set_optimizer(lr_values, lr_boundaries, n_values, momentum, weight_decay);
+    API_BEGIN_NET(h)
+    n.set_optimizer(lr_values, lr_boundaries, n_values, momentum, weight_decay);
     API_END
 }
 int ssd_get_global_step(ssd_handle h, long long* step) {
-    API_BEGIN
-    *step = N(h).global_step;
+    API_BEGIN_NET(h)
+    *step = n.global_step;
     API_END
 }
 int ssd_set_global_step(ssd_handle h, long long step) {
-    API_BEGIN
-    N(h).global_step = step;
+    API_BEGIN_NET(h)
+    n.global_step = step;
     API_END
 }
 
 int ssd_forward_backward_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     n.forward(x_dev, b, true, y_dev);
     n.backward(b, y_dev);
     API_END
 }
 int ssd_forward_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
-    API_BEGIN
-    N(h).forward(x_dev, b, true, y_dev);
+    API_BEGIN_NET(h)
+    n.forward(x_dev, b, true, y_dev);
     API_END
 }
 int ssd_backward_begin_dev(ssd_handle h, const float* y_dev, int b) {
-    API_BEGIN
-    N(h).backward_begin(b, y_dev);
+    API_BEGIN_NET(h)
+    n.backward_begin(b, y_dev);
     API_END
 }
 int ssd_backward_next_dev(ssd_handle h, size_t min_floats, int sync_main, size_t* offset, size_t* count, int* more) {
-    API_BEGIN
+    API_BEGIN_NET(h)
     SSD_REQUIRE(offset && count && more, "null output pointer");
-    *more = N(h).backward_step(min_floats, offset, count, sync_main != 0) ? 1 : 0;
+    *more = n.backward_step(min_floats, offset, count, sync_main != 0) ? 1 : 0;
     API_END
 }
 int ssd_set_wgrad_stream(ssd_handle h, void* stream) {
-    API_BEGIN
-    N(h).set_wgrad_stream((hipStream_t)stream);
+    API_BEGIN_NET(h)
+    n.set_wgrad_stream((hipStream_t)stream);
     API_END
 }
 int ssd_apply_gradients_dev(ssd_handle h, float grad_scale) {
-    API_BEGIN
-    N(h).apply_gradients(grad_scale);
+    API_BEGIN_NET(h)
+    n.apply_gradients(grad_scale);
+    API_END
+}
+int ssd_set_loss_normalizer(ssd_handle h, float batch) {
+    API_BEGIN_NET(h)
+    n.set_loss_normalizer(batch);
+    API_END
+}
+int ssd_null_gradients_dev(ssd_handle h) {
+    API_BEGIN_NET(h)
+    n.null_gradients_step();
     API_END
 }
 int ssd_train_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     n.forward(x_dev, b, true, y_dev);
     n.backward(b, y_dev);
     n.apply_gradients(1.f);
     API_END
 }
 int ssd_eval_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
-    API_BEGIN
-    N(h).forward(x_dev, b, true, y_dev);
+    API_BEGIN_NET(h)
+    n.forward(x_dev, b, true, y_dev);
     API_END
 }
 int ssd_infer_dev(ssd_handle h, const float* x_dev, int b) {
-    API_BEGIN
-    N(h).forward(x_dev, b, false, nullptr);
+    API_BEGIN_NET(h)
+    n.forward(x_dev, b, false, nullptr);
     API_END
 }
 int ssd_result_dev(ssd_handle h, const float** result_dev) {
-    API_BEGIN
-    *result_dev = N(h).result();
+    API_BEGIN_NET(h)
+    *result_dev = n.result();
     API_END
 }
 int ssd_set_result_dev(ssd_handle h, const float* pred_dev, int b) {
-    API_BEGIN
-    N(h).set_result(pred_dev, b);
+    API_BEGIN_NET(h)
+    n.set_result(pred_dev, b);
     API_END
 }
 int ssd_get_result(ssd_handle h, int b, float* result_out) {
-    API_BEGIN
+    API_BEGIN_NET(h)
     SSD_REQUIRE(h != nullptr && result_out != nullptr, "null argument");
-    SSD_REQUIRE(b >= 1 && b <= h->net->max_batch(), "batch %d outside 1..%d", b, h->net->max_batch());
-    h->net->copy_result(result_out, b);
+    SSD_REQUIRE(b >= 1 && b <= n.max_batch(), "batch %d outside 1..%d", b, n.max_batch());
+    n.copy_result(result_out, b);
     API_END
 }
 
 int ssd_get_losses(ssd_handle h, float losses_out[4]) {
-    API_BEGIN
-    N(h).get_losses(losses_out);
+    API_BEGIN_NET(h)
+    n.get_losses(losses_out);
     API_END
 }
 int ssd_arenas(ssd_handle h, float** params_dev, float** grads_dev, float** momentum_dev, size_t* floats,
                size_t* filter_floats) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     if (params_dev) *params_dev = n.params();
     if (grads_dev) *grads_dev = n.grads();
     if (momentum_dev) *momentum_dev = n.momentum();
@@ -474,8 +555,7 @@ int ssd_arenas(ssd_handle h, float** params_dev, float** grads_dev, float** mome
 }
 
 int ssd_train_step(ssd_handle h, const float* x, const float* y, int b, float* result_out, float losses_out[4]) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     n.upload_xy(x, y, b);
     n.forward(n.x_stage(), b, true, n.y_stage());
     n.backward(b, n.y_stage());
@@ -486,8 +566,7 @@ int ssd_train_step(ssd_handle h, const float* x, const float* y, int b, float* r
     API_END
 }
 int ssd_eval_step(ssd_handle h, const float* x, const float* y, int b, float* result_out, float losses_out[4]) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     n.upload_xy(x, y, b);
     n.forward(n.x_stage(), b, true, n.y_stage());
     if (result_out) n.copy_result(result_out, b);
@@ -496,8 +575,7 @@ int ssd_eval_step(ssd_handle h, const float* x, const float* y, int b, float* re
     API_END
 }
 int ssd_infer(ssd_handle h, const float* x, int b, float* result_out) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     n.upload_xy(x, nullptr, b);
     n.forward(n.x_stage(), b, false, nullptr);
     if (result_out) n.copy_result(result_out, b);
@@ -507,29 +585,47 @@ int ssd_infer(ssd_handle h, const float* x, int b, float* result_out) {
 
 int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, int out_cap, int nms, int* count, float* conf,
                     int* cls, int* idx, int* box) {
-    API_BEGIN
-    N(h).detect_last(b, conf_thr, cap, max_out, out_cap, nms != 0, count, conf, cls, idx, box);
+    API_BEGIN_NET(h)
+    n.detect_last(b, conf_thr, cap, max_out, out_cap, nms != 0, count, conf, cls, idx, box);
+    API_END
+}
+
+int ssd_detect_last_dev(ssd_handle h, int b, float conf_thr, int cap, int max_out, int out_cap, int nms, int** count_dev,
+                        float** conf_dev, int** cls_dev, int** idx_dev, int** box_dev) {
+    API_BEGIN_NET(h)
+    DetectOut d{};
+    n.detect_last_dev(b, conf_thr, cap, max_out, out_cap, nms != 0, &d);
+    if (count_dev) *count_dev = d.count;
+    if (conf_dev) *conf_dev = d.conf;
+    if (cls_dev) *cls_dev = d.cls;
+    if (idx_dev) *idx_dev = d.idx;
+    if (box_dev) *box_dev = d.box;
+    API_END
+}
+
+int ssd_detect_fetch(ssd_handle h, int which, int* count, float* conf, int* cls, int* idx, int* box) {
+    API_BEGIN_NET(h)
+    n.detect_fetch(which, count, conf, cls, idx, box);
     API_END
 }
 
 int ssd_set_overlap(ssd_handle h, int on) {
-    API_BEGIN
-    N(h).set_overlap(on != 0);
+    API_BEGIN_NET(h)
+    n.set_overlap(on != 0);
     API_END
 }
 
 int ssd_profile_enable(ssd_handle h, int on) {
-    API_BEGIN
-    N(h).profiler().on = on != 0;
-    N(h).profiler().detailed = on == 2;
-    N(h).profiler().reset();
+    API_BEGIN_NET(h)
+    n.profiler().on = on != 0;
+    n.profiler().detailed = on == 2;
+    n.profiler().reset();
     API_END
 }
 
 // one line per kernel label: "label\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n"
 int ssd_profile_report(ssd_handle h, char* buf, size_t cap) {
-    API_BEGIN
-    Net& n = N(h);
+    API_BEGIN_NET(h)
     HIP_OK(hipStreamSynchronize(n.stream()));
     struct Agg { long long cnt = 0; double ms = 0, fl = 0, by = 0; };
     std::map<std::string, Agg> agg;
@@ -553,14 +649,14 @@ int ssd_profile_report(ssd_handle h, char* buf, size_t cap) {
 }
 
 int ssd_activation_shape(ssd_handle h, const char* name, int* height, int* width, int* channels) {
-    API_BEGIN
-    N(h).activation_shape(name, height, width, channels);
+    API_BEGIN_NET(h)
+    n.activation_shape(name, height, width, channels);
     API_END
 }
 
 int ssd_activation(ssd_handle h, const char* name, int b, float* out, size_t count) {
-    API_BEGIN
-    N(h).activation(name, b, out, count);
+    API_BEGIN_NET(h)
+    n.activation(name, b, out, count);
     API_END
 }
 

@@ -53,4 +53,10 @@ size_t detect_ws_bytes(int B, int A);
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap,
             int max_out, int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s);
 
+// non_maximum_suppression / suppress_overlaps on an arbitrary list: boxes [n][4] i32 (xmin,xmax,ymin,ymax),
+// conf [n], group [n] (0..ngroups-1); keep [n+1]: keep[0] = count, then the selected input indices in output order.
+size_t nms_boxes_ws_bytes(int n, int ngroups);
+void nms_boxes_device(int n, int ngroups, const int* boxes, const float* conf, const int* group, double thr, int* keep, void* ws,
+                      hipStream_t s);
+
 }  // namespace ssd

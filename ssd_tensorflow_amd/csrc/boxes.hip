@@ -249,21 +249,23 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // =================================================================================
 // Pass 1, HBM-bound: every anchor row [C+5] f32 is read exactly once through LDS (coalesced
 // float4 loads, all issued before the first is consumed; rows are then read at an odd stride:
-// conflict-free).  Every anchor gets one 64-bit sort key, 0 when its confidence is below thr:
+// conflict-free).  Every anchor whose confidence reaches thr becomes one 64-bit sort key
 //   conf bits << 32 | (32767 - anchor) << 8 | 0x80 | class   (descending sort == conf desc, anchor asc)
-// No atomics: the per-image kernel compacts the non-zero keys.
+// appended to its image's candidate list: one integer atomic per wave and image reserves the slots, a
+// ballot prefix places the lanes.  The list order is arbitrary, the keys are unique and pass 2 sorts them,
+// so the result does not depend on it.
 constexpr int SCAN_ROWS = 256;
 constexpr int SCAN_MAXV = 32;                       // nv <= 32
 constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
 
-__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          u64* __restrict__ keys) {
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int A2, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          u64* __restrict__ keys, int* __restrict__ ncand) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
-    const size_t total_rows = (size_t)B * A;
-    const size_t r0 = (size_t)blockIdx.x * SCAN_ROWS;
-    const int nrows = (int)min((size_t)SCAN_ROWS, total_rows - r0);
+    const int total_rows = B * A;
+    const int r0 = blockIdx.x * SCAN_ROWS;
+    const int nrows = min(SCAN_ROWS, total_rows - r0);
     const int nfl = nrows * nv;
-    const float* src = pred + r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
+    const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
     const int n4 = nfl >> 2;
     // all of this thread's loads are issued before the first one is consumed
     float4 v[SCAN_LOADS];
@@ -280,18 +282,35 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, 
     }
     for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
     __syncthreads();
-    // one 64-bit key per anchor, 0 = not a candidate: no atomics, the per-image kernel compacts
-    if ((int)threadIdx.x < nrows) {
+    const int lane = threadIdx.x & 63;
+    const bool valid = (int)threadIdx.x < nrows;
+    u64 key = 0ull;
+    int img = 0;
+    if (valid) {
         const float* r = rows + (size_t)threadIdx.x * nv;
         const int nfg = nv - 5;                  // argmax excludes the background class
         int best = 0;
         float conf = r[0];
         for (int c = 1; c < nfg; ++c)
             if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-        const size_t row = r0 + threadIdx.x;
-        const int a = (int)(row % A);
-        const bool cand = !(conf < thr);         // the reference breaks at the first conf < thr
-        keys[row] = cand ? (((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7)) : 0ull;
+        const int row = r0 + threadIdx.x;
+        img = row / A;
+        const int a = row - img * A;
+        if (!(conf < thr))                        // the reference breaks at the first conf < thr
+            key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
+    }
+    // a wave covers 64 consecutive rows: at most two images (A >= SCAN_ROWS)
+    const int img0 = __builtin_amdgcn_readfirstlane(img);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int bb = img0 + pass;
+        const bool mine = key != 0ull && img == bb;
+        const u64 bal = __ballot(mine);
+        if (bal == 0ull) continue;
+        int base = 0;
+        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&ncand[bb], __popcll(bal));
+        base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+        if (mine) keys[(size_t)bb * A2 + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
     }
 }
 
@@ -359,55 +378,204 @@ __device__ __forceinline__ void nms_roundtrip(const int* b, int* o) {
     prop2abs_f64(cx, cy, __ddiv_rn(width, 1000.0), __ddiv_rn(height, 1000.0), o);
 }
 
-constexpr int DET_THREADS = 256;
-constexpr int DET_LDS_KEYS = 2048;       // sort in LDS up to this many keys, else in (L2-resident) global
+// IoU(+1) > 0.45 without a division: 20*inter > 9*union (exact for the integer areas of the 1000 grid)
+__device__ __forceinline__ bool overlaps45(int x0, int x1, int y0, int y1, int area_i, int4 bj) {
+    const int w = max(0, min(x1, bj.y) - max(x0, bj.x) + 1);
+    const int h = max(0, min(y1, bj.w) - max(y0, bj.z) + 1);
+    const int inter = w * h;
+    const int uni = area_i + (bj.y - bj.x + 1) * (bj.w - bj.z + 1) - inter;
+    return 20 * inter > 9 * uni;
+}
+
+// Greedy NMS of one class segment (boxes in descending confidence) by one wave.  Segments of up to 64 boxes
+// live in registers: lane j holds box j, the pivot is broadcast with v_readlane, the survivors are a 64-bit
+// mask; no memory traffic in the loop.  Longer segments walk the boxes in LDS / global.
+__device__ __forceinline__ void nms_segment(const int4* nbox, volatile unsigned char* al, int s0, int len, int lane) {
+    if (len <= 64) {
+        int4 me = make_int4(0, 0, 0, 0);
+        if (lane < len) me = nbox[s0 + lane];
+        u64 alive = len == 64 ? ~0ull : ((1ull << len) - 1ull);
+        for (int i = 0; i < len; ++i) {
+            if (!((alive >> i) & 1ull)) continue;
+            const int x0 = __builtin_amdgcn_readlane(me.x, i), x1 = __builtin_amdgcn_readlane(me.y, i);
+            const int y0 = __builtin_amdgcn_readlane(me.z, i), y1 = __builtin_amdgcn_readlane(me.w, i);
+            const int area_i = (x1 - x0 + 1) * (y1 - y0 + 1);
+            const bool kill = lane > i && lane < len && overlaps45(x0, x1, y0, y1, area_i, me);
+            alive &= ~__ballot(kill);
+        }
+        if (lane < len) al[s0 + lane] = (alive >> lane) & 1ull ? 1 : 0;
+        return;
+    }
+    for (int i = 0; i < len; ++i) {
+        if (!al[s0 + i]) continue;
+        const int4 bi = nbox[s0 + i];
+        const int area_i = (bi.y - bi.x + 1) * (bi.w - bi.z + 1);
+        for (int j = i + 1 + lane; j < len; j += 64) {
+            if (!al[s0 + j]) continue;
+            if (overlaps45(bi.x, bi.y, bi.z, bi.w, area_i, nbox[s0 + j])) al[s0 + j] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+constexpr int DET_THREADS = 512;
+constexpr int DET_WAVES = DET_THREADS / 64;
+constexpr int DET_FAST = 1024;           // up to this many candidates the whole image is handled in LDS
+constexpr int DET_LDS_KEYS = 2048;       // general path: sort in LDS up to this many keys, else in (L2-resident) global
 constexpr int DET_MAX_ALIVE = 32768;
+constexpr int DET_SMEM = 50 * 1024;      // carved per path (general: 16 KB keys + 32 KB flags; fast: 49 KB)
+static_assert(DET_SMEM >= DET_FAST * (8 + 8 + 16 + 16 + 1) && DET_SMEM >= DET_LDS_KEYS * 8 + DET_MAX_ALIVE, "LDS carve");
 
 struct DetectArgs {
     int A, A2, nv, B;
     const double* anchors;
     const float* pred;
     int cap, max_out, out_cap, do_nms;
-    const u64* dense;   // [B][A] one key per anchor, 0 = below the threshold
-    u64* keys1;
+    const int* ncand;   // [B] candidates per image
+    u64* keys1;         // [B][A2] candidate keys (unordered on entry)
     u64* keys2;
     int* box;       // [B][A][4]
     int* nbox;      // [B][A][4]
     DetectOut out;
 };
 
-__global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p) {
-    __shared__ u64 lkeys[DET_LDS_KEYS];
-    __shared__ unsigned char alive[DET_MAX_ALIVE];
-    __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
-    __shared__ int s_npresent, s_wtot[DET_THREADS / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    u64* g1 = p.keys1 + (size_t)b * p.A2;
-    // ---- compact the image's candidates (non-zero keys of the dense per-anchor array) ---------
-    int n = 0;
-    {
-        const u64* dense = p.dense + (size_t)b * p.A;
-        const int lane0 = tid & 63, wv0 = tid >> 6;
-        for (int a0 = 0; a0 < p.A; a0 += DET_THREADS) {
-            const int a = a0 + tid;
-            const u64 key = a < p.A ? dense[a] : 0ull;
-            const u64 bal = __ballot(key != 0ull);
-            if (lane0 == 0) s_wtot[wv0] = __popcll(bal);
-            __syncthreads();
-            int base = n, tot = 0;
+// survivors in order -> the caller's arrays, clipped to [:max_out] / out_cap
+template <typename KeyAt, typename BoxAt>
+__device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, const volatile unsigned char* alive, KeyAt key_at,
+                                            BoxAt box_at, int* s_wtot) {
+    const int tid = threadIdx.x;
+    int limit = p.out_cap;
+    if (p.max_out >= 0 && p.max_out < limit) limit = p.max_out;
+    const int lane = tid & 63, wv = tid >> 6;
+    int total = 0;
+    for (int q0 = 0; q0 < m; q0 += DET_THREADS) {
+        const int q = q0 + tid;
+        const bool keep = q < m && alive[q];
+        const u64 bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = total, tot = 0;
 #pragma unroll
-            for (int i = 0; i < DET_THREADS / 64; ++i) {
-                if (i < wv0) base += s_wtot[i];
-                tot += s_wtot[i];
-            }
-            if (key != 0ull) g1[base + __popcll(bal & ((1ull << lane0) - 1ull))] = key;
-            n += tot;
-            __syncthreads();
+        for (int i = 0; i < DET_WAVES; ++i) {
+            if (i < wv) wbase += s_wtot[i];
+            tot += s_wtot[i];
         }
+        const int o = wbase + before;
+        if (keep && o < limit) {
+            const u64 key = key_at(q);
+            const size_t dst = (size_t)b * p.out_cap + o;
+            p.out.conf[dst] = __uint_as_float((unsigned)(key >> 32));
+            p.out.cls[dst] = (int)(key & 31ull);
+            p.out.idx[dst] = 32767 - (int)((key >> 8) & 0xFFFFull);
+            *reinterpret_cast<int4*>(p.out.box + dst * 4) = box_at(q);
+        }
+        total += tot;
+        __syncthreads();
     }
+    if (tid == 0) p.out.count[b] = p.max_out >= 0 ? min(total, p.max_out) : total;
+}
+
+__global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DET_SMEM];
+    __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
+    __shared__ int s_npresent, s_wtot[DET_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    u64* g1 = p.keys1 + (size_t)b * p.A2;
+    const int n = min(p.ncand[b], p.A);
+
+    if (n <= DET_FAST) {
+        // ================= everything in LDS: rank sort, decode, NMS, emit =================
+        u64* skey = reinterpret_cast<u64*>(smem);                       // candidates as listed
+        u64* okey = skey + DET_FAST;                                    // candidates in output order
+        int4* box = reinterpret_cast<int4*>(okey + DET_FAST);
+        int4* nbox = box + DET_FAST;
+        volatile unsigned char* alive = reinterpret_cast<unsigned char*>(nbox + DET_FAST);
+        for (int i = tid; i < n; i += DET_THREADS) skey[i] = g1[i];
+        if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
+        __syncthreads();
+        // rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and
+        // among those of its own class, in one sweep over the list (each read is an LDS broadcast)
+        constexpr int PER = DET_FAST / DET_THREADS;
+        u64 mykey[PER];
+        int pos[PER], cpos[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int i = tid + DET_THREADS * r;
+            mykey[r] = i < n ? skey[i] : ~0ull;
+            pos[r] = cpos[r] = 0;
+        }
+        for (int j = 0; j < n; ++j) {
+            const u64 kj = skey[j];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const bool gt = kj > mykey[r];
+                pos[r] += gt ? 1 : 0;
+                cpos[r] += (gt && ((kj ^ mykey[r]) & 31ull) == 0ull) ? 1 : 0;
+            }
+        }
+        const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
+        // class groups in first-appearance order (defaultdict, ssdutils.py:311-314)
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int i = tid + DET_THREADS * r;
+            if (i < n && pos[r] < m) {
+                const int c = (int)(mykey[r] & 31ull);
+                atomicMin(&firstpos[c], pos[r]);
+                atomicAdd(&ccount[c], 1);
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            int r = 0;
+            for (int c = 0; c < 32; ++c)
+                if (firstpos[c] < firstpos[tid]) ++r;
+            crank[tid] = r;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int np = 0;
+            if (p.do_nms) {     // decode-only mode: one group in confidence order, no suppression
+                for (int c = 0; c < 32; ++c)
+                    if (firstpos[c] != INT_MAX) { order_cls[crank[c]] = c; ++np; }
+                int acc = 0;
+                for (int r = 0; r < np; ++r) { segstart[r] = acc; acc += ccount[order_cls[r]]; }
+                segstart[np] = acc;
+            }
+            s_npresent = np;
+        }
+        __syncthreads();
+        // place, decode
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int i = tid + DET_THREADS * r;
+            if (i < n && pos[r] < m) {
+                const u64 key = mykey[r];
+                const int q = p.do_nms ? segstart[crank[(int)(key & 31ull)]] + cpos[r] : pos[r];
+                const int a = 32767 - (int)((key >> 8) & 0xFFFFull);
+                int bx[4], nb[4];
+                decode_box(p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4), p.anchors + (size_t)a * 4, bx);
+                nms_roundtrip(bx, nb);
+                okey[q] = key;
+                box[q] = make_int4(bx[0], bx[1], bx[2], bx[3]);
+                nbox[q] = make_int4(nb[0], nb[1], nb[2], nb[3]);
+                alive[q] = 1;
+            }
+        }
+        __syncthreads();
+        for (int r = wave; r < s_npresent; r += DET_WAVES) nms_segment(nbox, alive, segstart[r], segstart[r + 1] - segstart[r], lane);
+        __syncthreads();
+        detect_emit(p, b, m, alive, [&](int q) { return okey[q]; }, [&](int q) { return box[q]; }, s_wtot);
+        return;
+    }
+
+    // ================= general path: bitonic sorts, boxes in (L2-resident) global memory =================
+    u64* lkeys = reinterpret_cast<u64*>(smem);
+    volatile unsigned char* alive = smem + DET_LDS_KEYS * 8;
     u64* g2 = p.keys2 + (size_t)b * p.A2;
-    int* box = p.box + (size_t)b * p.A * 4;
-    int* nbox = p.nbox + (size_t)b * p.A * 4;
+    int4* box = reinterpret_cast<int4*>(p.box + (size_t)b * p.A * 4);
+    int4* nbox = reinterpret_cast<int4*>(p.nbox + (size_t)b * p.A * 4);
 
     // ---- sort 1: confidence descending, anchor ascending ------------------------------
     const int n2 = next_pow2(n > 1 ? n : 1);
@@ -472,71 +640,18 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         int bx[4], nb[4];
         decode_box(p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4), p.anchors + (size_t)a * 4, bx);
         nms_roundtrip(bx, nb);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { box[q * 4 + e] = bx[e]; nbox[q * 4 + e] = nb[e]; }
+        box[q] = make_int4(bx[0], bx[1], bx[2], bx[3]);
+        nbox[q] = make_int4(nb[0], nb[1], nb[2], nb[3]);
         if (q < DET_MAX_ALIVE) alive[q] = 1;
     }
     __syncthreads();
 
-    // ---- greedy NMS: one wave per class segment; IoU(+1) > 0.45 as 20*inter > 9*union ---
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        volatile unsigned char* al = alive;
-        for (int r = wave; r < s_npresent; r += DET_THREADS / 64) {
-            const int s0 = segstart[r], len = segstart[r + 1] - s0;
-            for (int i = 0; i < len; ++i) {
-                if (!al[s0 + i]) continue;
-                const int* bi = nbox + (size_t)(s0 + i) * 4;
-                const int x0 = bi[0], x1 = bi[1], y0 = bi[2], y1 = bi[3];
-                const int area_i = (x1 - x0 + 1) * (y1 - y0 + 1);
-                for (int j = i + 1 + lane; j < len; j += 64) {
-                    if (!al[s0 + j]) continue;
-                    const int* bj = nbox + (size_t)(s0 + j) * 4;
-                    const int w = max(0, min(x1, bj[1]) - max(x0, bj[0]) + 1);
-                    const int h = max(0, min(y1, bj[3]) - max(y0, bj[2]) + 1);
-                    const int inter = w * h;
-                    const int uni = area_i + (bj[1] - bj[0] + 1) * (bj[3] - bj[2] + 1) - inter;
-                    if (20 * inter > 9 * uni) al[s0 + j] = 0;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
+    // ---- greedy NMS: one wave per class segment ---
+    for (int r = wave; r < s_npresent; r += DET_WAVES) nms_segment(nbox, alive, segstart[r], segstart[r + 1] - segstart[r], lane);
     __syncthreads();
 
     // ---- compact survivors in order; the caller's [:max_out] -------------------------------
-    int limit = p.out_cap;
-    if (p.max_out >= 0 && p.max_out < limit) limit = p.max_out;
-    const int lane = tid & 63, wv = tid >> 6;
-    int total = 0;
-    for (int q0 = 0; q0 < m; q0 += DET_THREADS) {
-        const int q = q0 + tid;
-        const bool keep = q < m && alive[q];
-        const u64 bal = __ballot(keep);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wtot[wv] = __popcll(bal);
-        __syncthreads();
-        int wbase = total, tot = 0;
-#pragma unroll
-        for (int i = 0; i < DET_THREADS / 64; ++i) {
-            if (i < wv) wbase += s_wtot[i];
-            tot += s_wtot[i];
-        }
-        const int o = wbase + before;
-        if (keep && o < limit) {
-            const int pos = (int)((~k2[q]) & 0xFFFFFFFFull);
-            const u64 key = g1[pos];
-            const size_t dst = (size_t)b * p.out_cap + o;
-            p.out.conf[dst] = __uint_as_float((unsigned)(key >> 32));
-            p.out.cls[dst] = (int)(key & 31ull);
-            p.out.idx[dst] = 32767 - (int)((key >> 8) & 0xFFFFull);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) p.out.box[dst * 4 + e] = box[q * 4 + e];
-        }
-        total += tot;
-        __syncthreads();
-    }
-    if (tid == 0) p.out.count[b] = p.max_out >= 0 ? min(total, p.max_out) : total;
+    detect_emit(p, b, m, alive, [&](int q) { return g1[(int)((~k2[q]) & 0xFFFFFFFFull)]; }, [&](int q) { return box[q]; }, s_wtot);
 }
 
 static int pow2_ge(int n) {
@@ -545,9 +660,11 @@ static int pow2_ge(int n) {
     return p;
 }
 
+static size_t det_head_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256 + 256; }
+
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
-    return 512 + (size_t)B * A * 8 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
+    return det_head_bytes(B) + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
@@ -556,10 +673,11 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
     SSD_REQUIRE(A >= SCAN_ROWS, "detect: at least %d anchors", SCAN_ROWS);
     SSD_REQUIRE(out_cap >= 1, "detect: out_cap must be >= 1");
+    SSD_REQUIRE((long long)B * A < (1LL << 31), "detect: batch * anchors must stay below 2^31");
     const int nv = num_classes + 5;
     const int A2 = pow2_ge(A);
     char* base = (char*)ws;
-    u64* dense = (u64*)base; base += ((size_t)B * A * 8 + 255) / 256 * 256;
+    int* ncand = (int*)base; base += det_head_bytes(B);
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
     int* box = (int*)base; base += (size_t)B * A * 16;
@@ -568,15 +686,112 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
-        hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                           conf_thr, dense);
+        HIP_OK(hipMemsetAsync(ncand, 0, (size_t)B * 4, s));
+        hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, A2, nv, B, pred,
+                           conf_thr, keys1, ncand);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
-    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.dense = dense;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.ncand = ncand;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
     ProfScope prof("detect_image", 0.0, 0.0, s);
     hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
+    HIP_OK(hipGetLastError());
+}
+
+// =================================================================================
+// non_maximum_suppression / suppress_overlaps on an arbitrary box list (ssdutils.py:232-318)
+// =================================================================================
+// One workgroup: sort by (group ascending, confidence descending, input index ascending), greedy NMS per group
+// (one wave per group, IoU as the reference's f64 quotient against an arbitrary threshold), survivors in order.
+constexpr int NMSB_THREADS = 512;
+
+__device__ __forceinline__ unsigned float_order_bits(float f) {      // monotone map float -> unsigned (any sign)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(NMSB_THREADS) void nms_boxes_kernel(int n, int n2, int ngroups, const int4* __restrict__ boxes,
+                                                                 const float* __restrict__ conf, const int* __restrict__ group,
+                                                                 double thr, u64* __restrict__ keys, int* __restrict__ gstart,
+                                                                 unsigned char* __restrict__ alive, int* __restrict__ keep) {
+    __shared__ int s_wtot[NMSB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n2; i += NMSB_THREADS) {
+        u64 k = 0ull;        // padding sorts last
+        if (i < n) k = ((u64)(65535 - group[i]) << 48) | ((u64)float_order_bits(conf[i]) << 16) | (u64)(65535 - i);
+        keys[i] = k;
+        if (i < n) alive[i] = 1;
+    }
+    for (int g = tid; g <= ngroups; g += NMSB_THREADS) gstart[g] = n;
+    __syncthreads();
+    bitonic_desc(keys, n2);
+    // segment starts: first sorted position of every group (groups without boxes keep the next start)
+    for (int q = tid; q < n; q += NMSB_THREADS) {
+        const int g = 65535 - (int)(keys[q] >> 48);
+        if (q == 0 || (65535 - (int)(keys[q - 1] >> 48)) != g) gstart[g] = q;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int g = ngroups - 1; g >= 0; --g)
+            if (gstart[g] == n) gstart[g] = gstart[g + 1];
+    __syncthreads();
+    volatile unsigned char* al = alive;
+    for (int g = wave; g < ngroups; g += NMSB_THREADS / 64) {
+        const int s0 = gstart[g], len = gstart[g + 1] - s0;
+        for (int i = 0; i < len; ++i) {
+            if (!al[s0 + i]) continue;
+            const int4 bi = boxes[65535 - (int)(keys[s0 + i] & 0xFFFFull)];
+            const long long area_i = (long long)(bi.y - bi.x + 1) * (bi.w - bi.z + 1);
+            for (int j = i + 1 + lane; j < len; j += 64) {
+                if (!al[s0 + j]) continue;
+                const int4 bj = boxes[65535 - (int)(keys[s0 + j] & 0xFFFFull)];
+                const long long w = max(0, min(bi.y, bj.y) - max(bi.x, bj.x) + 1);
+                const long long h = max(0, min(bi.w, bj.w) - max(bi.z, bj.z) + 1);
+                const long long inter = w * h;
+                const long long uni = area_i + (long long)(bj.y - bj.x + 1) * (bj.w - bj.z + 1) - inter;
+                // intersection / union as numpy divides two int64 arrays: IEEE f64 quotient (ssdutils.py:290-292)
+                if (__ddiv_rn((double)inter, (double)uni) > thr) al[s0 + j] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    int total = 0;
+    for (int q0 = 0; q0 < n; q0 += NMSB_THREADS) {
+        const int q = q0 + tid;
+        const bool kp = q < n && alive[q];
+        const u64 bal = __ballot(kp);
+        if (lane == 0) s_wtot[wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = total, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NMSB_THREADS / 64; ++i) {
+            if (i < wave) wbase += s_wtot[i];
+            tot += s_wtot[i];
+        }
+        if (kp) keep[1 + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = 65535 - (int)(keys[q] & 0xFFFFull);
+        total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) keep[0] = total;
+}
+
+size_t nms_boxes_ws_bytes(int n, int ngroups) {
+    const size_t n2 = pow2_ge(n > 1 ? n : 1);
+    return n2 * 8 + ((size_t)(ngroups + 2) * 4 + 15) / 16 * 16 + (size_t)n + 64;
+}
+
+void nms_boxes_device(int n, int ngroups, const int* boxes, const float* conf, const int* group, double thr, int* keep, void* ws,
+                      hipStream_t s) {
+    SSD_REQUIRE(n >= 1 && n <= 65535 && ngroups >= 1 && ngroups <= 65535, "nms_boxes: 1..65535 boxes and groups");
+    const int n2 = pow2_ge(n);
+    char* base = (char*)ws;
+    u64* keys = (u64*)base; base += (size_t)n2 * 8;
+    int* gstart = (int*)base; base += ((size_t)(ngroups + 2) * 4 + 15) / 16 * 16;
+    unsigned char* alive = (unsigned char*)base;
+    hipLaunchKernelGGL(nms_boxes_kernel, dim3(1), dim3(NMSB_THREADS), 0, s, n, n2, ngroups, reinterpret_cast<const int4*>(boxes), conf,
+                       group, thr, keys, gstart, alive, keep);
     HIP_OK(hipGetLastError());
 }
 

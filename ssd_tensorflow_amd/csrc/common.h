@@ -41,6 +41,26 @@ inline void fail(const char* fmt, ...) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// RAII: make `device` the calling thread's current HIP device for the scope and put the caller's
+// device back afterwards.  Every handle-based or device-numbered C entry point holds one, so a rank of
+// a multi-GPU job can mix calls on its own GPU with free functions without its kernels migrating.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        HIP_OK(hipGetDevice(&prev));
+        if (prev != device) {
+            HIP_OK(hipSetDevice(device));
+            switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // Per-launch timing with HIP events on the launching stream (bench.py's roofline block).
 // Off by default; a Net turns it on for its steps.  One record per kernel launch.
 struct Profiler {

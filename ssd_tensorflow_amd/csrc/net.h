@@ -55,6 +55,15 @@ struct Variable {
     size_t count() const { return rows * width; }
 };
 
+// one output slot of the decode + NMS pass: packed [count | conf | cls | idx | box] in HBM + pinned host mirror
+struct DetectSlot {
+    char* dev = nullptr;
+    char* host = nullptr;
+    size_t bytes = 0, used = 0;
+    int b = 0, out_cap = 0;
+    hipEvent_t ready = nullptr;     // recorded behind the device-to-host copy
+};
+
 class Net {
 public:
     // dtype 0: fp32 everywhere (BASELINE.json configs[1]); 1: bf16 activations / gradients / filter mirrors with fp32
@@ -76,6 +85,8 @@ public:
     bool backward_step(size_t min_floats, size_t* off, size_t* count, bool sync_main);
     void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
+    void set_loss_normalizer(float bnorm) { loss_bnorm_ = bnorm; }      // <= 0: every step's own batch size
+    void null_gradients_step();                                         // gradient arena of a step without samples
     void set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd);
 
     // host-buffer conveniences
@@ -94,6 +105,10 @@ public:
     void activation_shape(const char* name, int* H, int* W, int* C) const;
 
     void detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls, int* idx, int* box);
+    // asynchronous form: kernels + one device-to-host copy enqueued; dev_out (optional) = the HBM arrays of the slot
+    const DetectSlot& detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out);
+    // host copy of the latest (which = 0) or the previous (which = 1) pass; waits for that slot's copy only
+    void detect_fetch(int which, int* count, float* conf, int* cls, int* idx, int* box);
 
     const Preset& preset() const { return *preset_; }
     int num_classes() const { return C_; }
@@ -158,12 +173,15 @@ private:
     double* anchors_dev_ = nullptr;
     int* anchors_abs_dev_ = nullptr;
     void* detect_ws_ = nullptr;
-    int detect_ws_b_ = 0;
+    DetectSlot det_slot_[2];
+    int det_cur_ = 0;
+    void detect_slot_carve(const DetectSlot& sl, DetectOut& d, char* base) const;
     std::vector<void*> allocs_;
 
     std::vector<float> lr_values_{0.001f};
     std::vector<long long> lr_bounds_;
     float momentum_ = 0.9f, wd_ = 0.0005f;
+    float loss_bnorm_ = 0.f;
     Profiler prof_;
     int bw_next_ = -1, bw_b_ = 0;
     size_t bw_done_off_ = 0;

@@ -327,8 +327,15 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
 
 Net::~Net() {
     if (g_prof == &prof_) g_prof = nullptr;
+    int prev_dev = device_;
+    (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    for (DetectSlot& sl : det_slot_) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+    }
     if (hstream_) {
         (void)hipStreamDestroy(hstream_);
         (void)hipEventDestroy(ev_h_);
@@ -341,6 +348,7 @@ Net::~Net() {
     }
     for (void* p : allocs_) (void)hipFree(p);
     if (losses_host_) (void)hipHostFree(losses_host_);
+    if (prev_dev != device_) (void)hipSetDevice(prev_dev);
 }
 
 // ---------------------------------------------------------------------------------
@@ -401,7 +409,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
     prof_.layer = "loss";
     if (train_mode) {
-        multibox_loss(heads_, b, result_, y, lw_, params_, nfilters_, wd_, stream_);
+        multibox_loss(heads_, b, result_, y, lw_, params_, nfilters_, wd_, loss_bnorm_, stream_);
         HIP_OK(hipMemcpyAsync(losses_host_, lw_.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     } else {
         heads_result(heads_, b, result_, stream_);
@@ -490,6 +498,13 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         HIP_OK(hipEventRecord(ev_w_, wstream_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_w_, 0));
     }
+    // Overlap switched off (ssd_set_overlap(0) / SSD_OVERLAP_WGRAD=0): the weight gradients ran on the main
+    // stream.  A caller that consumes the range on the weight-gradient stream (sync_main = false) must still
+    // find it final there, so that stream waits for the main stream instead.
+    if (wstream_ && !overlap_ && !sync_main) {
+        HIP_OK(hipEventRecord(ev_dy_, stream_));
+        HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+    }
     bw_done_off_ = lo;
     *off = lo;
     *count = hi - lo;
@@ -521,6 +536,12 @@ void Net::apply_gradients(float grad_scale) {
     prof_.layer = "optimizer";
     momentum_update(params_, mom_, grads_, nparams_, current_lr(), momentum_, grad_scale, stream_);
     ++global_step;
+}
+
+void Net::null_gradients_step() {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    null_gradients(params_, grads_, nfilters_, nparams_, wd_, stream_);
+    for (int i = 0; i < 4; ++i) losses_host_[i] = 0.f;
 }
 
 void Net::set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd) {
@@ -626,34 +647,74 @@ void Net::activation(const char* name, int b, float* out, size_t count) {
 // ---------------------------------------------------------------------------------
 // decode + NMS of the last result
 // ---------------------------------------------------------------------------------
-void Net::detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls,
-                      int* idx, int* box) {
-    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
-    SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
-    const int A = preset_->num_anchors;
-    if (!detect_ws_ || detect_ws_b_ < b) {
-        detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
-        detect_ws_b_ = Bmax_;
-    }
-    g_prof = &prof_;
-    prof_.layer = "detect";
-    const size_t n = (size_t)b * out_cap;
-    char* o = (char*)dalloc(n * 4 * 7 + (size_t)b * 4 + 256);     // small, freed with the handle
-    DetectOut d;
-    d.count = (int*)o;
-    d.conf = (float*)(o + ((size_t)b * 4 + 255) / 256 * 256);
+// Two output slots alternate, each one packed device buffer [count | conf | cls | idx | box] with a pinned
+// host mirror: the kernels and ONE device-to-host copy are enqueued, an event marks the copy, and the
+// caller collects a slot later (detect_fetch) -- e.g. after it has launched the next batch -- or at once.
+static size_t det_count_bytes(int b) { return ((size_t)b * 4 + 255) / 256 * 256; }
+
+void Net::detect_slot_carve(const DetectSlot& sl, DetectOut& d, char* base) const {
+    const size_t n = (size_t)sl.b * sl.out_cap;
+    d.count = (int*)base;
+    d.conf = (float*)(base + det_count_bytes(sl.b));
     d.cls = (int*)(d.conf + n);
     d.idx = d.cls + n;
     d.box = d.idx + n;
+}
+
+const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out) {
+    SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
+    SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
+    const int A = preset_->num_anchors;
+    if (!detect_ws_) detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
+    det_cur_ ^= 1;
+    DetectSlot& sl = det_slot_[det_cur_];
+    if (!sl.ready) {
+        HIP_OK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    } else {
+        HIP_OK(hipEventSynchronize(sl.ready));      // the slot's previous copy must have landed before it is reused
+    }
+    const size_t need = det_count_bytes(b) + (size_t)b * out_cap * 28;
+    if (need > sl.bytes) {
+        if (sl.dev) HIP_OK(hipFree(sl.dev));
+        if (sl.host) HIP_OK(hipHostFree(sl.host));
+        sl.dev = sl.host = nullptr;
+        sl.bytes = 0;
+        const size_t grow = std::max(need, det_count_bytes(Bmax_) + (size_t)Bmax_ * std::min(out_cap, 200) * 28);
+        HIP_OK(hipMalloc((void**)&sl.dev, grow));
+        HIP_OK(hipHostMalloc((void**)&sl.host, grow));
+        sl.bytes = grow;
+    }
+    sl.b = b; sl.out_cap = out_cap; sl.used = need;
+    g_prof = &prof_;
+    prof_.layer = "detect";
+    DetectOut d;
+    detect_slot_carve(sl, d, sl.dev);
     detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
-    HIP_OK(hipMemcpyAsync(count, d.count, (size_t)b * 4, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(conf, d.conf, n * 4, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(cls, d.cls, n * 4, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(idx, d.idx, n * 4, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(box, d.box, n * 16, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipStreamSynchronize(stream_));
-    HIP_OK(hipFree(o));
-    allocs_.pop_back();
+    HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipEventRecord(sl.ready, stream_));
+    if (dev_out) *dev_out = d;
+    return sl;
+}
+
+void Net::detect_fetch(int which, int* count, float* conf, int* cls, int* idx, int* box) {
+    SSD_REQUIRE(which == 0 || which == 1, "which must be 0 (latest) or 1 (the one before)");
+    DetectSlot& sl = det_slot_[det_cur_ ^ which];
+    SSD_REQUIRE(sl.ready != nullptr && sl.b > 0, "no detection pass in that slot");
+    HIP_OK(hipEventSynchronize(sl.ready));
+    DetectOut h;
+    detect_slot_carve(sl, h, sl.host);
+    const size_t n = (size_t)sl.b * sl.out_cap;
+    if (count) memcpy(count, h.count, (size_t)sl.b * 4);
+    if (conf) memcpy(conf, h.conf, n * 4);
+    if (cls) memcpy(cls, h.cls, n * 4);
+    if (idx) memcpy(idx, h.idx, n * 4);
+    if (box) memcpy(box, h.box, n * 16);
+}
+
+void Net::detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls,
+                      int* idx, int* box) {
+    detect_last_dev(b, thr, cap, max_out, out_cap, nms, nullptr);
+    detect_fetch(0, count, conf, cls, idx, box);
 }
 
 }  // namespace ssd

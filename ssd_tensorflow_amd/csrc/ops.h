@@ -60,8 +60,10 @@ struct LossWork {                    // per-step scratch, all device
 size_t loss_work_bytes(int B, int A);
 void loss_work_carve(LossWork& w, void* base, int B, int A);
 // Forward of the loss; labels [B][A][nvars] device.  result must hold heads_result's output.
+// bnorm: the batch size the per-sample losses are averaged over (<= 0: this step's own B).  A data-parallel
+// caller whose shards are unequal passes global_samples / world, so that the mean over ranks is the global mean.
 void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
-                   const float* filters, size_t nfilters, float weight_decay, hipStream_t s);
+                   const float* filters, size_t nfilters, float weight_decay, float bnorm, hipStream_t s);
 // d(loss)/d(head outputs) written into L.dbuf (pad columns stay zero).
 void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s);
@@ -69,6 +71,9 @@ void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const f
 // ---- MomentumOptimizer without Nesterov (ssdvgg.py:586-588): acc = m*acc + g; w -= lr*acc
 void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, float momentum, float gscale,
                      hipStream_t s);
+
+// gradients of a step without samples (a data-parallel rank whose shard of a short last batch is empty)
+void null_gradients(const float* w, float* g, size_t nfilters, size_t n, float wd, hipStream_t s);
 
 void fill_zero(void* p, size_t bytes, hipStream_t s);
 

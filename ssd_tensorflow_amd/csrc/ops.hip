@@ -432,198 +432,316 @@ void l2norm_bwd(int npix, int C, const bf16_t* x, const float* scale, const bf16
 // multibox heads: anchor a of image b lives in map i at (box type j, cell hw):
 //   a = off[i] + j*hw[i] + cell ;  source row (b*hw[i] + cell) of buf[i], columns j*nvars..
 // =================================================================================
-struct AnchorLoc {
-    int map, col0;
-    size_t row;
+constexpr int MAXV = 32;   // nvars <= 32  (num_classes <= 27)
+
+// ---- work decomposition of the head kernels ---------------------------------------------------------------
+// One workgroup owns HCH consecutive cells of one feature map of one image, i.e. the HCH * nj anchors whose
+// head outputs are the HCH contiguous rows [cell][ld] of the fused head buffer.  Every global access of the
+// kernels below is then a contiguous run: the rows themselves (HCH*ld floats), and per box type j the HCH
+// anchors' [nvars] records of result / labels (anchor a = off + j*hw + cell).  Tiles are staged through LDS
+// with 16-byte loads; thread (cell = t & 31, j = t >> 5) works on one anchor from LDS at odd strides.
+constexpr int HCH = 32;
+constexpr int HTHREADS = 256;               // 32 cells x 8 type slots (nj <= 8)
+struct HeadGrid {
+    int blk_off[MAX_MAPS + 1];              // first workgroup of each map
+    int nchunk[MAX_MAPS];                   // cell chunks per image
+    int ldp_max, nj_max;
 };
-__device__ __forceinline__ AnchorLoc locate(const HeadLayout& L, int b, int a) {
+static HeadGrid head_grid(const HeadLayout& L, int B) {
+    HeadGrid g{};
+    int off = 0;
+    for (int i = 0; i < L.nmaps; ++i) {
+        g.blk_off[i] = off;
+        g.nchunk[i] = (L.hw[i] + HCH - 1) / HCH;
+        off += g.nchunk[i] * B;
+        g.ldp_max = std::max(g.ldp_max, L.ld[i] + 1);
+        g.nj_max = std::max(g.nj_max, L.nj[i]);
+    }
+    for (int i = L.nmaps; i <= MAX_MAPS; ++i) g.blk_off[i] = off;
+    SSD_REQUIRE(g.nj_max <= HTHREADS / HCH, "heads: at most %d box types per map", HTHREADS / HCH);
+    return g;
+}
+struct HeadBlock {
+    int map, b, cell0, ncell;
+};
+__device__ __forceinline__ HeadBlock head_block(const HeadLayout& L, const HeadGrid& G) {
     int i = 0;
 #pragma unroll
     for (int k = 1; k < MAX_MAPS; ++k)
-        if (k < L.nmaps && a >= L.off[k]) i = k;
-    const int al = a - L.off[i];
-    const int j = al / L.hw[i];
-    const int cell = al - j * L.hw[i];
-    AnchorLoc r;
+        if (k < L.nmaps && (int)blockIdx.x >= G.blk_off[k]) i = k;
+    const int local = blockIdx.x - G.blk_off[i];
+    HeadBlock r;
     r.map = i;
-    r.col0 = j * L.nvars;
-    r.row = (size_t)b * L.hw[i] + cell;
+    r.b = local / G.nchunk[i];
+    r.cell0 = (local - r.b * G.nchunk[i]) * HCH;
+    r.ncell = min(HCH, L.hw[i] - r.cell0);
     return r;
 }
 
-constexpr int MAXV = 32;   // nvars <= 32  (num_classes <= 27)
+// contiguous global run (4-byte aligned) <-> LDS, 16-byte global accesses on the aligned middle
+__device__ __forceinline__ void run_to_lds(float* dst, const float* __restrict__ src, int n) {
+    const int pre = min(n, (int)((4u - (unsigned)(((size_t)src >> 2) & 3u)) & 3u));
+    if ((int)threadIdx.x < pre) dst[threadIdx.x] = src[threadIdx.x];
+    const int n4 = (n - pre) >> 2;
+    for (int i = threadIdx.x; i < n4; i += HTHREADS) {
+        const f32x4 v = ld4(src + pre + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[pre + 4 * i + e] = v[e];
+    }
+    for (int i = pre + 4 * n4 + threadIdx.x; i < n; i += HTHREADS) dst[i] = src[i];
+}
+__device__ __forceinline__ void lds_to_run(float* __restrict__ dst, const float* src, int n) {
+    const int pre = min(n, (int)((4u - (unsigned)(((size_t)dst >> 2) & 3u)) & 3u));
+    if ((int)threadIdx.x < pre) dst[threadIdx.x] = src[threadIdx.x];
+    const int n4 = (n - pre) >> 2;
+    for (int i = threadIdx.x; i < n4; i += HTHREADS) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = src[pre + 4 * i + e];
+        st4(dst + pre + 4 * i, v);
+    }
+    for (int i = pre + 4 * n4 + threadIdx.x; i < n; i += HTHREADS) dst[i] = src[i];
+}
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void heads_kernel(HeadLayout L, int B, float* __restrict__ result,
-                                                    const float* __restrict__ labels, float* __restrict__ ce_out,
-                                                    float* __restrict__ sl1_out, unsigned char* __restrict__ pos_out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * L.A) return;
-    const int b = idx / L.A, a = idx - b * L.A;
-    const AnchorLoc p = locate(L, b, a);
-    const float* src = L.buf[p.map] + p.row * L.ld[p.map] + p.col0;
+__global__ __launch_bounds__(HTHREADS) void heads_kernel(HeadLayout L, HeadGrid G, int B, float* __restrict__ result,
+                                                         const float* __restrict__ labels, float* __restrict__ ce_out,
+                                                         float* __restrict__ sl1_out, unsigned char* __restrict__ pos_out) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const HeadBlock k = head_block(L, G);
     const int nv = L.nvars, nc = nv - 4;
-    float z[MAXV];
-    float m = -__builtin_inff();
+    const int ld = L.ld[k.map], ldp = ld + 1, nj = L.nj[k.map], hw = L.hw[k.map];
+    float* hin = hsm;                         // [HCH][ldp]   raw head outputs, odd row pitch
+    float* rec = hsm + HCH * G.ldp_max;       // [nj][HCH][nv] labels in, result out
+    {   // the chunk's rows of the fused head buffer: one contiguous, 16-byte aligned run
+        const float* src = L.buf[k.map] + ((size_t)k.b * hw + k.cell0) * ld;
+        const int n4 = (k.ncell * ld) >> 2;
+        for (int i = threadIdx.x; i < n4; i += HTHREADS) {
+            const f32x4 v = ld4(src + 4 * i);
+            const int row = (4 * i) / ld, col = 4 * i - row * ld;
 #pragma unroll
-    for (int c = 0; c < MAXV; ++c) {
-        z[c] = c < nv ? src[c] : 0.f;
-        if (c < nc) m = fmaxf(m, z[c]);
+            for (int e = 0; e < 4; ++e) hin[row * ldp + col + e] = v[e];
+        }
     }
-    // accurate expf/logf (not the fast intrinsics): softmax must match an fp32 reference
-    // to 1e-3 rel even for tiny probabilities
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c)
-        if (c < nc) se += expf(z[c] - m);
-    const float lse = m + logf(se);
-    float* out = result + (size_t)idx * nv;
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c)
-        if (c < nv) out[c] = c < nc ? expf(z[c] - lse) : z[c];
-    if constexpr (TRAIN) {
-        const float* y = labels + (size_t)idx * nv;
-        float ce = 0.f, sl = 0.f;
-        const bool pos = y[nc - 1] == 0.f;
+    const size_t a0 = (size_t)k.b * L.A + L.off[k.map] + k.cell0;      // anchor of (type 0, first cell)
+    if constexpr (TRAIN)
+        for (int j = 0; j < nj; ++j) run_to_lds(rec + j * HCH * nv, labels + (a0 + (size_t)j * hw) * nv, k.ncell * nv);
+    __syncthreads();
+    const int cell = threadIdx.x & (HCH - 1), j = threadIdx.x / HCH;
+    if (cell < k.ncell && j < nj) {
+        const float* src = hin + cell * ldp + j * nv;
+        float* r = rec + (j * HCH + cell) * nv;
+        float z[MAXV], y[MAXV];
+        float m = -__builtin_inff();
 #pragma unroll
         for (int c = 0; c < MAXV; ++c) {
-            if (c < nc) {
-                const float yc = y[c];
-                if (yc != 0.f) ce += yc * (lse - z[c]);
-            } else if (c < nv) {
-                const float d = z[c] - y[c];
-                const float ad = fabsf(d);
-                sl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
-            }
+            z[c] = c < nv ? src[c] : 0.f;
+            y[c] = (TRAIN && c < nv) ? r[c] : 0.f;
+            if (c < nc) m = fmaxf(m, z[c]);
         }
-        ce_out[idx] = ce;
-        sl1_out[idx] = pos ? sl : 0.f;
-        pos_out[idx] = pos ? 1 : 0;
+        // accurate expf/logf (not the fast intrinsics): softmax must match an fp32 reference
+        // to 1e-3 rel even for tiny probabilities
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c)
+            if (c < nc) se += expf(z[c] - m);
+        const float lse = m + logf(se);
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c)
+            if (c < nv) r[c] = c < nc ? expf(z[c] - lse) : z[c];
+        if constexpr (TRAIN) {
+            float ce = 0.f, sl = 0.f;
+            const bool pos = y[nc - 1] == 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXV; ++c) {
+                if (c < nc) {
+                    if (y[c] != 0.f) ce += y[c] * (lse - z[c]);
+                } else if (c < nv) {
+                    const float d = z[c] - y[c];
+                    const float ad = fabsf(d);
+                    sl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+                }
+            }
+            const size_t idx = a0 + (size_t)j * hw + cell;
+            ce_out[idx] = ce;
+            sl1_out[idx] = pos ? sl : 0.f;
+            pos_out[idx] = pos ? 1 : 0;
+        }
     }
+    __syncthreads();
+    for (int jj = 0; jj < nj; ++jj) lds_to_run(result + (a0 + (size_t)jj * hw) * nv, rec + jj * HCH * nv, k.ncell * nv);
+}
+
+static size_t heads_lds_bytes(const HeadLayout& L, const HeadGrid& G) {
+    return ((size_t)HCH * G.ldp_max + (size_t)G.nj_max * HCH * L.nvars) * sizeof(float);
 }
 
 void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     const int total = B * L.A;
+    const HeadGrid G = head_grid(L, B);
     ProfScope prof("heads_result", 0.0, 8.0 * total * L.nvars, s);
-    hipLaunchKernelGGL(heads_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, nullptr, nullptr,
-                       nullptr, nullptr);
+    hipLaunchKernelGGL(heads_kernel<false>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B, result,
+                       nullptr, nullptr, nullptr, nullptr);
     HIP_OK(hipGetLastError());
 }
 
 // ---- per-sample: counts, sums, hard-negative selection (top-k by radix select) ------
+// One workgroup per sample holds the sample's A cross-entropy values in registers (PT per thread): every
+// pass of the MSB-first radix select (8 bits per pass over the float bit pattern, values are >= 0) runs from
+// registers into an LDS histogram, the bin holding the k-th largest is found by a parallel suffix scan.
 constexpr int LS_THREADS = 1024;
+constexpr int LS_WAVES = LS_THREADS / 64;
 
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
-    v = wave_sum(v);
+__device__ __forceinline__ void block_sum3_1024(float& a, float& b, float& c, float* red) {     // red[3 * LS_WAVES]
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = a; red[LS_WAVES + (threadIdx.x >> 6)] = b; red[2 * LS_WAVES + (threadIdx.x >> 6)] = c;
+    }
     __syncthreads();
-    float t = 0.f;
+    float ta = 0.f, tb = 0.f, tc = 0.f;
 #pragma unroll
-    for (int i = 0; i < LS_THREADS / 64; ++i) t += red[i];
-    return t;
+    for (int i = 0; i < LS_WAVES; ++i) { ta += red[i]; tb += red[LS_WAVES + i]; tc += red[2 * LS_WAVES + i]; }
+    a = ta; b = tb; c = tc;
 }
 
-__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, const float* __restrict__ ce,
+template <int PT>
+__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, float bnorm, const float* __restrict__ ce,
                                                                  const float* __restrict__ sl1,
                                                                  const unsigned char* __restrict__ pos,
                                                                  unsigned char* __restrict__ sel,
                                                                  float* __restrict__ sample) {
-    __shared__ float red[LS_THREADS / 64];
+    __shared__ float red[3 * LS_WAVES];
     __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_k, sh_wtot[LS_THREADS / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned sh_prefix, sh_k, sh_ties, sh_wsum[4], sh_wtot[LS_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* cb = ce + (size_t)b * A;
     const float* lb = sl1 + (size_t)b * A;
     const unsigned char* pb = pos + (size_t)b * A;
     unsigned char* sb = sel + (size_t)b * A;
 
+    // the sample's values, loaded once (coalesced, all loads in flight together)
+    unsigned u[PT];          // negatives[a] = pos ? 0 : ce  (ssdvgg.py:459) as bit patterns
+    unsigned pmask = 0, vmask = 0;
     float npos = 0.f, psum = 0.f, lsum = 0.f;
-    for (int a = tid; a < A; a += LS_THREADS) {
-        const bool p = pb[a];
-        npos += p ? 1.f : 0.f;
-        psum += p ? cb[a] : 0.f;
-        lsum += lb[a];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int a = tid + LS_THREADS * r;
+        u[r] = 0u;
+        if (a < A) {
+            const float c = cb[a];
+            const bool p = pb[a] != 0;
+            lsum += lb[a];
+            vmask |= 1u << r;
+            if (p) { pmask |= 1u << r; npos += 1.f; psum += c; }
+            else u[r] = __float_as_uint(c);
+        }
     }
-    npos = block_sum_1024(npos, red);
-    psum = block_sum_1024(psum, red);
-    lsum = block_sum_1024(lsum, red);
+    block_sum3_1024(npos, psum, lsum, red);
     const int pos_n = (int)npos;
     const int neg_n = A - pos_n;
     const int k = min(neg_n, 3 * pos_n);
     if (pos_n == 0) {   // ssdvgg.py:513-516,552-555: the sample contributes exactly 0
-        for (int a = tid; a < A; a += LS_THREADS) sb[a] = 0;
+#pragma unroll
+        for (int r = 0; r < PT; ++r)
+            if (vmask >> r & 1u) sb[tid + LS_THREADS * r] = 0;
         if (tid == 0) {
             sample[b * 4 + 0] = 0.f; sample[b * 4 + 1] = 0.f; sample[b * 4 + 2] = 0.f; sample[b * 4 + 3] = 0.f;
         }
         return;
     }
-    // negatives[a] = pos ? 0 : ce  (ssdvgg.py:459); k-th largest by MSB-first radix select
-    // on the float bit pattern (values are >= 0, so bits order like the floats).
     unsigned prefix = 0, kk = (unsigned)k;   // kk-th largest among entries matching prefix
+    bool ties = false;
     if (k > 0) {
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (int a = tid; a < A; a += LS_THREADS) {
-                const unsigned u = pb[a] ? 0u : __float_as_uint(cb[a]);
-                if ((u & himask) == (prefix & himask)) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+#pragma unroll
+            for (int r = 0; r < PT; ++r) {
+                const bool in = (vmask >> r & 1u) && (u[r] & himask) == (prefix & himask);
+                const unsigned digit = (u[r] >> shift) & 255u;
+                const unsigned long long bal = __ballot(in);
+                if (bal == 0ull) continue;
+                // a wave whose entries all fall into one bin (the usual case for the exponent byte) adds once
+                const unsigned d0 = __builtin_amdgcn_readlane(digit, __ffsll((long long)bal) - 1);
+                if (__ballot(in && digit == d0) == bal) {
+                    if (lane == __ffsll((long long)bal) - 1) atomicAdd(&hist[d0], (unsigned)__popcll(bal));
+                } else if (in) {
+                    atomicAdd(&hist[digit], 1u);
+                }
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned acc = 0;
-                int bin = 255;
-                for (; bin > 0; --bin) {
-                    if (acc + hist[bin] >= kk) break;
-                    acc += hist[bin];
+            // bin of the kk-th largest: inclusive suffix sums over bins 255..0 by the first four waves
+            unsigned h = 0, inc = 0;
+            if (tid < 256) {
+                h = hist[255 - tid];
+                inc = h;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
                 }
-                sh_prefix = prefix | ((unsigned)bin << shift);
-                sh_k = kk - acc;
+                if (lane == 63) sh_wsum[wv] = inc;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                for (int i = 0; i < wv; ++i) inc += sh_wsum[i];
+                const unsigned exc = inc - h;
+                if (inc >= kk && exc < kk) {
+                    sh_prefix = prefix | ((unsigned)(255 - tid) << shift);
+                    sh_k = kk - exc;
+                    sh_ties = h > kk - exc ? 1u : 0u;
+                }
             }
             __syncthreads();
             prefix = sh_prefix;
             kk = sh_k;
+            ties = sh_ties != 0u;          // meaningful after the last pass: more entries equal T than are taken
         }
     }
     // prefix = bit pattern of the threshold T; kk = how many entries == T are taken
     const float T = __uint_as_float(prefix);
-    float tsum = 0.f;
-    for (int a = tid; a < A; a += LS_THREADS) {
-        const float v = pb[a] ? 0.f : cb[a];
-        if (k > 0 && v > T) tsum += v;
+    float tsum = 0.f, z0 = 0.f, z1 = 0.f;
+    if (k > 0) {
+#pragma unroll
+        for (int r = 0; r < PT; ++r)
+            if ((vmask >> r & 1u) && u[r] > prefix) tsum += __uint_as_float(u[r]);
     }
-    tsum = block_sum_1024(tsum, red);
+    block_sum3_1024(tsum, z0, z1, red);
     if (k > 0) tsum += (float)kk * T;
     // selection mask; ties at T go to the LOWER index first (tf.nn.top_k)
-    unsigned base = 0;
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int a0 = 0; a0 < A; a0 += LS_THREADS) {
-        const int a = a0 + tid;
-        const bool in = a < A;
-        const bool p = in ? (bool)pb[a] : false;
-        const float v = in ? (p ? 0.f : cb[a]) : -1.f;
-        const bool eq = in && k > 0 && v == T;
-        const unsigned long long bal = __ballot(eq);
-        const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) sh_wtot[wv] = __popcll(bal);
-        __syncthreads();
-        unsigned wbase = base, tot = 0;
+    if (!ties) {
 #pragma unroll
-        for (int i = 0; i < LS_THREADS / 64; ++i) {
-            if (i < wv) wbase += sh_wtot[i];
-            tot += sh_wtot[i];
+        for (int r = 0; r < PT; ++r)
+            if (vmask >> r & 1u) sb[tid + LS_THREADS * r] = ((pmask >> r & 1u) || (k > 0 && u[r] >= prefix)) ? 1 : 0;
+    } else {
+        unsigned base = 0;
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {          // a = tid + 1024 r ascends with (r, tid)
+            const bool in = vmask >> r & 1u;
+            const bool eq = in && u[r] == prefix;      // positives hold 0: they tie with T == 0 like the reference's zeros
+            const unsigned long long bal = __ballot(eq);
+            const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (lane == 0) sh_wtot[wv] = __popcll(bal);
+            __syncthreads();
+            unsigned wbase = base, tot = 0;
+#pragma unroll
+            for (int i = 0; i < LS_WAVES; ++i) {
+                if (i < wv) wbase += sh_wtot[i];
+                tot += sh_wtot[i];
+            }
+            const bool take = u[r] > prefix || (eq && wbase + before < kk);
+            if (in) sb[tid + LS_THREADS * r] = ((pmask >> r & 1u) || take) ? 1 : 0;
+            base += tot;
         }
-        const bool take = k > 0 && (v > T || (eq && wbase + before < kk));
-        if (in) sb[a] = p ? 1 : (take ? 1 : 0);
-        base += tot;
     }
     if (tid == 0) {
         sample[b * 4 + 0] = (psum + tsum) / (float)pos_n;
         sample[b * 4 + 1] = lsum / (float)pos_n;
-        sample[b * 4 + 2] = 1.f / ((float)pos_n * (float)B);
+        sample[b * 4 + 2] = 1.f / ((float)pos_n * bnorm);
         sample[b * 4 + 3] = (float)pos_n;
     }
 }
@@ -642,8 +760,8 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void loss_final_kernel(int B, const float* __restrict__ sample, const float* __restrict__ partial, int npartial,
-                                  float wd, float* __restrict__ losses) {
+__global__ void loss_final_kernel(int B, float bnorm, const float* __restrict__ sample, const float* __restrict__ partial,
+                                  int npartial, float wd, float* __restrict__ losses) {
     // one wave; lane-strided partial sums then a fixed-order shuffle tree
     const int lane = threadIdx.x;
     double ss = 0.0;
@@ -656,8 +774,8 @@ __global__ void loss_final_kernel(int B, const float* __restrict__ sample, const
         conf += sample[b * 4 + 0];
         loc += sample[b * 4 + 1];
     }
-    conf /= (float)B;
-    loc /= (float)B;
+    conf /= bnorm;
+    loc /= bnorm;
     const float l2 = wd * (float)(0.5 * ss);
     losses[0] = conf + loc + l2;
     losses[1] = loc;
@@ -689,58 +807,78 @@ void loss_work_carve(LossWork& w, void* base, int B, int A) {
 }
 
 void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
-                   const float* filters, size_t nfilters, float weight_decay, hipStream_t s) {
+                   const float* filters, size_t nfilters, float weight_decay, float bnorm, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
+    SSD_REQUIRE(L.A <= 32 * LS_THREADS, "loss: at most %d anchors", 32 * LS_THREADS);
     const int total = B * L.A;
+    const HeadGrid G = head_grid(L, B);
+    if (!(bnorm > 0.f)) bnorm = (float)B;          // reduce_mean over this step's own batch (ssdvgg.py:520,559)
     ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars + 4.0 * nfilters, s);
-    hipLaunchKernelGGL(heads_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, const_cast<float*>(result),
-                       labels, w.ce, w.sl1, w.pos);
-    hipLaunchKernelGGL(loss_sample_kernel, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, w.ce, w.sl1, w.pos, w.sel, w.sample);
+    hipLaunchKernelGGL(heads_kernel<true>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B,
+                       const_cast<float*>(result), labels, w.ce, w.sl1, w.pos);
+    const int pt = (L.A + LS_THREADS - 1) / LS_THREADS;
+    if (pt <= 9)
+        hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
+    else if (pt <= 24)
+        hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
+    else
+        hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, filters, nfilters, w.partial);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, B, w.sample, w.partial, SUMSQ_BLOCKS, weight_decay,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, B, bnorm, w.sample, w.partial, SUMSQ_BLOCKS, weight_decay,
                        w.losses);
     HIP_OK(hipGetLastError());
 }
 
-__device__ __forceinline__ void put(float* p, float v) { *p = v; }
-__device__ __forceinline__ void put(bf16_t* p, float v) { p->v = f2bf(v); }
-
 // d/d(logits) = sel * (softmax - labels) * w_b ; d/d(loc) = pos * clip(loc - gt, -1, 1) * w_b,
 // w_b = 1 / (pos_n_b * B)  (reduce_mean over the batch of per-sample normalised sums).
+// All but a few hundred anchors per image are neither selected nor positive: a workgroup zero-fills its
+// [HCH][ld] tile of the gradient buffer in LDS, the few flagged anchors fetch their result / label records and
+// fill their columns, and the tile leaves as one contiguous run of 16-byte stores (pad columns included).
 template <typename T>
-__global__ __launch_bounds__(256) void loss_grad_kernel(HeadLayout L, int B, const float* __restrict__ result,
-                                                        const float* __restrict__ labels,
-                                                        const unsigned char* __restrict__ pos,
-                                                        const unsigned char* __restrict__ sel,
-                                                        const float* __restrict__ sample) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * L.A) return;
-    const int b = idx / L.A, a = idx - b * L.A;
-    const AnchorLoc p = locate(L, b, a);
-    T* dst = static_cast<T*>(L.dbuf[p.map]) + p.row * L.ld[p.map] + p.col0;
+__global__ __launch_bounds__(HTHREADS) void loss_grad_kernel(HeadLayout L, HeadGrid G, int B, const float* __restrict__ result,
+                                                             const float* __restrict__ labels,
+                                                             const unsigned char* __restrict__ pos,
+                                                             const unsigned char* __restrict__ sel,
+                                                             const float* __restrict__ sample) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];      // [HCH][ld]
+    const HeadBlock k = head_block(L, G);
     const int nv = L.nvars, nc = nv - 4;
-    const float wb = sample[b * 4 + 2];
-    const bool isel = sel[idx], ipos = pos[idx];
-    const float* r = result + (size_t)idx * nv;
-    const float* y = labels + (size_t)idx * nv;
-    for (int c = 0; c < nc; ++c) put(dst + c, isel ? (r[c] - y[c]) * wb : 0.f);
-    for (int c = nc; c < nv; ++c) {
-        float d = r[c] - y[c];
-        d = fminf(fmaxf(d, -1.f), 1.f);
-        put(dst + c, ipos ? d * wb : 0.f);
+    const int ld = L.ld[k.map], nj = L.nj[k.map], hw = L.hw[k.map];
+    const int n4 = (k.ncell * ld) >> 2;
+    for (int i = threadIdx.x; i < n4; i += HTHREADS) *reinterpret_cast<f32x4*>(gsm + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int cell = threadIdx.x & (HCH - 1), j = threadIdx.x / HCH;
+    if (cell < k.ncell && j < nj) {
+        const size_t idx = (size_t)k.b * L.A + L.off[k.map] + (size_t)j * hw + k.cell0 + cell;
+        const bool isel = sel[idx], ipos = pos[idx];
+        if (isel || ipos) {
+            const float wb = sample[k.b * 4 + 2];
+            const float* r = result + idx * nv;
+            const float* y = labels + idx * nv;
+            float* dst = gsm + cell * ld + j * nv;
+            if (isel)
+                for (int c = 0; c < nc; ++c) dst[c] = (r[c] - y[c]) * wb;
+            if (ipos)
+                for (int c = nc; c < nv; ++c) dst[c] = fminf(fmaxf(r[c] - y[c], -1.f), 1.f) * wb;
+        }
     }
+    __syncthreads();
+    T* out = static_cast<T*>(L.dbuf[k.map]) + ((size_t)k.b * hw + k.cell0) * ld;
+    for (int i = threadIdx.x; i < n4; i += HTHREADS) st4t(out + 4 * i, *reinterpret_cast<const f32x4*>(gsm + 4 * i));
 }
 
 void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s) {
     const int total = B * L.A;
+    const HeadGrid G = head_grid(L, B);
+    const size_t lds = (size_t)HCH * (G.ldp_max - 1) * sizeof(float);
     ProfScope prof("multibox_loss_grad", 0.0, (L.grad_bf16 ? 10.0 : 12.0) * total * L.nvars, s);
     if (L.grad_bf16)
-        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos,
+        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, result, labels, w.pos,
                            w.sel, w.sample);
     else
-        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, L, B, result, labels, w.pos, w.sel,
-                           w.sample);
+        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, result, labels, w.pos,
+                           w.sel, w.sample);
     HIP_OK(hipGetLastError());
 }
 
@@ -763,6 +901,19 @@ void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, f
     ProfScope prof("momentum_update", 0.0, 20.0 * n, s);
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n / 4, 256, 256 * 16)), dim3(256), 0, s, w, acc, g, n / 4, lr,
                        momentum, gscale);
+    HIP_OK(hipGetLastError());
+}
+
+// gradient arena of a step without samples: d(l2_loss)/dw = wd * w on the filters, zero elsewhere
+__global__ __launch_bounds__(256) void null_grads_kernel(const float* __restrict__ w, float* __restrict__ g, size_t nf4, size_t n4,
+                                                         float wd) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        st4(g + i * 4, i < nf4 ? wd * ld4(w + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f});
+}
+
+void null_gradients(const float* w, float* g, size_t nfilters, size_t n, float wd, hipStream_t s) {
+    SSD_REQUIRE(n % 4 == 0 && nfilters % 4 == 0, "arena sizes must be multiples of 4");
+    hipLaunchKernelGGL(null_grads_kernel, dim3(grid_for(n / 4, 256, 256 * 16)), dim3(256), 0, s, w, g, nfilters / 4, n / 4, wd);
     HIP_OK(hipGetLastError());
 }
 

@@ -36,9 +36,12 @@ def init(backend=None):
 class ShardSampler:
     """The reference's single feeder shuffles the sample list and cuts it into batches
     (training_data.py:137-139,176-178).  Here every rank draws the SAME permutation (same seed)
-    and takes a rank-strided slice of each global batch: shards are disjoint, their union is the
-    global batch, no exchange is needed.  The last global batch may be short; ranks whose slice
-    is empty skip it (the reference never pads a batch that reaches the net)."""
+    and takes its slice of each global batch: shards are disjoint, their union is the global batch,
+    no exchange is needed.  Every rank yields the same number of batches (one per global batch), so
+    the ranks issue the same collectives.  The last global batch may be short (the reference never
+    pads a batch that reaches the net): it is split as evenly as possible, shards differ by at most
+    one sample and a shard may be EMPTY when fewer samples than ranks are left -- such a rank still
+    takes part in the step (train_step_dp: null gradients, the same all-reduce)."""
 
     def __init__(self, num_samples, batch_per_rank, rank=0, world=1, seed=0):
         self.n, self.b, self.rank, self.world, self.seed = int(num_samples), int(batch_per_rank), rank, world, seed
@@ -47,12 +50,19 @@ class ShardSampler:
         g = self.b * self.world
         return (self.n + g - 1) // g
 
-    def batches(self, epoch):
+    def batches_with_count(self, epoch):
+        """(this rank's sample indices, size of the global batch) for every global batch of the epoch."""
         perm = np.random.default_rng(self.seed + epoch).permutation(self.n)
         g = self.b * self.world
         for k in range(self.num_batches()):
             glob = perm[k * g:(k + 1) * g]
-            yield glob[self.rank * self.b:(self.rank + 1) * self.b]
+            q, r = divmod(len(glob), self.world)
+            start = self.rank * q + min(self.rank, r)
+            yield glob[start:start + q + (1 if self.rank < r else 0)], len(glob)
+
+    def batches(self, epoch):
+        for idx, _ in self.batches_with_count(epoch):
+            yield idx
 
 
 def allreduce_flat(flat, world, bucket_floats=0):
@@ -78,31 +88,55 @@ def mean_scalars(values, world, device=None):
     return (t / world).tolist()
 
 
-def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0):
+def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, force_collectives=False):
     """One data-parallel step on this rank's shard (device tensors).
 
     bucket_floats > 0: backward is driven in stages and every finished range of the filter
     gradients (>= bucket_floats, completed from the end of the arena: heads, conv11 ... conv1) is
     all-reduced asynchronously while the remaining backward kernels run; the tiny bias / scale
-    tail goes last.  bucket_floats == 0: one all-reduce after backward."""
-    if world <= 1:
+    tail goes last.  bucket_floats == 0: one all-reduce after backward.
+
+    global_count: samples in the global batch when the shards may be unequal (the short last batch
+    of an epoch).  Every rank then normalises its losses by global_count / world, so the plain mean
+    over ranks (sum, then 1/world in the update) is the global-batch mean; a rank whose shard is empty
+    (x_dev is None or has no rows) contributes the shared weight-decay gradient only.
+    force_collectives: take the collective path even for world == 1 (a single-rank group: hardware test of the
+    stream ordering)."""
+    b = 0 if x_dev is None else int(x_dev.shape[0])
+    if world <= 1 and not force_collectives:
+        if b == 0:
+            return
         net.forward_backward_dev(x_dev, y_dev)
         net.apply_gradients_dev(1.0)
         return
-    if bucket_floats <= 0:
-        net.forward_backward_dev(x_dev, y_dev)
-        dist.all_reduce(net.grads_flat)
-    else:
-        # Collectives are enqueued behind the weight-gradient stream only: the data gradients on the
-        # current stream keep running ahead of them.  The last stage joins the two streams, after which
-        # the bias / scale tail is reduced and the current stream waits for everything.
-        side = net.use_torch_wgrad_stream()
-        net.forward_dev(x_dev, y_dev)
-        works = []
-        for off, cnt in net.backward_staged(y_dev, x_dev.shape[0], bucket_floats, sync_main=False):
-            with torch.cuda.stream(side):
-                works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
-        works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True))
-        for w in works:
-            w.wait()
+    if global_count is not None:
+        net.set_loss_normalizer(global_count / world)
+    # every rank must issue the same collectives: a global batch with fewer samples than ranks leaves some
+    # shards empty, and those ranks have no staged backward -- that step uses ONE all-reduce everywhere
+    some_empty = global_count is not None and global_count < world
+    if b == 0 and not some_empty:
+        raise ValueError('empty shard, but global_count does not say that shards may be empty')
+    try:
+        if b == 0:
+            net.null_gradients_dev()
+            dist.all_reduce(net.grads_flat)
+        elif bucket_floats <= 0 or some_empty:
+            net.forward_backward_dev(x_dev, y_dev)
+            dist.all_reduce(net.grads_flat)
+        else:
+            # Collectives are enqueued behind the weight-gradient stream only: the data gradients on the
+            # current stream keep running ahead of them.  The last stage joins the two streams, after which
+            # the bias / scale tail is reduced and the current stream waits for everything.
+            side = net.use_torch_wgrad_stream()
+            net.forward_dev(x_dev, y_dev)
+            works = []
+            for off, cnt in net.backward_staged(y_dev, b, bucket_floats, sync_main=False):
+                with torch.cuda.stream(side):
+                    works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
+            works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True))
+            for w in works:
+                w.wait()
+    finally:
+        if global_count is not None:
+            net.set_loss_normalizer(0.0)
     net.apply_gradients_dev(1.0 / world)

@@ -35,13 +35,11 @@ SSD_PRESETS = {
                          SSDMap(Size(1, 1), 0.9, _AR2)], 1.05, 24564),
 }
 IMG1000 = Size(1000, 1000)
-_DEVICE = 0
 
 
 def set_device(device):
-    """GPU ordinal the free functions of this module run on (a handle-owning SSDVGG has its own)."""
-    global _DEVICE
-    _DEVICE = int(device)
+    """GPU ordinal the free functions of this package run on (a handle-owning SSDVGG has its own)."""
+    _lib.set_device(device)
 
 
 def get_preset_by_name(pname):
@@ -58,7 +56,7 @@ def anchors_array(preset):
     """[A,4] float64 (cx, cy, w, h) from the HIP anchor kernel."""
     p = get_preset_by_name(preset if isinstance(preset, str) else preset.name)
     out = np.empty((p.num_anchors, 4), np.float64)
-    check(lib.ssd_anchors(_pname(p), _DEVICE, np_ptr(out)))
+    check(lib.ssd_anchors(_pname(p), _lib.device(), np_ptr(out)))
     return out
 
 
@@ -87,7 +85,7 @@ def anchors2array(anchors, img_size):
         for p in SSD_PRESETS.values():
             if len(anchors) == p.num_anchors:
                 out = np.empty((p.num_anchors, 4), np.int32)
-                check(lib.ssd_anchors_abs(_pname(p), _DEVICE, np_ptr(out)))
+                check(lib.ssd_anchors_abs(_pname(p), _lib.device(), np_ptr(out)))
                 return out.astype(np.float64)
     return np.array([prop2abs(a.center, a.size, img_size) for a in anchors], np.float64).reshape(-1, 4)
 
@@ -120,7 +118,7 @@ def detect_batch(pred, preset, confidence_threshold=0.01, detections_cap=200, ma
     cls = np.zeros((b, out_cap), np.int32)
     idx = np.zeros((b, out_cap), np.int32)
     box = np.zeros((b, out_cap, 4), np.int32)
-    check(lib.ssd_decode_nms(_pname(p), nv - 5, _DEVICE, np_ptr(pred), b, float(confidence_threshold), cap, mo, out_cap,
+    check(lib.ssd_decode_nms(_pname(p), nv - 5, _lib.device(), np_ptr(pred), b, float(confidence_threshold), cap, mo, out_cap,
                              1 if nms else 0, np_ptr(count), np_ptr(conf), np_ptr(cls), np_ptr(idx), np_ptr(box)))
     out = []
     for i in range(b):
@@ -152,22 +150,42 @@ def decode_boxes(pred, anchors, confidence_threshold=0.01, lid2name={}, detectio
     p = _preset_for(len(anchors))
     det = detect_batch(pred, p, confidence_threshold, detections_cap, None, nms=False)[0]
     out = DecodedBoxes(boxes_from_detection(det, lid2name))
-    out.source = (pred, p, confidence_threshold, detections_cap, lid2name)
+    out.source = (pred, p, confidence_threshold, detections_cap, lid2name, tuple(out))
     return out
 
 
+def _nms_list(boxes, groups, overlap_threshold):
+    """ssd_nms_boxes on a list of (confidence, Box): the reference's prop2abs on the 1000 grid
+    (ssdutils.py:244-249) is scalar host arithmetic, the sort and the suppression run on the GPU."""
+    from .utils import prop2abs
+    n = len(boxes)
+    if n == 0:
+        return []
+    if n > 65535:
+        raise ValueError('at most 65535 boxes per call')
+    arr = np.array([prop2abs(b[1].center, b[1].size, IMG1000) for b in boxes], np.int64).reshape(n, 4)
+    arr = np.ascontiguousarray(np.clip(arr, -(1 << 30), 1 << 30), np.int32)
+    conf = np.ascontiguousarray([b[0] for b in boxes], np.float32)
+    grp = None if groups is None else np.ascontiguousarray(groups, np.int32)
+    keep = np.empty(n, np.int32)
+    nk = C.c_int(0)
+    check(lib.ssd_nms_boxes(_lib.device(), n, np_ptr(arr), np_ptr(conf), np_ptr(grp), float(overlap_threshold), np_ptr(keep),
+                            C.byref(nk)))
+    return [boxes[int(i)] for i in keep[:nk.value]]
+
+
 def suppress_overlaps(boxes):
-    """ssdutils.py:310-318.  Boxes from decode_boxes go back through the fused GPU
-    decode+NMS; any other list of (confidence, Box) has no GPU-resident source and is refused."""
+    """ssdutils.py:310-318: per-class NMS at 0.45, classes in first-appearance order.  An untouched list
+    from decode_boxes goes back through the fused GPU decode + NMS (same result, no second upload);
+    any other list of (confidence, Box) runs through ssd_nms_boxes."""
     src = getattr(boxes, 'source', None)
-    if src is None:
-        if len(boxes) == 0:
-            return []
-        raise RuntimeError('suppress_overlaps needs the list returned by decode_boxes '
-                           '(use detect_batch for raw predictions); there is no CPU fallback')
-    pred, p, thr, cap, lid2name = src
-    det = detect_batch(pred, p, thr, cap, None, nms=True)[0]
-    return boxes_from_detection(det, lid2name)
+    if src is not None and len(boxes) == len(src[5]) and all(a is b for a, b in zip(boxes, src[5])):
+        pred, p, thr, cap, lid2name = src[:5]
+        det = detect_batch(pred, p, thr, cap, None, nms=True)[0]
+        return boxes_from_detection(det, lid2name)
+    rank = {}
+    groups = [rank.setdefault(b[1].labelid, len(rank)) for b in boxes]
+    return _nms_list(list(boxes), groups, 0.45)
 
 
 # ---- scalar / per-box helpers of the reference kept under their names (ssdutils.py:133-189) ----
@@ -182,7 +200,7 @@ def jaccard_overlap(box_arr, anchors_arr):
     a = np.ascontiguousarray(anchors_arr, np.float64).reshape(-1, 4)
     box = np.ascontiguousarray(box_arr, np.float64).reshape(4)
     iou = np.empty(a.shape[0], np.float64)
-    check(lib.ssd_jaccard_overlap(_DEVICE, np_ptr(box), np_ptr(a), a.shape[0], np_ptr(iou)))
+    check(lib.ssd_jaccard_overlap(_lib.device(), np_ptr(box), np_ptr(a), a.shape[0], np_ptr(iou)))
     return iou
 
 
@@ -216,11 +234,10 @@ def decode_location(box, anchor):
 
 
 def non_maximum_suppression(boxes, overlap_threshold):
-    """ssdutils.py:232-307 for one class.  Only the reference's own call (threshold 0.45 from
-    suppress_overlaps) is built: it maps to the fused GPU decode + NMS."""
-    if abs(overlap_threshold - 0.45) > 1e-12:
-        raise NotImplementedError('the HIP kernel implements the reference\'s 0.45 threshold (20*inter > 9*union)')
-    return suppress_overlaps(boxes)
+    """ssdutils.py:232-307 for one list of (confidence, Box) (the caller has grouped by class): greedy NMS
+    with intersection/union > overlap_threshold (any threshold), selected boxes in descending confidence.
+    Equal confidences: the earlier box first (the reference's argsort leaves that unspecified)."""
+    return _nms_list(list(boxes), None, overlap_threshold)
 
 
 _ANCHORS_ABS = {}
@@ -235,7 +252,7 @@ def has_positive_anchor(preset, boxes):
     key = preset.name
     if key not in _ANCHORS_ABS:
         out = np.empty((preset.num_anchors, 4), np.int32)
-        check(lib.ssd_anchors_abs(_pname(preset), _DEVICE, np_ptr(out)))
+        check(lib.ssd_anchors_abs(_pname(preset), _lib.device(), np_ptr(out)))
         _ANCHORS_ABS[key] = out.astype(np.float64)
     an = _ANCHORS_ABS[key]
     area_a = (an[:, 1] - an[:, 0] + 1) * (an[:, 3] - an[:, 2] + 1)
@@ -251,16 +268,35 @@ def has_positive_anchor(preset, boxes):
     return False
 
 
-def encode_labels_batch(preset, num_classes, gt_boxes_list, gt_cls_list):
-    """LabelCreatorTransform for a batch on the GPU: lists (one per image) of [n,4] float64
-    proportional (cx, cy, w, h) and [n] class ids -> [b, A, num_classes+5] float32."""
+def _pack_gt(gt_boxes_list, gt_cls_list):
     b = len(gt_boxes_list)
     offs = np.zeros(b + 1, np.int32)
     for i, g in enumerate(gt_boxes_list):
         offs[i + 1] = offs[i] + len(g)
     gt = np.concatenate([np.asarray(g, np.float64).reshape(-1, 4) for g in gt_boxes_list] + [np.zeros((0, 4))], 0)
     cls = np.concatenate([np.asarray(c, np.int32).reshape(-1) for c in gt_cls_list] + [np.zeros((0,), np.int32)], 0)
-    gt = np.ascontiguousarray(gt, np.float64); cls = np.ascontiguousarray(cls, np.int32)
+    return np.ascontiguousarray(gt, np.float64), np.ascontiguousarray(cls, np.int32), offs
+
+
+def encode_labels_batch(preset, num_classes, gt_boxes_list, gt_cls_list):
+    """LabelCreatorTransform for a batch on the GPU: lists (one per image) of [n,4] float64
+    proportional (cx, cy, w, h) and [n] class ids -> [b, A, num_classes+5] float32 (host)."""
+    b = len(gt_boxes_list)
+    gt, cls, offs = _pack_gt(gt_boxes_list, gt_cls_list)
     vec = np.empty((b, preset.num_anchors, num_classes + 5), np.float32)
-    check(lib.ssd_encode_labels(_pname(preset), int(num_classes), _DEVICE, np_ptr(gt), np_ptr(cls), np_ptr(offs), b, np_ptr(vec)))
+    check(lib.ssd_encode_labels(_pname(preset), int(num_classes), _lib.device(), np_ptr(gt), np_ptr(cls), np_ptr(offs), b, np_ptr(vec)))
     return vec
+
+
+def encode_labels_batch_dev(preset, num_classes, gt_boxes_list, gt_cls_list, device=None, out=None):
+    """The same, left in HBM: a float32 CUDA tensor [b, A, num_classes+5] on `device` (default: this module's
+    device).  The few ground-truth boxes go up, 873 KB per image never come down (ssd_encode_labels_dev)."""
+    import torch
+    device = _lib.device() if device is None else int(device)
+    b = len(gt_boxes_list)
+    gt, cls, offs = _pack_gt(gt_boxes_list, gt_cls_list)
+    if out is None:
+        out = torch.empty((b, preset.num_anchors, num_classes + 5), dtype=torch.float32, device=torch.device('cuda', device))
+    check(lib.ssd_encode_labels_dev(_pname(preset), int(num_classes), device, np_ptr(gt), np_ptr(cls), np_ptr(offs), b,
+                                    out.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    return out

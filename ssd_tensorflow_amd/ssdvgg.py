@@ -33,6 +33,24 @@ class _Token:
         return f'<ssd token {self.name}>'
 
 
+class _Detections:
+    """Ticket of SSDVGG.detect_last_launch."""
+    def __init__(self, net, serial, b, out_cap):
+        self.net, self.serial, self.b, self.out_cap = net, serial, b, out_cap
+
+    def get(self):
+        which = self.net._det_serial - self.serial
+        if which not in (0, 1):
+            raise RuntimeError('these detections were overwritten: only the two most recent passes are kept')
+        b, out_cap = self.b, self.out_cap
+        count = np.zeros(b, np.int32); conf = np.zeros((b, out_cap), np.float32)
+        cls = np.zeros((b, out_cap), np.int32); idx = np.zeros((b, out_cap), np.int32)
+        box = np.zeros((b, out_cap, 4), np.int32)
+        check(lib.ssd_detect_fetch(self.net._h, which, np_ptr(count), np_ptr(conf), np_ptr(cls), np_ptr(idx), np_ptr(box)))
+        return [dict(conf=conf[i, :min(count[i], out_cap)], cls=cls[i, :min(count[i], out_cap)],
+                     idx=idx[i, :min(count[i], out_cap)], box=box[i, :min(count[i], out_cap)]) for i in range(b)]
+
+
 class LearningRate:
     """compute_lr's result (train.py:43-47): piecewise-constant values over global_step."""
     def __init__(self, values, boundaries):
@@ -364,6 +382,15 @@ class SSDVGG:
             if cnt.value:
                 yield off.value, cnt.value
 
+    def set_loss_normalizer(self, batch):
+        """reduce_mean over `batch` samples instead of the step's own b (<= 0 restores the default): data
+        parallel shards of unequal size pass global_samples / world (parallel.train_step_dp)."""
+        check(lib.ssd_set_loss_normalizer(self._h, float(batch)))
+
+    def null_gradients_dev(self):
+        """The gradient arena of a step without samples: weight_decay * filters, zero elsewhere."""
+        check(lib.ssd_null_gradients_dev(self._h))
+
     def apply_gradients_dev(self, grad_scale=1.0):
         check(lib.ssd_apply_gradients_dev(self._h, float(grad_scale)))
 
@@ -384,20 +411,27 @@ class SSDVGG:
     def set_stream(self, stream_ptr):
         check(lib.ssd_set_stream(self._h, stream_ptr))
 
-    def detect_last(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):
-        """decode + NMS of the last step's result without leaving the GPU (train.py:275-277)."""
-        cap = -1 if detections_cap is None else int(detections_cap)
-        mo = -1 if max_out is None else int(max_out)
+    def _det_caps(self, cap, mo):
+        cap = -1 if cap is None else int(cap)
+        mo = -1 if mo is None else int(mo)
         out_cap = self.preset.num_anchors if cap < 0 else max(cap, 1)
         if mo >= 0:
             out_cap = max(min(out_cap, mo), 1)
-        count = np.zeros(b, np.int32); conf = np.zeros((b, out_cap), np.float32)
-        cls = np.zeros((b, out_cap), np.int32); idx = np.zeros((b, out_cap), np.int32)
-        box = np.zeros((b, out_cap, 4), np.int32)
-        check(lib.ssd_detect_last(self._h, b, float(confidence_threshold), cap, mo, out_cap, 1 if nms else 0,
-                                  np_ptr(count), np_ptr(conf), np_ptr(cls), np_ptr(idx), np_ptr(box)))
-        return [dict(conf=conf[i, :min(count[i], out_cap)], cls=cls[i, :min(count[i], out_cap)],
-                     idx=idx[i, :min(count[i], out_cap)], box=box[i, :min(count[i], out_cap)]) for i in range(b)]
+        return cap, mo, out_cap
+
+    def detect_last_launch(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):
+        """Enqueue decode + NMS of the last step's result and the copy of its (small) output; returns a
+        ticket whose get() yields what detect_last returns.  Two output slots alternate in the handle, so a
+        caller may launch the next batch before it collects this one (infer.py:225-235, pipelined)."""
+        cap, mo, out_cap = self._det_caps(detections_cap, max_out)
+        check(lib.ssd_detect_last_dev(self._h, b, float(confidence_threshold), cap, mo, out_cap, 1 if nms else 0,
+                                      None, None, None, None, None))
+        self._det_serial = getattr(self, '_det_serial', 0) + 1
+        return _Detections(self, self._det_serial, b, out_cap)
+
+    def detect_last(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):
+        """decode + NMS of the last step's result without leaving the GPU (train.py:275-277)."""
+        return self.detect_last_launch(b, confidence_threshold, detections_cap, max_out, nms).get()
 
     # ------------------------------------------------------------------ Session.run routing
     def _run(self, fetches, feed):
@@ -407,14 +441,15 @@ class SSDVGG:
         y = feed.get(self.labels) if self.labels is not None else None
         want_opt = any(f is self.optimizer for f in fetches if self.optimizer is not None)
         want_loss = any(isinstance(f, dict) or (self.losses and f in self.losses.values()) for f in fetches)
+        want_res = any(f is self.result for f in fetches)      # the [b, A, C+5] copy to the host only when fetched
         if want_opt:
             if y is None:
                 raise ValueError('feed_dict must hold net.labels')
-            res, L = self.train_step(x, y)
+            res, L = self.train_step(x, y, want_res)
         elif want_loss:
             if y is None:
                 raise ValueError('feed_dict must hold net.labels')
-            res, L = self.eval_step(x, y)
+            res, L = self.eval_step(x, y, want_res)
         else:
             res, L = self.infer(x), None
         out = []

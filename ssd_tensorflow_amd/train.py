@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Training driver: the counterpart of the reference's train.py loop (train.py:247-343) over
-the HIP library.  Same flags (train.py:55-80) plus --preset / --synthetic-train / --synthetic-valid.
-TensorBoard summaries, AP bookkeeping and image dumps are out of scope.
+the HIP library.  Same flags (train.py:55-80) plus --preset / --synthetic-train / --synthetic-valid /
+--augment / --dtype / --allreduce-bucket-mb.  Scalar summaries go to <tensorboard-dir>/<name>/scalars.jsonl
+(summaries.py); image summaries and TensorBoard event files are out of scope.
 
     python -m ssd_tensorflow_amd.train --name run1 --epochs 2 --batch-size 8
     python -m torch.distributed.run --nproc-per-node 8 -m ssd_tensorflow_amd.train ...   # data parallel
-"""
+
+A batch never leaves the GPU: the feeder hands out device tensors, the step runs on them, decode + NMS
+for the AP bookkeeping runs on the result where it lies (the reference fetches `result` to the host for
+decode_boxes, train.py:262-277).  Data parallel: one process per GPU, rank-sharded batches, bucketed
+all-reduce of the gradient arena overlapped with backward (parallel.train_step_dp)."""
 import argparse
 import math
 import os
@@ -13,12 +18,18 @@ import sys
 
 import numpy as np
 
-from . import parallel
+from . import _lib, parallel
 from .average_precision import APCalculator, APs2mAP
 from .ssdutils import boxes_from_detection
 from .ssdvgg import SSDVGG, Session, LearningRate
+from .summaries import SummaryWriter, LossSummary, PrecisionSummary
 from .training_data import TrainingData
 from .utils import str2bool
+
+
+def compute_lr(lr_values, lr_boundaries):
+    """train.py:43-47"""
+    return LearningRate(lr_values, lr_boundaries)
 
 
 def main(argv=None):
@@ -28,7 +39,7 @@ def main(argv=None):
     parser.add_argument('--vgg-dir', default='vgg_graph', help='directory for the VGG-16 model')
     parser.add_argument('--epochs', type=int, default=200, help='number of training epochs')
     parser.add_argument('--batch-size', type=int, default=8, help='batch size (per GPU)')
-    parser.add_argument('--tensorboard-dir', default='tb', help='name of the tensorboard data directory')
+    parser.add_argument('--tensorboard-dir', default='tb', help='name of the summary data directory')
     parser.add_argument('--checkpoint-interval', type=int, default=5, help='checkpoint interval')
     parser.add_argument('--lr-values', type=str, default='0.00075;0.0001;0.00001', help='learning rate values')
     parser.add_argument('--lr-boundaries', type=str, default='320000;400000', help='learning rate chage boundaries (in batches)')
@@ -37,23 +48,31 @@ def main(argv=None):
     parser.add_argument('--continue-training', type=str2bool, default='False', help='continue training from the latest checkpoint')
     parser.add_argument('--num-workers', type=int, default=0, help='number of parallel generators')
     parser.add_argument('--preset', default='vgg300')
+    parser.add_argument('--data-source', default='pascal_voc', help='data source module for a real --data-dir')
     parser.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='f32, or bf16 activations on the bf16 matrix cores (fp32 master weights, loss and optimizer)')
     parser.add_argument('--synthetic-train', type=int, default=64, help='synthetic training samples per epoch')
     parser.add_argument('--synthetic-valid', type=int, default=16)
     parser.add_argument('--augment', type=str2bool, default='False', help="run the reference's train augmentation recipe (process_dataset.py) on the GPU over a uint8 synthetic dataset")
+    parser.add_argument('--allreduce-bucket-mb', type=float, default=16, help='data parallel: all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     args = parser.parse_args(argv)
 
     rank, local, world = parallel.init()
+    import torch
+    torch.cuda.set_device(local)           # every backend: kernels, .cuda() tensors and collectives of this rank on ITS GPU
+    _lib.set_device(local)                 # ... and the package's free functions (label encoder, AP)
     say = print if rank == 0 else (lambda *a, **k: None)
     say('[i] Project name:         ', args.name)
     say('[i] Data directory:       ', args.data_dir)
     say('[i] # epochs:             ', args.epochs)
     say('[i] Batch size:           ', args.batch_size, 'x', world, 'GPU(s)')
+    say('[i] Tensorboard directory:', args.tensorboard_dir)
+    say('[i] Checkpoint interval:  ', args.checkpoint_interval)
     say('[i] Learning rate values: ', args.lr_values)
     say('[i] Learning rate boundaries: ', args.lr_boundaries)
     say('[i] Momentum:             ', args.momentum)
     say('[i] Weight decay:         ', args.weight_decay)
     say('[i] Continue:             ', args.continue_training)
+    say('[i] Number of workers:    ', args.num_workers)
 
     try:
         lr_values = [float(v) for v in args.lr_values.split(';')]
@@ -67,18 +86,22 @@ def main(argv=None):
     start_epoch = 0
     ckpt = None
     if args.continue_training:
-        cands = [f for f in (os.listdir(args.name) if os.path.isdir(args.name) else []) if f.startswith('e') and f.endswith('.npz')]
+        cands = [f for f in (os.listdir(args.name) if os.path.isdir(args.name) else [])
+                 if f.startswith('e') and f.endswith('.npz') and f[1:-4].isdigit()]
         if not cands:
             print('[!] No network state found in ' + args.name); return 1
         start_epoch = max(int(f[1:-4]) for f in cands)
         ckpt = os.path.join(args.name, f'e{start_epoch}.npz')
         say('[i] Last checkpoint:      ', ckpt)
     elif rank == 0:
-        os.makedirs(args.name, exist_ok=True)
+        try:
+            os.makedirs(args.name, exist_ok=True)
+        except OSError as e:
+            print('[!] Cannot create directory {}: {}'.format(args.name, e)); return 1      # train.py:143-145
 
     try:
         td = TrainingData(args.data_dir, args.preset, args.synthetic_train, args.synthetic_valid, rank=rank, world=world,
-                          augment=args.augment, device=local)
+                          augment=args.augment, device=local, data_source=args.data_source)
     except RuntimeError as e:
         print('[!] Unable to load training data:', str(e)); return 1                       # train.py:155-161
     say('[i] # training samples:   ', td.num_train)
@@ -86,8 +109,17 @@ def main(argv=None):
     say('[i] # classes:            ', td.num_classes)
     say('[i] Image size:           ', td.preset.image_size)
 
-    import torch
-    lr = LearningRate(lr_values, lr_boundaries)
+    lr = compute_lr(lr_values, lr_boundaries)
+    bucket = int(args.allreduce_bucket_mb * 1e6 / 4)
+    dev = torch.device('cuda', local)
+
+    def rank_sum(values):
+        if world <= 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t)
+        return t.tolist()
+
     with Session(local) as sess:
         say('[i] Creating the model...')
         net = SSDVGG(sess, td.preset)
@@ -101,52 +133,84 @@ def main(argv=None):
             torch.distributed.broadcast(net.params_flat, 0)
         net.set_stream(torch.cuda.current_stream().cuda_stream)
 
+        writer = SummaryWriter(os.path.join(args.tensorboard_dir, os.path.basename(os.path.normpath(args.name)))) if rank == 0 else None
         training_ap_calc = APCalculator()
         validation_ap_calc = APCalculator()
+        labels = list(td.lname2id.keys())
+        training_ap = PrecisionSummary(writer, 'training', labels)
+        validation_ap = PrecisionSummary(writer, 'validation', labels)
+        training_loss = LossSummary(writer, 'training', td.num_train)
+        validation_loss = LossSummary(writer, 'validation', td.num_valid)
+
+        def collect(dets, gt_boxes, calc):
+            if dets is None:
+                return
+            for gt, det in zip(gt_boxes, dets.get()):
+                calc.add_detections(gt, boxes_from_detection(det, td.lid2name))
+
         say('[i] Training...')
         for e in range(start_epoch, args.epochs):
             td.epoch = e
             # ---- train (train.py:254-281) --------------------------------------------------------
-            tot = np.zeros(4); seen = 0
+            pending = None
             for x, y, gt_boxes in td.train_generator(args.batch_size, args.num_workers):
+                n = len(gt_boxes)
                 if world > 1:
-                    xt = x if torch.is_tensor(x) else torch.from_numpy(x).cuda(non_blocking=True)
-                    yt = torch.from_numpy(y).cuda(non_blocking=True)
-                    parallel.train_step_dp(net, xt, yt, world)
-                    loss_batch = net.get_losses()
+                    parallel.train_step_dp(net, x, y, world, bucket, td.global_count)
+                    # this rank's losses are normalised by global_count / world: their sum over ranks is world x the
+                    # global-batch loss, so each rank books its share of the batch's samples
+                    loss_batch, weight = net.get_losses(), td.global_count / world
                 else:
-                    result, loss_batch, _ = sess.run([net.result, net.losses, net.optimizer],
-                                                     feed_dict={net.image_input: x, net.labels: y})
+                    loss_batch, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+                    weight = n
                 if math.isnan(loss_batch['confidence']):
                     print('[!] Confidence loss is NaN.')
-                tot += np.array([loss_batch[k] for k in ('total', 'localization', 'confidence', 'l2')]) * x.shape[0]
-                seen += x.shape[0]
-                if e == 0:
+                training_loss.add(loss_batch, weight)
+                if e == 0 or n == 0:
                     continue
-                # decode + NMS of the batch just computed, on the GPU (train.py:275-277), then AP bookkeeping
-                dets = net.detect_last(x.shape[0], 0.5, 200, None)
-                for i in range(x.shape[0]):
-                    training_ap_calc.add_detections(gt_boxes[i], boxes_from_detection(dets[i], td.lid2name))
-            tot = np.array(parallel.mean_scalars(tot / max(seen, 1), world, 'cuda' if world > 1 else None))
-            say('[i] Train {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(e + 1, args.epochs, *tot))
+                # decode + NMS of the batch just computed, on the GPU (train.py:275-277); the detections of batch k
+                # are collected after batch k+1 has been launched
+                launched = net.detect_last_launch(n, 0.5, 200, None)
+                collect(pending[0], pending[1], training_ap_calc) if pending else None
+                pending = (launched, gt_boxes)
+            if pending:
+                collect(pending[0], pending[1], training_ap_calc)
             # ---- validate (train.py:286-306) ---------------------------------------------------
-            vt = np.zeros(4); vs = 0
+            pending = None
             for x, y, gt_boxes in td.valid_generator(args.batch_size, args.num_workers):
-                result, loss_batch = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
-                vt += np.array([loss_batch[k] for k in ('total', 'localization', 'confidence', 'l2')]) * x.shape[0]
-                vs += x.shape[0]
+                n = len(gt_boxes)
+                if n == 0:
+                    continue
+                if world > 1:
+                    net.set_loss_normalizer(td.global_count / world)
+                loss_batch = sess.run(net.losses, feed_dict={net.image_input: x, net.labels: y})
+                if world > 1:
+                    net.set_loss_normalizer(0.0)
+                validation_loss.add(loss_batch, td.global_count / world if world > 1 else n)
                 if e == 0:
                     continue
-                dets = net.detect_last(x.shape[0], 0.5, 200, None)
-                for i in range(x.shape[0]):
-                    validation_ap_calc.add_detections(gt_boxes[i], boxes_from_detection(dets[i], td.lid2name))
-            vt = np.array(parallel.mean_scalars(vt / max(vs, 1), world, 'cuda' if world > 1 else None))
-            say('[i] Valid {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(e + 1, args.epochs, *vt))
-            # ---- mAP of this rank's shard (train.py:317-323, VOC07 11-point, on the GPU) ---------------------
+                launched = net.detect_last_launch(n, 0.5, 200, None)
+                collect(pending[0], pending[1], validation_ap_calc) if pending else None
+                pending = (launched, gt_boxes)
+            if pending:
+                collect(pending[0], pending[1], validation_ap_calc)
+            # ---- summaries (train.py:311-331) -----------------------------------------------------
+            tl = training_loss.push(e + 1, rank_sum)
+            vl = validation_loss.push(e + 1, rank_sum)
+            say('[i] Train {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(
+                e + 1, args.epochs, tl['total'], tl['localization'], tl['confidence'], tl['l2']))
+            say('[i] Valid {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(
+                e + 1, args.epochs, vl['total'], vl['localization'], vl['confidence'], vl['l2']))
+            # mAP of this rank's shard (VOC07 11-point, on the GPU); rank 0's is reported
+            APs = training_ap_calc.compute_aps(); mAP = APs2mAP(APs)
+            training_ap.push(e + 1, mAP, APs)
+            vAPs = validation_ap_calc.compute_aps(); vmAP = APs2mAP(vAPs)
+            validation_ap.push(e + 1, vmAP, vAPs)
             if e > 0:
-                say('[i] mAP  {:>2}/{}  training {:.4f}  validation {:.4f}'.format(
-                    e + 1, args.epochs, APs2mAP(training_ap_calc.compute_aps()), APs2mAP(validation_ap_calc.compute_aps())))
+                say('[i] mAP  {:>2}/{}  training {:.4f}  validation {:.4f}'.format(e + 1, args.epochs, mAP, vmAP))
             training_ap_calc.clear(); validation_ap_calc.clear()
+            if writer is not None:
+                writer.flush()
             # ---- checkpoint (train.py:336-343) -------------------------------------------------
             if (e + 1) % args.checkpoint_interval == 0 and rank == 0:
                 path = '{}/e{}.npz'.format(args.name, e + 1)
@@ -156,6 +220,10 @@ def main(argv=None):
             path = '{}/final.npz'.format(args.name)
             net.save_checkpoint(path, lr, args.momentum, args.weight_decay)
             print('[i] Checkpoint saved:', path)
+        if writer is not None:
+            writer.close()
+    if world > 1:
+        torch.distributed.barrier()
     return 0
 
 

@@ -15,6 +15,7 @@ flip? -> resize.  A transform applied outside that order raises NotImplementedEr
 silently producing something else.
 """
 import ctypes as C
+import os
 import random
 from math import sqrt
 
@@ -75,16 +76,31 @@ class Transform:
         self.initialized = False
 
 
+def load_image_bgr(filename):
+    """cv2.imread(filename) without OpenCV: a .npy file holds the uint8 BGR array itself; anything else is
+    decoded by Pillow (RGB -> BGR).  Decoder parity with OpenCV is unpinned (no cv2 in the build container)."""
+    if filename.endswith('.npy'):
+        return np.load(filename)
+    if os.path.exists(filename + '.npy'):
+        return np.load(filename + '.npy')
+    try:
+        from PIL import Image
+    except ImportError:
+        raise RuntimeError('cannot decode %r: neither OpenCV nor Pillow is available (use .npy images)' % (filename,))
+    with Image.open(filename) as im:
+        return np.ascontiguousarray(np.asarray(im.convert('RGB'))[:, :, ::-1])
+
+
 class ImageLoaderTransform(Transform):
-    """transforms.py:38-43 reads gt.filename with cv2.imread.  Without OpenCV the pixels come from `images`
-    (a mapping filename -> uint8 BGR array) or from a .npy file of that name."""
+    """transforms.py:38-43 reads gt.filename with cv2.imread.  Here the pixels come from `images` (a mapping
+    filename -> uint8 BGR array) when given, else from load_image_bgr (a .npy array or a Pillow decode)."""
     def __call__(self, data, label, gt):
         images = getattr(self, 'images', None)
         if images is not None and gt.filename in images:
             return ImagePlan(images[gt.filename]), label, gt
-        if isinstance(gt.filename, str) and gt.filename.endswith('.npy'):
-            return ImagePlan(np.load(gt.filename)), label, gt
-        raise RuntimeError('cannot load %r: no OpenCV in this build (pass images={filename: uint8 BGR array} or a .npy file)' % (gt.filename,))
+        if isinstance(gt.filename, str):
+            return ImagePlan(load_image_bgr(gt.filename)), label, gt
+        raise RuntimeError('cannot load %r' % (gt.filename,))
 
 
 class LabelCreatorTransform(Transform):

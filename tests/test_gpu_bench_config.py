@@ -1,0 +1,137 @@
+"""-m gpu: parity AT THE BENCHMARKED CONFIGURATIONS (BASELINE.json configs[1] / configs[3] per GPU): vgg300 at batch 32
+and vgg512 at batch 16 -- the sizes at which the cost model picks the 128x128 / 64x128 tiles, the round-aware
+weight-gradient splits and the large-M kernels that a batch-2 test never launches -- and the end-to-end gradient
+against the oracle evaluated in float64.  Tolerance 1e-3 relative (north_star).  The CPU oracle needs tens of seconds
+per case on the GPU box's host cores."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import ssdvgg_ref as ref
+from gpu_util import rel_err, max_rel
+from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+from test_gpu_model import make_pair, layer_local_backward_check, report, TOL, WD
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bench_inputs(pname, b, seed=1234):
+    """bench.py's rank-0 inputs: images then boxes from ONE default_rng(1234) stream, labels by the label oracle."""
+    import bench
+    preset = ob.get_preset(pname)
+    rng = np.random.default_rng(seed)
+    H, W = preset['image_size'][1], preset['image_size'][0]
+    x = rng.integers(0, 256, (b, H, W, 3)).astype(np.float32)
+    gt, cls, offs = bench.synth_gt(rng, b)
+    anch = ob.anchors(preset); aabs = ob.anchors_abs(anch)
+    y = np.stack([ob.encode_labels(gt[offs[i]:offs[i + 1]], cls[offs[i]:offs[i + 1]], preset, 20, anch, aabs) for i in range(b)])
+    return preset, x, y
+
+
+def oracle_forward_chunked(m, x, y, chunk=4):
+    """result and the four losses at batch b from chunks (the loss is a mean of per-sample terms)."""
+    b = x.shape[0]
+    res, L = [], {'localization': 0.0, 'confidence': 0.0}
+    for i0 in range(0, b, chunk):
+        r, Lc = m.eval_step(x[i0:i0 + chunk], y[i0:i0 + chunk])
+        n = r.shape[0]
+        res.append(r)
+        for k in L:
+            L[k] += Lc[k] * n / b
+        L['l2'] = Lc['l2']
+    L['total'] = L['localization'] + L['confidence'] + L['l2']
+    return np.concatenate(res), L
+
+
+BENCH_LAYERS = {'vgg300': ['conv1_2', 'conv2_2', 'conv3_2', 'conv4_2', 'mod_conv6', 'heads/map0', 'heads/map1', 'conv8_2', 'pool1', 'mod_pool5'],
+                'vgg512': ['conv1_2', 'conv2_2', 'conv3_3', 'conv4_1', 'conv5_1', 'mod_conv7', 'heads/map0', 'conv10_2', 'conv12_2', 'pool2']}
+
+
+@pytest.mark.parametrize('pname,b', [('vgg300', 32), ('vgg512', 16)])
+def test_benchmarked_batch_forward_loss_and_layer_local_backward(pname, b):
+    preset, x, y = bench_inputs(pname, b)
+    w = ref.init_params(preset, 20, seed=42, alive=True)        # every layer alive (Xavier + 0..255 input dies past mod_conv7)
+    m = ref.RefModel(pname, params=w)
+    m.set_optimizer([0.00075], [], 0.9, WD)
+    sess = Session(0)
+    net = SSDVGG(sess, pname)
+    net.build_from_vgg(None, 20, max_batch=b, weights=w)
+    net.build_optimizer(learning_rate=0.00075, weight_decay=WD, momentum=0.9)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    net.forward_dev(xt, yt)
+    L = net.get_losses()
+    r = net._dev_result(b, True)
+    r_ref, L_ref = oracle_forward_chunked(m, x, y)
+    assert report(f'{pname} b={b} result', max_rel(r, r_ref)) < TOL
+    for k in L_ref:
+        assert abs(L[k] - L_ref[k]) < TOL * abs(L_ref[k]), (k, L[k], L_ref[k])
+    # backward of the layers whose kernels / tiles only exist at this batch, recomputed by the oracle from the GPU's
+    # own input activation and output gradient of that layer
+    net.forward_backward_dev(xt, yt)
+    torch.cuda.synchronize()
+    worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y, only=BENCH_LAYERS[pname])
+    print('    worst layer-local weight-gradient error', worst_w, ' data-gradient error', worst_x)
+    assert worst_w < TOL and worst_x < TOL
+    sess.close()
+
+
+def test_bench_step0_losses_equal_stored_oracle_values():
+    """The stored step-0 losses bench.py checks itself against (tests/golden/bench_expect.json, made on the CPU by
+    tools/make_bench_expect.py from oracle.init_params_lib weights): (1) the library's own initial weights ARE that
+    restatement, bit for bit; (2) the GPU's step-0 losses on bench.py's inputs equal the stored values to 1e-3."""
+    table = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expect.json')))
+    for pname, b in (('vgg300', 32), ('vgg512', 16)):
+        preset, x, y = bench_inputs(pname, b)
+        sess = Session(0)
+        net = SSDVGG(sess, pname)
+        net.build_from_vgg(None, 20, max_batch=b, seed=42)
+        net.build_optimizer(learning_rate=0.00075, weight_decay=WD, momentum=0.9)
+        w_lib = net.save_variables()
+        w_ref = ref.init_params_lib(preset, 20, seed=42)
+        assert set(w_lib) == set(w_ref)
+        for k in w_ref:
+            assert np.array_equal(w_lib[k], w_ref[k]), k
+        net.eval_step_dev(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+        L = net.get_losses()
+        want = table[f'{pname}_b{b}']
+        for k in want:
+            assert abs(L[k] - want[k]) < TOL * abs(want[k]), (pname, k, L[k], want[k])
+        sess.close()
+
+
+def test_end_to_end_gradient_error_is_flips_not_bias():
+    """The end-to-end gradient of the 30-layer relu / max-pool net differs from the fp32 oracle by up to ~1e-2 in the
+    trunk (tests/test_gpu_model.py allows 3e-2).  Is that the chaos of relu / argmax flips, or a systematic error of
+    some GPU layer?  Evaluate the oracle in FLOAT64 (flips decided by exact arithmetic): the GPU's distance to that
+    ground truth must not exceed the fp32 oracle's own distance to it by more than a small factor, per variable."""
+    b = 2
+    preset, m, sess, net = make_pair('vgg300', b)
+    rng = np.random.default_rng(1234)
+    x, y, _ = ref.synth_batch(rng, b, preset)
+    m.set_optimizer([0.001], [], 0.9, WD)
+    net.build_optimizer(learning_rate=0.001, weight_decay=WD, momentum=0.9)
+    net.forward_backward_dev(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    g_gpu = net.save_gradients()
+    _, _, g32 = m.grads(x, y)
+    # the same graph in float64
+    p64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in m.params.items()}
+    out, _ = ref.forward(p64, torch.as_tensor(x, dtype=torch.float64), preset, 20)
+    L64 = ref.losses(out, torch.as_tensor(y, dtype=torch.float64), p64, 20, WD)
+    L64['total'].backward()
+    g64 = {k: p.grad.numpy() for k, p in p64.items()}
+    worst_ratio, worst_gpu = 0.0, 0.0
+    for k in g64:
+        e_gpu = rel_err(g_gpu[k], g64[k]); e_32 = rel_err(g32[k], g64[k])
+        worst_gpu = max(worst_gpu, e_gpu)
+        if e_32 > 1e-6:
+            worst_ratio = max(worst_ratio, e_gpu / e_32)
+        # wherever fp32 arithmetic itself is clean against float64, so is the GPU; elsewhere it is no worse than fp32-on-CPU
+        assert e_gpu < max(4.0 * e_32, 2e-5), (k, e_gpu, e_32)
+    print(f'    worst GPU-vs-f64 gradient rel-L2 {worst_gpu:.3e}; worst ratio to the fp32 oracle\'s own error {worst_ratio:.2f}')
+    sess.close()

@@ -121,8 +121,82 @@ def test_decode_boxes_and_suppress_overlaps_mirror():
     keep = g[f'keep_{tag}']
     assert [float(s[0]) for s in sel] == [float(c) for c in g[f'conf_{tag}'][keep]]
     assert su.suppress_overlaps([]) == []
-    with pytest.raises(RuntimeError):
-        su.suppress_overlaps([(0.9, boxes[0][1])])
+    # a list that is not decode_boxes' own goes through the general box-list NMS: same survivors
+    plain = list(boxes)
+    sel2 = su.suppress_overlaps(plain)
+    assert [(float(c), b) for c, b in sel2] == [(float(c), b) for c, b in sel]
+    assert su.suppress_overlaps([(0.9, boxes[0][1])]) == [(0.9, boxes[0][1])]
+    # ... and a filtered list follows the reference on what is left (oracle: ssdutils.py:232-318 restated)
+    part = [bx for i, bx in enumerate(boxes) if i % 3 != 1]
+    want = ob.suppress_list([(float(c), b.labelid, ob.prop2abs(b.center.x, b.center.y, b.size.w, b.size.h)) for c, b in part], 0.45)
+    got = su.suppress_overlaps(part)
+    assert [part.index(g) for g in got] == want
+
+
+def test_nms_boxes_golden():
+    """ssd_nms_boxes behind suppress_overlaps / non_maximum_suppression vs picks captured from the reference (G10)."""
+    g = load('g10_nms_lists.npz')
+    for case in range(int(g['ncases'][0])):
+        box, conf, lab = g[f'box_{case}'], g[f'conf_{case}'], g[f'label_{case}']
+        boxes = [(conf[i], Box('c%d' % lab[i], int(lab[i]), Point(float(box[i, 0]), float(box[i, 1])), Size(float(box[i, 2]), float(box[i, 3]))))
+                 for i in range(len(conf))]
+        got = su.suppress_overlaps(boxes)
+        assert [next(i for i, bx in enumerate(boxes) if bx is s_) for s_ in got] == list(g[f'keep_{case}']), case
+        one = [boxes[i] for i in g[f'one_{case}']]
+        got = su.non_maximum_suppression(one, float(g[f'thr_{case}'][0]))
+        assert [next(i for i, bx in enumerate(one) if bx is s_) for s_ in got] == list(g[f'keep1_{case}']), case
+
+
+def test_nms_boxes_general_threshold_and_order():
+    """ssd_nms_boxes against the numpy restatement of non_maximum_suppression / suppress_overlaps on random box lists:
+    any threshold, class groups in first-appearance order, negative and tied confidences."""
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        n = int(rng.integers(1, 400))
+        cx = rng.uniform(0.1, 0.9, n); cy = rng.uniform(0.1, 0.9, n)
+        w = rng.uniform(0.05, 0.5, n); h = rng.uniform(0.05, 0.5, n)
+        conf = rng.uniform(-0.2, 1.0, n).astype(np.float32)
+        if case % 3 == 0:
+            conf = np.round(conf * 8) / 8                      # many exact ties
+        lab = rng.integers(0, 6, n) * 7 - 3                     # arbitrary label ids, negative included
+        boxes = [(np.float32(conf[i]), Box('c%d' % lab[i], int(lab[i]), Point(float(cx[i]), float(cy[i])), Size(float(w[i]), float(h[i]))))
+                 for i in range(n)]
+        thr = [0.45, 0.3, 0.6, 0.05][case % 4]
+        recs = [(float(c), b.labelid, ob.prop2abs(b.center.x, b.center.y, b.size.w, b.size.h)) for c, b in boxes]
+        if thr == 0.45:
+            got = su.suppress_overlaps(boxes)
+            assert [boxes.index(g) for g in got] == ob.suppress_list(recs, 0.45), case
+        one = [bx for bx in boxes if bx[1].labelid == boxes[0][1].labelid]
+        got = su.non_maximum_suppression(one, thr)
+        want = ob.nms_list([(float(c), ob.prop2abs(b.center.x, b.center.y, b.size.w, b.size.h)) for c, b in one], thr)
+        assert [one.index(g) for g in got] == want, case
+    assert su.non_maximum_suppression([], 0.5) == []
+
+
+def test_detect_fast_and_general_paths_agree_with_oracle():
+    """<= 1024 candidates per image run entirely in LDS (rank sort), more take the bitonic path: both against the oracle,
+    in one batch (image 0 few, image 1 > 1024, image 2 none, image 3 exactly capped)."""
+    rng = np.random.default_rng(99)
+    A = 8732
+    preset = su.get_preset_by_name('vgg300')
+    oa = ob.anchors(ob.get_preset('vgg300'))
+    pred = np.zeros((4, A, 25), np.float32); pred[:, :, 20] = 1
+    for i, ncand in enumerate((300, 1500, 0, 1024)):
+        hot = rng.choice(A, ncand, replace=False)
+        cls = rng.integers(0, 20, ncand)
+        conf = rng.uniform(0.2, 0.99, ncand).astype(np.float32)
+        pred[i, hot, 20] = 1 - conf
+        pred[i, hot, cls] = conf
+        pred[i, :, 21:] = rng.normal(0, 0.3, (A, 4))
+    for thr, cap, mo in ((0.2, None, 200), (0.2, 200, None), (0.5, None, None), (0.2, 1100, 400)):
+        for nms in (True, False):
+            dets = su.detect_batch(pred, preset, thr, cap, mo, nms=nms)
+            for i in range(4):
+                ref = ob.detect(pred[i], oa, thr, cap, mo) if nms else ob.decode(pred[i], oa, thr, cap)
+                n = len(dets[i]['idx'])
+                assert np.array_equal(dets[i]['idx'], ref['idx'][:n]) and np.array_equal(dets[i]['box'], ref['box'][:n]), (thr, cap, mo, nms, i)
+                assert np.array_equal(dets[i]['conf'], ref['conf'][:n]) and np.array_equal(dets[i]['cls'], ref['cls'][:n])
+                assert n == (len(ref['idx']) if mo is None else min(len(ref['idx']), mo))
 
 
 def test_detect_batch_properties_full_size():

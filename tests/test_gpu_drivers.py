@@ -1,0 +1,145 @@
+"""-m gpu: the training / inference drivers end to end (the reference's train.py:99-134,256-343 and infer.py:111-280
+over the HIP library): flags, printed lines, checkpoints under the reference's TF variable names, resume, summaries,
+the `[!]` error exits, and a real (tiny) Pascal-VOC directory through the data source + transform recipe."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ssd_tensorflow_amd import train, infer
+
+pytestmark = pytest.mark.gpu
+
+COMMON = ['--batch-size', '4', '--synthetic-train', '10', '--synthetic-valid', '4', '--checkpoint-interval', '1',
+          '--lr-values', '0.0001;0.00001', '--lr-boundaries', '4']
+
+
+def test_train_resume_infer_cycle(tmp_path, capsys):
+    run = str(tmp_path / 'run'); tb = str(tmp_path / 'tb')
+    assert train.main(['--name', run, '--tensorboard-dir', tb, '--epochs', '2'] + COMMON) == 0
+    out = capsys.readouterr().out
+    for needle in ('[i] Project name:', '[i] # training samples:    10', '[i] Train  1/2  total', 'localization', 'confidence', 'l2',
+                   '[i] Valid  2/2', '[i] mAP   2/2', 'Checkpoint saved: ' + run + '/e2.npz', run + '/final.npz'):
+        assert needle in out, needle
+    assert sorted(os.listdir(run)) == ['e1.npz', 'e2.npz', 'final.npz']
+    ck = np.load(run + '/e2.npz')
+    for k in ('conv1_1/filter', 'conv5_3/biases', 'mod_conv6/filter', 'mod_conv7/biases', 'conv11_2/filter',
+              'classifiers/classifier0_3/filter', 'classifiers/classifier5_0/biases', 'l2_norm_conv4_3/scale',
+              '__momentum__/conv4_2/filter', '__global_step__', '__lr_values__', '__lr_boundaries__'):
+        assert k in ck.files, k
+    assert ck['conv1_1/filter'].shape == (3, 3, 3, 64) and ck['classifiers/classifier1_5/filter'].shape == (3, 3, 1024, 25)
+    assert int(ck['__global_step__']) == 6                          # 2 epochs x ceil(10 / 4) batches
+    tags = {json.loads(l)['tag'] for l in open(os.path.join(tb, 'run', 'scalars.jsonl'))}
+    assert {'training_total_loss', 'training_confidence_loss', 'validation_l2_loss', 'validation_localization_loss'} <= tags
+
+    # an uninterrupted 3-epoch run vs. resuming the 2-epoch run for a third epoch: bit-identical weights and momentum
+    straight = str(tmp_path / 'straight')
+    assert train.main(['--name', straight, '--tensorboard-dir', tb, '--epochs', '3'] + COMMON) == 0
+    capsys.readouterr()
+    assert train.main(['--name', run, '--tensorboard-dir', tb, '--epochs', '3', '--continue-training', 'true'] + COMMON) == 0
+    out = capsys.readouterr().out
+    assert '[i] Last checkpoint:       ' + run + '/e2.npz' in out and '[i] Train  3/3' in out and '[i] Train  2/3' not in out
+    a, b = np.load(run + '/final.npz'), np.load(straight + '/final.npz')
+    assert int(a['__global_step__']) == int(b['__global_step__']) == 9          # the LR schedule position is restored
+    for k in b.files:
+        assert np.array_equal(a[k], b[k]), k
+
+    # inference from the checkpoint directory: latest = final.npz; VOC summary files; raw prediction dumps
+    odir = str(tmp_path / 'out')
+    assert infer.main(['--name', run, '--synthetic', '5', '--batch-size', '4', '--threshold', '0.01', '--pascal-summary', 'true',
+                       '--dump-predictions', 'true', '--output-dir', odir]) == 0
+    out = capsys.readouterr().out
+    assert '[i] Network checkpoint: ' + run + '/final.npz' in out and '[i] Processed 5 images' in out and '[i] All done.' in out
+    dumps = sorted(f for f in os.listdir(odir) if f.endswith('.npy'))
+    assert len(dumps) == 5 and np.load(os.path.join(odir, dumps[0])).shape == (8732, 25)
+    for f in os.listdir(odir):
+        if f.startswith('comp4_det_test_'):
+            for line in open(os.path.join(odir, f)):
+                parts = line.split()
+                assert len(parts) == 6 and 1.0 <= float(parts[2]) <= 300.0 and 1.0 <= float(parts[5]) <= 300.0
+    assert infer.main(['--name', run, '--checkpoint', '1', '--synthetic', '2', '--output-dir', odir]) == 0
+    assert run + '/e1.npz' in capsys.readouterr().out
+
+
+def test_driver_error_exits(tmp_path, capsys):
+    empty = str(tmp_path / 'empty'); os.makedirs(empty)
+    assert train.main(['--name', empty, '--continue-training', 'true'] + COMMON) == 1                       # train.py:104-106
+    assert '[!] No network state found in ' + empty in capsys.readouterr().out
+    assert train.main(['--name', str(tmp_path / 'x'), '--lr-values', '0.1;zzz', '--lr-boundaries', '3']) == 1  # train.py:174-185
+    assert '[!]' in capsys.readouterr().out
+    assert train.main(['--name', str(tmp_path / 'x'), '--lr-values', '0.1', '--lr-boundaries', '3']) == 1
+    capsys.readouterr()
+    assert train.main(['--name', str(tmp_path / 'y'), '--data-dir', str(tmp_path / 'nowhere'), '--epochs', '1'] + COMMON) == 1
+    assert '[!] Unable to load training data:' in capsys.readouterr().out                                     # train.py:155-161
+    assert infer.main(['--name', str(tmp_path / 'nothing')]) == 1                                           # infer.py:111-114
+    assert '[!] No network state found' in capsys.readouterr().out
+    assert infer.main(['--name', empty, '--checkpoint', '7']) == 1
+    assert '[!] Cannot find checkpoint' in capsys.readouterr().out
+    assert infer.main(['--preset', 'vgg300', '--name', str(tmp_path / 'nothing')]) == 1                      # no files
+    assert '[!] No files specified' in capsys.readouterr().out
+    assert infer.main(['--preset', 'vgg300', '--name', str(tmp_path / 'nothing'), '--data-source', 'nosuchsource']) == 1
+    assert '[!] Unable to load data source' in capsys.readouterr().out
+
+
+VOC_XML = """<annotation><folder>{vocid}</folder><filename>{name}.jpg</filename>
+<size><width>{w}</width><height>{h}</height><depth>3</depth></size>
+<object><name>dog</name><bndbox><xmin>{x0}</xmin><ymin>{y0}</ymin><xmax>{x1}</xmax><ymax>{y1}</ymax></bndbox></object>
+<object><name>person</name><bndbox><xmin>20</xmin><ymin>30</ymin><xmax>{x1}</xmax><ymax>{h2}</ymax></bndbox></object>
+</annotation>"""
+
+
+def make_voc(root, rng):
+    from PIL import Image
+    n = 0
+    for part, vocid, lst, count in (('trainval', 'VOC2007', 'trainval', 3), ('trainval', 'VOC2012', 'trainval', 3), ('test', 'VOC2007', 'test', 2),
+                                    ('test', 'VOC2012', 'test', 3)):
+        base = root / part / 'VOCdevkit' / vocid
+        for d in ('Annotations', 'ImageSets/Main', 'JPEGImages'):
+            os.makedirs(base / d, exist_ok=True)
+        names = []
+        for i in range(count):
+            name = '%s_%s_%06d' % (vocid, lst, i); names.append(name)
+            w, h = int(rng.integers(240, 500)), int(rng.integers(200, 400))
+            img = rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3)).astype(np.uint8).repeat(8, 0).repeat(8, 1)[:h, :w]
+            Image.fromarray(img).save(base / 'JPEGImages' / (name + '.jpg'), quality=92)
+            (base / 'Annotations' / (name + '.xml')).write_text(VOC_XML.format(vocid=vocid, name=name, w=w, h=h, x0=w // 5, y0=h // 6,
+                                                                               x1=w - 30, y1=h - 25, h2=h // 2 + 40))
+            n += 1
+        (base / 'ImageSets' / 'Main' / (lst + '.txt')).write_text('\n'.join(names) + '\n')
+    # VOC2012 annotations on no list validate (source_pascal_voc.py:168-178)
+    base = root / 'trainval' / 'VOCdevkit' / 'VOC2012'
+    for i in range(2):
+        name = 'extra_%06d' % i
+        from PIL import Image as I2
+        I2.fromarray(rng.integers(0, 256, (210, 320, 3)).astype(np.uint8)).save(base / 'JPEGImages' / (name + '.jpg'))
+        (base / 'Annotations' / (name + '.xml')).write_text(VOC_XML.format(vocid='VOC2012', name=name, w=320, h=210, x0=40, y0=30, x1=290, y1=190, h2=150))
+    return n
+
+
+def test_real_dataset_directory_feeds_training_and_inference(tmp_path, capsys):
+    """TrainingData(data_dir) over a Pascal-VOC tree: XML -> Sample records (source_pascal_voc), JPEG decode (Pillow),
+    the train / valid transform recipes, redraw until an anchor is positive, batches born on the GPU; infer.py over the
+    data source with AP statistics and the VOC summary."""
+    import random
+    random.seed(11)
+    voc = tmp_path / 'voc'
+    make_voc(voc, np.random.default_rng(5))
+    run = str(tmp_path / 'vocrun')
+    assert train.main(['--name', run, '--tensorboard-dir', str(tmp_path / 'tb'), '--data-dir', str(voc), '--epochs', '2', '--batch-size', '4',
+                       '--checkpoint-interval', '5']) == 0
+    out = capsys.readouterr().out
+    assert '[i] # training samples:    8' in out and '[i] # validation samples:  2' in out and '[i] Train  2/2' in out
+    assert 'nan' not in out.lower()
+    odir = str(tmp_path / 'vocout')
+    assert infer.main(['--name', run, '--data-source', 'pascal_voc', '--data-dir', str(voc), '--sample', 'test', '--batch-size', '2',
+                       '--threshold', '0.01', '--pascal-summary', 'true', '--output-dir', odir]) == 0
+    out = capsys.readouterr().out
+    assert '[i] # samples:          3' in out and '[i] Compute stats:      True' in out and '[i] mAP:' in out and '[i] AP [dog]' in out
+    assert infer.main(['--name', run, '--data-source', 'pascal_voc', '--data-dir', str(voc), '--sample', 'trainval', '--compute-stats', 'false',
+                       '--output-dir', odir]) == 0
+    assert '[i] # samples:          8' in capsys.readouterr().out
+    # explicit image files, decoded and resized on the way in
+    files = sorted(str(p) for p in (voc / 'test' / 'VOCdevkit' / 'VOC2007' / 'JPEGImages').iterdir())
+    assert infer.main(['--name', run, '--output-dir', odir] + files) == 0
+    assert '[i] Number of files:    2' in capsys.readouterr().out

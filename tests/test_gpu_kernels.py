@@ -33,6 +33,15 @@ CONV_CASES = [
 ]
 
 
+# sizes at which the batch-32 step picks its big tiles (M = 90k..180k pixels) + a ragged one: run under forced variants
+LARGE_CASES = [
+    ('conv2_2-size 150x150 128->128 b4', 4, 150, 150, 128, 128, 3, 1, 1, 'SAME', True),
+    ('conv3_2-size 75x75 256->256 b3 ragged M', 3, 75, 75, 256, 256, 3, 1, 1, 'SAME', True),
+    ('conv4_2-size 38x38 512->512 b5', 5, 38, 38, 512, 512, 3, 1, 1, 'SAME', True),
+    ('ragged channels 33x29 192->320 b2', 2, 33, 29, 192, 320, 3, 1, 1, 'SAME', True),
+]
+
+
 def oracle_conv(x, w, bias, stride, dil, padding, relu):
     xt = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_(True)
     wt = torch.tensor(w).requires_grad_(True)
@@ -101,6 +110,37 @@ def test_conv_fwd_dgrad_wgrad(case):
         expect = (dx_ref + prev) * (x > 0)
         e = max_rel(host(gx_), expect)
         assert e < TOL, f'{name}: dgrad accumulate+mask max-rel {e:.3e}'
+
+
+@pytest.mark.parametrize('case', LARGE_CASES, ids=[c[0] for c in LARGE_CASES])
+def test_conv_large_layers(case):
+    test_conv_fwd_dgrad_wgrad(case)
+
+
+# every fp32 tile / staging / split / parity switch the step can take, forced for ALL layers of a child
+# process (the library reads the switches once): the cost model only picks most of them at batch-32 sizes
+FP32_VARIANTS = [
+    dict(SSD_TILE='0', SSD_WGRAD_CFG='0'),                                            # 128x128 everywhere, LDS-DMA staging
+    dict(SSD_TILE='1', SSD_WGRAD_CFG='1', SSD_WGRAD_ROUNDS='0'),                      # 128x64 / 64x64, plain split count
+    dict(SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_DGRAD_PARITY='0'),                      # 64x128, all-taps strided data gradient
+    dict(SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_GLDS_WGRAD='2'),                        # 64x64 / 128x64, DMA weight gradient on every tile
+    dict(SSD_GLDS='0', SSD_TILE='0', SSD_WGRAD_CFG='0', SSD_GLDS_WGRAD='0'),          # register-staged kernels
+    dict(SSD_GLDS='0', SSD_TILE='1', SSD_WGRAD_CFG='1'),
+    dict(SSD_GLDS='0', SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_FIRST_F32='0'),
+    dict(SSD_GLDS='0', SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_DGRAD_PARITY='0', SSD_WGRAD_ROUNDS='0'),
+]
+
+
+@pytest.mark.parametrize('variant', FP32_VARIANTS, ids=[' '.join(f'{k[4:]}={v}' for k, v in d.items()) for d in FP32_VARIANTS])
+def test_conv_fp32_forced_variants(variant):
+    import os, subprocess, sys
+    if os.environ.get('SSD_VARIANT_CHILD') == '1':
+        pytest.skip('already a forced configuration')
+    env = dict(os.environ, SSD_VARIANT_CHILD='1', **variant)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
+                        'test_conv_fwd_dgrad_wgrad or test_conv_large_layers or test_conv_full_size_layer', '-p', 'no:cacheprovider'],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_conv_full_size_layer():

@@ -51,9 +51,11 @@ def head_out_from_buffers(net, preset, b, prefix=''):
     return np.concatenate(parts, 1)
 
 
-def layer_local_backward_check(net, m, preset, b, x, y, wq=lambda w: w, tol_dout=TOL):
+def layer_local_backward_check(net, m, preset, b, x, y, wq=lambda w: w, tol_dout=TOL, only=None):
     """Every op's backward, recomputed by the oracle from the GPU's own tensors.
-    wq: the rounding the product applies to a filter before it multiplies (identity for fp32)."""
+    wq: the rounding the product applies to a filter before it multiplies (identity for fp32).
+    only: optional list of op names ('conv4_2', 'pool3', 'heads/map0', 'l2_norm_conv4_3'): check just the input
+    tensors those ops read (the large-batch tests cannot afford every layer on the CPU)."""
     g_gpu = net.save_gradients()
     act = {'image_input': x}
 
@@ -82,7 +84,12 @@ def layer_local_backward_check(net, m, preset, b, x, y, wq=lambda w: w, tol_dout
         nj = 2 + len(preset['maps'][i][2])
         assert not gbuf[..., nj * 25:].any()
 
+    def op_name(op):
+        return 'heads/map%d' % op[1] if op[0] == 'head' else ('l2_norm_conv4_3' if op[0] == 'l2norm' else op[1])
+
     for tname, cons in consumers.items():
+        if only is not None and not any(op_name(op) in only for op in cons):
+            continue
         a = nchw(A(tname)).clone().requires_grad_(tname != 'image_input')
         for op in cons:
             if op[0] == 'conv':

@@ -1,0 +1,96 @@
+"""-m gpu: the data-parallel step on hardware as far as one GPU allows: a single-rank RCCL group (backend "nccl" on
+ROCm) runs the staged backward with bucketed all-reduces enqueued behind the weight-gradient stream -- RCCL
+initialisation, stream ordering and side-stream collectives execute for real -- and must reproduce the plain step bit
+for bit.  The multi-rank arithmetic is covered on CPU (tests/test_parallel_cpu.py, gloo, world size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import boxes as ob, ssdvgg_ref as ref
+from ssd_tensorflow_amd import parallel
+from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.fixture(scope='module')
+def nccl_group():
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield
+    dist.destroy_process_group()
+
+
+def _net(b, w, dtype='f32'):
+    sess = Session(0)
+    net = SSDVGG(sess, 'vgg300')
+    net.build_from_vgg(None, 20, max_batch=b, weights=w, dtype=dtype)
+    net.build_optimizer(learning_rate=0.001, weight_decay=0.0005, momentum=0.9)
+    net.set_stream(torch.cuda.current_stream().cuda_stream)
+    return sess, net
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_bucketed_allreduce_over_rccl_equals_plain_step(nccl_group, overlap):
+    b = 2
+    preset = ob.get_preset('vgg300')
+    w = ref.init_params(preset, 20, seed=3, alive=True)
+    rng = np.random.default_rng(17)
+    x, y, _ = ref.synth_batch(rng, b, preset)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    sess1, plain = _net(b, w)
+    sess2, dp = _net(b, w)
+    if not overlap:      # weight gradients on the main stream: the collectives behind the side stream must still see them
+        from ssd_tensorflow_amd._lib import lib, check
+        check(lib.ssd_set_overlap(dp._h, 0))
+    for step in range(3):
+        plain.train_step_dev(xt, yt)
+        parallel.train_step_dp(dp, xt, yt, 1, bucket_floats=4_000_000, force_collectives=True)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.grads_flat, dp.grads_flat), 'all-reduce over one rank is the identity'
+    assert torch.equal(plain.params_flat, dp.params_flat) and torch.equal(plain.momentum_flat, dp.momentum_flat)
+    assert plain.get_losses() == dp.get_losses() and dp.global_step == 3
+    # single all-reduce after backward, and the unequal-shard normaliser at its neutral value
+    parallel.train_step_dp(dp, xt, yt, 1, bucket_floats=0, force_collectives=True, global_count=b)
+    plain.train_step_dev(xt, yt)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params_flat, dp.params_flat)
+    sess1.close(); sess2.close()
+
+
+def test_loss_normalizer_and_null_gradients(nccl_group):
+    """Unequal shards: a rank that normalises by global_count / world = 3/2 instead of its own b = 2 scales its data
+    gradient by 2/1.5; a rank with an empty shard contributes weight_decay * filters only."""
+    b = 2
+    preset = ob.get_preset('vgg300')
+    w = ref.init_params(preset, 20, seed=4, alive=True)
+    rng = np.random.default_rng(18)
+    x, y, _ = ref.synth_batch(rng, b, preset)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    sess, net = _net(b, w)
+    net.forward_backward_dev(xt, yt)
+    g_own = net.grads_flat.clone(); L_own = net.get_losses()
+    net.set_loss_normalizer(1.5)
+    net.forward_backward_dev(xt, yt)
+    g_n = net.grads_flat.clone(); L_n = net.get_losses()
+    net.set_loss_normalizer(0.0)
+    nf = net.filter_floats
+    wd_term = 0.0005 * net.params_flat
+    wd_term[nf:] = 0
+    want = (g_own - wd_term) * (2.0 / 1.5) + wd_term
+    err = float((g_n - want).norm() / want.norm())
+    assert err < 1e-6, err
+    assert abs(L_n['confidence'] - L_own['confidence'] * 2 / 1.5) < 1e-5 * L_n['confidence'] and L_n['l2'] == L_own['l2']
+    net.null_gradients_dev()
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads_flat, wd_term)
+    sess.close()

@@ -114,3 +114,15 @@ def test_decode_empty_and_nms_idempotent():
     det2 = {k: v[keep] for k, v in det.items()}
     # survivors re-suppressed (already class-grouped, conf-descending per class): nothing more goes
     assert len(ob.suppress(det2)) == len(keep)
+
+
+def test_g10_list_nms():
+    """suppress_overlaps / non_maximum_suppression on arbitrary box lists (ssdutils.py:232-318) vs the reference's picks."""
+    g = load('g10_nms_lists.npz')
+    for case in range(int(g['ncases'][0])):
+        box, conf, lab = g[f'box_{case}'], g[f'conf_{case}'], g[f'label_{case}']
+        recs = [(float(conf[i]), int(lab[i]), tuple(int(v) for v in ob.prop2abs(*box[i]))) for i in range(len(conf))]
+        assert ob.suppress_list(recs, 0.45) == list(g[f'keep_{case}'])
+        one = list(g[f'one_{case}'])
+        assert ob.nms_list([(recs[i][0], recs[i][2]) for i in one], float(g[f'thr_{case}'][0])) == list(g[f'keep1_{case}'])
+    assert ob.nms_list([], 0.5) == [] and ob.suppress_list([]) == []

@@ -36,6 +36,46 @@ def test_shard_sampler_partitions_every_global_batch():
     assert s.num_batches() == 10 and sum(len(i) for i in s.batches(0)) == n
 
 
+def test_shard_sampler_short_last_batch_is_split_evenly_and_every_rank_steps():
+    """ranks must take the same number of steps (same collectives); a short last global batch is split as
+    evenly as possible, an empty shard is yielded (not skipped) when fewer samples than ranks are left."""
+    n, b, world = 70, 8, 8                      # 64 + 6: the last global batch leaves ranks 6, 7 empty
+    per_rank = [list(parallel.ShardSampler(n, b, r, world, seed=1).batches_with_count(0)) for r in range(world)]
+    assert {len(p) for p in per_rank} == {2}
+    last = [per_rank[r][1] for r in range(world)]
+    assert [len(i) for i, _ in last] == [1, 1, 1, 1, 1, 1, 0, 0] and {c for _, c in last} == {6}
+    assert sorted(np.concatenate([i for i, _ in last]).tolist() + np.concatenate([per_rank[r][0][0] for r in range(world)]).tolist()) == list(range(n))
+    n = 37                                      # 3 ranks x 4: last global batch of 1... 37 = 3*12 + 1
+    last = [list(parallel.ShardSampler(n, 4, r, 3, seed=2).batches_with_count(0))[-1] for r in range(3)]
+    assert [len(i) for i, _ in last] == [1, 0, 0] and all(c == 1 for _, c in last)
+    n = 29                                      # 24 + 5 over 3 ranks: 2, 2, 1
+    last = [list(parallel.ShardSampler(n, 4, r, 3, seed=2).batches_with_count(0))[-1] for r in range(3)]
+    assert [len(i) for i, _ in last] == [2, 2, 1]
+
+
+def test_loss_summary_is_sample_weighted(tmp_path):
+    """utils.py:236-283: sum(loss_b * n_b) / num_samples, reset after the push; tags as in the reference."""
+    import json
+    from ssd_tensorflow_amd.summaries import SummaryWriter, LossSummary, PrecisionSummary
+    w = SummaryWriter(str(tmp_path))
+    ls = LossSummary(w, 'training', 10)
+    ls.add(dict(total=4.0, localization=1.0, confidence=2.0, l2=1.0), 8)
+    ls.add(dict(total=2.0, localization=0.5, confidence=1.0, l2=0.5), 2)
+    means = ls.push(3)
+    assert means == dict(total=3.6, localization=0.9, confidence=1.8, l2=0.9) and ls.loss_values['total'] == 0.0
+    doubled = LossSummary(None, 'validation', 4)
+    doubled.add(dict(total=1.0, localization=1.0, confidence=1.0, l2=1.0), 2)
+    assert doubled.push(1, reduce=lambda v: [2 * x for x in v])['total'] == 1.0        # two ranks, 2 of 4 samples each
+    ps = PrecisionSummary(w, 'training', ['cat', 'dog'])
+    ps.push(3, 0.5, {'cat': 0.25, 'dog': 0.75})
+    ps.push(4, 0.0, {})                                                                 # nothing computed: nothing written
+    w.close()
+    rows = [json.loads(l) for l in open(tmp_path / 'scalars.jsonl')]
+    assert [r['tag'] for r in rows] == ['training_total_loss', 'training_localization_loss', 'training_confidence_loss', 'training_l2_loss',
+                                        'training_mAP', 'training_AP_cat', 'training_AP_dog']
+    assert rows[0] == {'tag': 'training_total_loss', 'value': 3.6, 'step': 3} and rows[-1]['value'] == 0.75
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -67,6 +107,26 @@ def _worker(rank, world, port, out):
         got = flat / world
         err = float((got - want).norm() / want.norm())
         out.put(dict(err=err, loss=(mean_loss[0], Lg['total']), conf=(mean_loss[1], Lg['confidence']), idx=int(idx[0])))
+    # ---- unequal shards: a global batch of 3 over 2 ranks (2 + 1).  Each rank normalises its data term by
+    # global_count / world = 1.5 instead of its own shard size (ssd_set_loss_normalizer); the plain mean over ranks
+    # is then the gradient of the 3-sample batch.  The oracle's gradient (mean over the shard + wd * w) is rescaled
+    # the way the library's normaliser does.
+    x3, y3 = np.concatenate([x, x[:1]]), np.concatenate([y, y[:1]])
+    x3[2] = x3[2][::-1].copy()                                  # a third, different image
+    shard, count = list(parallel.ShardSampler(3, 2, rank, world, seed=0).batches_with_count(0))[0]
+    assert count == 3 and len(shard) == (2 if rank == 0 else 1)
+    _, Ls, gs = m.grads(x3[shard], y3[shard])
+    wd = m.weight_decay
+    scaled = []
+    for k in names:
+        decay = wd * m.params[k].detach().numpy() if k.endswith('/filter') else 0.0
+        scaled.append(torch.from_numpy(((gs[k] - decay) * (len(shard) / (count / world)) + decay).astype(np.float32)).reshape(-1))
+    flat3 = torch.cat(scaled)
+    parallel.allreduce_flat(flat3, world)
+    if rank == 0:
+        _, _, g3 = m.grads(x3, y3)
+        want3 = torch.cat([torch.from_numpy(g3[k]).reshape(-1) for k in names])
+        out.put(dict(err3=float((flat3 / world - want3).norm() / want3.norm())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,9 +139,11 @@ def test_two_rank_gradient_averaging_gloo():
     for p in procs:
         p.start()
     res = out.get(timeout=600)
+    res3 = out.get(timeout=900)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
+    assert res3['err3'] < 1e-5, res3
     assert res['err'] < 1e-5, res
     assert abs(res['loss'][0] - res['loss'][1]) < 1e-4 * abs(res['loss'][1])
     assert abs(res['conf'][0] - res['conf'][1]) < 1e-4 * abs(res['conf'][1])

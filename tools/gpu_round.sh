@@ -1,0 +1,34 @@
+#!/bin/bash
+# One GPU-box visit: the -m gpu suite (no -x: every failure in one visit), then the default bench line and the
+# per-layer tables.  tools/gpu_round.sh <tag> [pytest -k expression]     -> gpurun_out/<tag>/
+set -u
+TAG=${1:-visit}
+KEXPR=${2:-}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd "$R"
+if [ -n "$KEXPR" ]; then
+    timeout 1500 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider -k "$KEXPR" > "$O/pytest.log" 2>&1
+else
+    timeout 1500 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider > "$O/pytest.log" 2>&1
+fi
+echo "pytest rc=$?" >> "$O/pytest.log"
+tail -40 "$O/pytest.log"
+timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.stderr"; echo "bench rc=$?"
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap --per-layer > /dev/null 2> "$O/per_layer_f32.txt"
+timeout 300 python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap --per-layer > /dev/null 2> "$O/per_layer_bf16.txt"
+python - "$O/bench.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+except Exception as e:
+    print('no bench line:', e); sys.exit(0)
+print('HEADLINE', d['value'], d['unit'], d['ms_per_step'], 'ms', 'mfma_frac', d.get('model_mfma_frac'), 'roofline', d['roofline'] and (d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['traffic']))
+print('losses_check', d.get('losses_check'))
+for k in ('bf16', 'vgg512_b16', 'vgg512_b16_bf16', 'infer_b128', 'decode_b128'):
+    s = d.get(k)
+    if s:
+        print(k, s.get('value'), s.get('ms_per_step'), s.get('model_mfma_frac'), s.get('error'), s.get('roofline') and (s['roofline']['kernel'][:60], s['roofline']['frac']))
+print('cpu', d.get('cpu_baseline'))
+PY

@@ -344,6 +344,37 @@ def main():
         g9[f'pix_in_{case}'] = img; g9[f'pix_seed_{case}'] = np.array([seed]); g9[f'pix_out_{case}'] = np.asarray(d)
     g9['ncases'] = np.array([ncase]); g9['npix'] = np.array([npix])
     np.savez_compressed(os.path.join(OUT, 'g9_augment.npz'), **g9)
+    # ---- G10 suppress_overlaps / non_maximum_suppression on arbitrary box lists (ssdutils.py:232-318) ----
+    # lists that did not come out of decode_boxes: random boxes, several classes, any threshold.  Confidences are
+    # distinct (the reference's order among exact ties is np.argsort's, i.e. unspecified).
+    rng = np.random.default_rng(31)
+    g10 = {}
+    ncase = 10
+    for case in range(ncase):
+        n = int(rng.integers(1, 300))
+        cx = rng.uniform(0.1, 0.9, n); cy = rng.uniform(0.1, 0.9, n)
+        w = rng.uniform(0.05, 0.5, n); h = rng.uniform(0.05, 0.5, n)
+        conf = rng.permutation(n).astype(np.float64) / n + rng.uniform(0, 0.4 / n, n)       # distinct also as float32
+        conf = conf.astype(np.float32)
+        assert len(set(conf.tolist())) == n
+        lab = rng.integers(0, 5, n) * 3 - 2
+        boxes = [(conf[i], ut.Box('c%d' % lab[i], int(lab[i]), ut.Point(float(cx[i]), float(cy[i])), ut.Size(float(w[i]), float(h[i]))))
+                 for i in range(n)]
+        sel = su.suppress_overlaps(boxes)
+        keep = [next(i for i, bx in enumerate(boxes) if bx is s_) for s_ in sel]
+        recs = [(float(c), b.labelid, tuple(int(v) for v in ut.prop2abs(b.center, b.size, ut.Size(1000, 1000)))) for c, b in boxes]
+        assert ob.suppress_list(recs, 0.45) == keep, ('G10 suppress', case)
+        thr = [0.3, 0.6, 0.05, 0.45, 0.9][case % 5]
+        one = [i for i in range(n) if lab[i] == lab[0]]
+        sel1 = su.non_maximum_suppression([boxes[i] for i in one], thr)
+        keep1 = [next(k for k, i in enumerate(one) if boxes[i] is s_) for s_ in sel1]
+        assert ob.nms_list([(recs[i][0], recs[i][2]) for i in one], thr) == keep1, ('G10 nms', case)
+        g10[f'box_{case}'] = np.stack([cx, cy, w, h], 1); g10[f'conf_{case}'] = conf; g10[f'label_{case}'] = lab.astype(np.int32)
+        g10[f'keep_{case}'] = np.array(keep, np.int32)
+        g10[f'thr_{case}'] = np.array([thr]); g10[f'one_{case}'] = np.array(one, np.int32); g10[f'keep1_{case}'] = np.array(keep1, np.int32)
+        print('G10 case', case, 'boxes', n, 'kept', len(keep), '| single class', len(one), 'thr', thr, 'kept', len(keep1))
+    g10['ncases'] = np.array([ncase])
+    np.savez_compressed(os.path.join(OUT, 'g10_nms_lists.npz'), **g10)
     print('all golden fixtures written and oracle agrees bit-exactly')
 
 

@@ -14,18 +14,18 @@ cd /tmp && export TMPDIR=/tmp
 
 # 1. kernel trace, one kernel at a time (durations comparable with bench.py's HIP events)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -o a -- \
-    python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-overlap $EXTRA \
+    python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap $EXTRA \
     > "$O/bench_under_rocprof_serialized.json" 2>/dev/null
 cp /tmp/pa/a_kernel_stats.csv "$O/rocprofv3_kernel_stats_serialized.csv"
 # 2. kernel trace of the overlapped step (what the headline runs)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- \
-    python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline $EXTRA \
+    python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary $EXTRA \
     > "$O/bench_under_rocprof_overlapped.json" 2>/dev/null
 cp /tmp/pb/b_kernel_stats.csv "$O/rocprofv3_kernel_stats_overlapped.csv"
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pc_$C -o c -- \
-        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-kernel-events $EXTRA >/dev/null 2>&1
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-overlap --no-kernel-events $EXTRA >/dev/null 2>&1
     python - "$C" /tmp/pc_$C/c_counter_collection.csv > "$O/pmc_$C.txt" <<'EOF'
 import csv, sys, collections
 name, path = sys.argv[1], sys.argv[2]
@@ -40,7 +40,7 @@ EOF
 done
 # 4. per-layer event table + the headline line (with the CPU baseline)
 cd "$R"
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap --per-layer $EXTRA > /dev/null 2> "$O/per_layer_events.txt"
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap --per-layer $EXTRA > /dev/null 2> "$O/per_layer_events.txt"
 python bench.py $EXTRA > "$O/bench.json" 2> "$O/bench.stderr"
 python bench.py --mode infer --batch 128 --no-cpu-baseline $EXTRA > "$O/bench_infer_b128.json" 2>/dev/null
 python bench.py --preset vgg512 --batch 16 --no-cpu-baseline $EXTRA > "$O/bench_vgg512_b16.json" 2>/dev/null
