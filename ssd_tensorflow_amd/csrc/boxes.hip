@@ -251,16 +251,18 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // float4 loads, all issued before the first is consumed; rows are then read at an odd stride:
 // conflict-free).  Every anchor whose confidence reaches thr becomes one 64-bit sort key
 //   conf bits << 32 | (32767 - anchor) << 8 | 0x80 | class   (descending sort == conf desc, anchor asc)
-// appended to its image's candidate list: one integer atomic per wave and image reserves the slots, a
-// ballot prefix places the lanes.  The list order is arbitrary, the keys are unique and pass 2 sorts them,
-// so the result does not depend on it.
+// A workgroup compacts the keys of its 256 rows in place: ballot prefix per wave, wave totals through LDS,
+// the survivors stored from the first row of the segment on, their number in `bcount`.  A workgroup's rows
+// belong to at most two images (A >= 256): two segments, the second one starting at the image boundary.
+// No atomics (a per-image counter serialises in L2: 137 waves hit each address), no memset, deterministic.
 constexpr int SCAN_ROWS = 256;
 constexpr int SCAN_MAXV = 32;                       // nv <= 32
 constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
 
-__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int A2, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          u64* __restrict__ keys, int* __restrict__ ncand) {
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          u64* __restrict__ dense, int* __restrict__ bcount) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
+    __shared__ int s_cnt[2][4];
     const int total_rows = B * A;
     const int r0 = blockIdx.x * SCAN_ROWS;
     const int nrows = min(SCAN_ROWS, total_rows - r0);
@@ -282,11 +284,12 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int A2, int nv,
     }
     for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const bool valid = (int)threadIdx.x < nrows;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int img_first = r0 / A;
+    const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
     u64 key = 0ull;
-    int img = 0;
-    if (valid) {
+    int half = 0;
+    if ((int)threadIdx.x < nrows) {
         const float* r = rows + (size_t)threadIdx.x * nv;
         const int nfg = nv - 5;                  // argmax excludes the background class
         int best = 0;
@@ -294,24 +297,25 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int A2, int nv,
         for (int c = 1; c < nfg; ++c)
             if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
         const int row = r0 + threadIdx.x;
-        img = row / A;
-        const int a = row - img * A;
+        half = row >= boundary ? 1 : 0;
+        const int a = row - (img_first + half) * A;
         if (!(conf < thr))                        // the reference breaks at the first conf < thr
             key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
     }
-    // a wave covers 64 consecutive rows: at most two images (A >= SCAN_ROWS)
-    const int img0 = __builtin_amdgcn_readfirstlane(img);
+    const u64 bal0 = __ballot(key != 0ull && half == 0), bal1 = __ballot(key != 0ull && half == 1);
+    if (lane == 0) { s_cnt[0][wv] = __popcll(bal0); s_cnt[1][wv] = __popcll(bal1); }
+    __syncthreads();
+    int base = 0, tot0 = 0, tot1 = 0;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int bb = img0 + pass;
-        const bool mine = key != 0ull && img == bb;
-        const u64 bal = __ballot(mine);
-        if (bal == 0ull) continue;
-        int base = 0;
-        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&ncand[bb], __popcll(bal));
-        base = __shfl(base, __ffsll((long long)bal) - 1, 64);
-        if (mine) keys[(size_t)bb * A2 + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) base += s_cnt[half][w];
+        tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
     }
+    if (key != 0ull) {
+        const u64 bal = half ? bal1 : bal0;
+        dense[(size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    }
+    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
 }
 
 // descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
@@ -423,6 +427,7 @@ constexpr int DET_WAVES = DET_THREADS / 64;
 constexpr int DET_FAST = 1024;           // up to this many candidates the whole image is handled in LDS
 constexpr int DET_LDS_KEYS = 2048;       // general path: sort in LDS up to this many keys, else in (L2-resident) global
 constexpr int DET_MAX_ALIVE = 32768;
+constexpr int DET_MAX_SEGS = DET_MAX_ALIVE / SCAN_ROWS + 2;      // scan workgroups touching one image
 constexpr int DET_SMEM = 50 * 1024;      // carved per path (general: 16 KB keys + 32 KB flags; fast: 49 KB)
 static_assert(DET_SMEM >= DET_FAST * (8 + 8 + 16 + 16 + 1) && DET_SMEM >= DET_LDS_KEYS * 8 + DET_MAX_ALIVE, "LDS carve");
 
@@ -431,8 +436,9 @@ struct DetectArgs {
     const double* anchors;
     const float* pred;
     int cap, max_out, out_cap, do_nms;
-    const int* ncand;   // [B] candidates per image
-    u64* keys1;         // [B][A2] candidate keys (unordered on entry)
+    const int* bcount;  // [scan workgroups][2] candidates per (workgroup, image) segment
+    const u64* dense;   // [B*A] the segments' keys, compacted at each segment's first row
+    u64* keys1;         // [B][A2] general path: the image's candidates gathered for the sort
     u64* keys2;
     int* box;       // [B][A][4]
     int* nbox;      // [B][A][4]
@@ -483,7 +489,32 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     u64* g1 = p.keys1 + (size_t)b * p.A2;
-    const int n = min(p.ncand[b], p.A);
+    // ---- the image's candidate segments (one per scan workgroup that touched the image) ----------------
+    __shared__ int seg_off[DET_MAX_SEGS + 1], seg_base[DET_MAX_SEGS];
+    const int row_lo = b * p.A, row_hi = row_lo + p.A;
+    const int first_blk = row_lo / SCAN_ROWS, nseg = (row_hi - 1) / SCAN_ROWS - first_blk + 1;
+    if (tid < nseg) {
+        const int blk = first_blk + tid;
+        const bool tail_of_prev = blk * SCAN_ROWS < row_lo;      // the workgroup started in the previous image
+        seg_base[tid] = tail_of_prev ? row_lo : blk * SCAN_ROWS;
+        seg_off[tid + 1] = p.bcount[blk * 2 + (tail_of_prev ? 1 : 0)];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        seg_off[0] = 0;
+        for (int i = 1; i <= nseg; ++i) { acc += seg_off[i]; seg_off[i] = acc; }
+    }
+    __syncthreads();
+    const int n = seg_off[nseg];
+    auto candidate = [&](int f) {            // f-th candidate of the image (any order: the keys are unique and get sorted)
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_off[mid] <= f) lo = mid; else hi = mid - 1;
+        }
+        return p.dense[(size_t)seg_base[lo] + (f - seg_off[lo])];
+    };
 
     if (n <= DET_FAST) {
         // ================= everything in LDS: rank sort, decode, NMS, emit =================
@@ -492,7 +523,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         int4* box = reinterpret_cast<int4*>(okey + DET_FAST);
         int4* nbox = box + DET_FAST;
         volatile unsigned char* alive = reinterpret_cast<unsigned char*>(nbox + DET_FAST);
-        for (int i = tid; i < n; i += DET_THREADS) skey[i] = g1[i];
+        for (int i = tid; i < n; i += DET_THREADS) skey[i] = candidate(i);
         if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
         __syncthreads();
         // rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and
@@ -580,12 +611,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     // ---- sort 1: confidence descending, anchor ascending ------------------------------
     const int n2 = next_pow2(n > 1 ? n : 1);
     if (n2 <= DET_LDS_KEYS) {
-        for (int i = tid; i < n2; i += DET_THREADS) lkeys[i] = i < n ? g1[i] : 0ull;
+        for (int i = tid; i < n2; i += DET_THREADS) lkeys[i] = i < n ? candidate(i) : 0ull;
         __syncthreads();
         bitonic_desc(lkeys, n2);
         for (int i = tid; i < n; i += DET_THREADS) g1[i] = lkeys[i];
     } else {
-        for (int i = n + tid; i < n2; i += DET_THREADS) g1[i] = 0ull;
+        for (int i = tid; i < n2; i += DET_THREADS) g1[i] = i < n ? candidate(i) : 0ull;
         __syncthreads();
         bitonic_desc(g1, n2);
     }
@@ -660,11 +691,14 @@ static int pow2_ge(int n) {
     return p;
 }
 
-static size_t det_head_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256 + 256; }
+static size_t det_head_bytes(int B, int A) {      // bcount [scan workgroups][2]
+    const size_t blocks = ((size_t)B * A + SCAN_ROWS - 1) / SCAN_ROWS;
+    return (blocks * 8 + 255) / 256 * 256 + 256;
+}
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
-    return det_head_bytes(B) + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
+    return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
@@ -677,7 +711,8 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     const int nv = num_classes + 5;
     const int A2 = pow2_ge(A);
     char* base = (char*)ws;
-    int* ncand = (int*)base; base += det_head_bytes(B);
+    int* bcount = (int*)base; base += det_head_bytes(B, A);
+    u64* dense = (u64*)base; base += ((size_t)B * A * 8 + 255) / 256 * 256;
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
     int* box = (int*)base; base += (size_t)B * A * 16;
@@ -686,13 +721,12 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
-        HIP_OK(hipMemsetAsync(ncand, 0, (size_t)B * 4, s));
-        hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, A2, nv, B, pred,
-                           conf_thr, keys1, ncand);
+        hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
+                           conf_thr, dense, bcount);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
-    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.ncand = ncand;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
     ProfScope prof("detect_image", 0.0, 0.0, s);
     hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);

@@ -2,6 +2,7 @@
 // Replaces the TensorFlow kernels behind tf.nn.conv2d / atrous_conv2d / bias_add /
 // relu at ssdvgg.py:48-50, 61-62, 260-262, 287-290 and their gradients.
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace ssd {
@@ -47,6 +48,27 @@ void conv_first_fwd_bf16(const ConvDesc& d, const float* x, const float* w, cons
 size_t conv_first_wgrad_bf16_ws_floats(const ConvDesc& d);
 void conv_first_wgrad_bf16(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                            float weight_decay, float* ws, hipStream_t s);
+
+// Deferred reduce of the split-M weight-gradient slabs.  Every weight-gradient pass ends in a small reduce launch
+// (slabs -> dw + weight decay, bias sums): ~35 launches of 6..40 us per step.  While a ReduceBatch is installed
+// (thread local, by the step executor) those launches are queued instead and wgrad_reduce_flush() runs the whole
+// backward stage's reduces as ONE grouped launch.  Each queued layer's slab workspace must stay untouched until
+// the flush (the executor gives every layer its own).
+struct ReduceItem {
+    const float* ws;
+    const float* w;
+    float* dw;
+    float* db;
+    unsigned long long wcount;
+    int nsplit, Co;
+    float wd;
+    int lanes;          // threads sharing one float4 element (4, 16 or 64: many slabs x few elements -> more lanes)
+};
+struct ReduceBatch {
+    std::vector<ReduceItem> items;
+};
+extern thread_local ReduceBatch* g_reduce_batch;
+void wgrad_reduce_flush(ReduceBatch& batch, hipStream_t s);
 
 // One launch mirrors every layer's fp32 filter [tap][Ci][Co] as bf16 in the same order (io, the data
 // gradient's operand) and transposed [tap][Co][Ci] (oi, the forward operand), at the same offsets.

@@ -32,7 +32,9 @@ inline double conv_elems(const ConvDesc& d) {
     return (double)d.B * d.Hi * d.Wi * d.Ci + (double)d.B * d.Ho * d.Wo * d.Co + (double)d.KH * d.KW * d.Ci * d.Co;
 }
 
-// Fixed-order reduce of the split-M weight-gradient slabs (conv_igemm.hip): dw = sum_s slab_s + wd*w, db = sum_s bias_s
+// Fixed-order reduce of the split-M weight-gradient slabs (conv_igemm.hip): dw = sum_s slab_s + wd*w, db = sum_s bias_s.
+// While a ReduceBatch is installed (conv.h) the call only queues its descriptor: the step executor flushes a whole
+// backward stage's reduces as ONE grouped launch.
 void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
                   hipStream_t s);
 

@@ -1298,8 +1298,78 @@ static void launch_wgrad_dma(WgradArgs& a, const WgradPlan& pl, const char* labe
     HIP_OK(hipGetLastError());
 }
 
+// ---- grouped form: one launch for a list of layers -------------------------------------------------------------
+constexpr int RG_MAX = 40;
+struct GroupedReduceArgs {
+    int n;
+    int blk_off[RG_MAX + 1];
+    ReduceItem it[RG_MAX];
+};
+
+// A workgroup owns 256 / lanes consecutive float4 elements of one layer; `lanes` threads share an element, each
+// summing every lanes-th slab in ascending order; the partials are added in lane order through LDS (fixed order).
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(GroupedReduceArgs g) {
+    __shared__ f32x4 part[256];
+    int i = 0;
+    for (int k = 1; k < g.n; ++k)
+        if ((int)blockIdx.x >= g.blk_off[k]) i = k;
+    const ReduceItem& it = g.it[i];
+    const int lanes = it.lanes, per = 256 / lanes;
+    const int e = threadIdx.x % per, sl = threadIdx.x / per;
+    const size_t total = it.wcount + it.Co;
+    const size_t idx = ((size_t)(blockIdx.x - g.blk_off[i]) * per + e) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (idx < total)
+        for (int k = sl; k < it.nsplit; k += lanes) s += ld4(it.ws + (size_t)k * total + idx);
+    part[sl * per + e] = s;
+    __syncthreads();
+    if (sl == 0 && idx < total) {
+        f32x4 t = part[e];
+        for (int q = 1; q < lanes; ++q) t += part[q * per + e];
+        if (idx < it.wcount) {
+            if (it.wd != 0.f) t += it.wd * ld4(it.w + idx);
+            *reinterpret_cast<f32x4*>(it.dw + idx) = t;
+        } else if (it.db) {
+            *reinterpret_cast<f32x4*>(it.db + (idx - it.wcount)) = t;
+        }
+    }
+}
+
+thread_local ReduceBatch* g_reduce_batch = nullptr;
+
+void wgrad_reduce_flush(ReduceBatch& batch, hipStream_t s) {
+    size_t done = 0;
+    while (done < batch.items.size()) {
+        GroupedReduceArgs g{};
+        int blocks = 0;
+        double bytes = 0.0;
+        for (; done < batch.items.size() && g.n < RG_MAX; ++done) {
+            const ReduceItem& it = batch.items[done];
+            const size_t total = it.wcount + it.Co;
+            g.blk_off[g.n] = blocks;
+            g.it[g.n++] = it;
+            blocks += cdiv((long long)(total / 4), 256 / it.lanes);
+            bytes += 4.0 * (double)total * (it.nsplit + 2);
+        }
+        for (int k = g.n; k <= RG_MAX; ++k) g.blk_off[k] = blocks;
+        ProfScope prof("wgrad_reduce_grouped", 0.0, bytes, s);
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3(blocks), dim3(256), 0, s, g);
+        HIP_OK(hipGetLastError());
+    }
+    batch.items.clear();
+}
+
 void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
                   hipStream_t s) {
+    if (g_reduce_batch) {
+        const size_t total4 = (wcount + Co) / 4;
+        // enough workgroups to spread over the chip, enough slabs per thread to be worth a thread
+        int lanes = 4;
+        if (nsplit >= 256 || (nsplit >= 32 && total4 < 16384)) lanes = 64;
+        else if (nsplit >= 32) lanes = 16;
+        g_reduce_batch->items.push_back(ReduceItem{ws, w, dw, db, (unsigned long long)wcount, nsplit, Co, wd, lanes});
+        return;
+    }
     const size_t total = wcount + Co;
     int blocks = cdiv((long long)total, 256 * 4);
     if (blocks > 2048) blocks = 2048;

@@ -40,8 +40,10 @@ struct Op {
     int KH = 1, KW = 1, stride = 1, dil = 1, pad_h = 0, pad_w = 0;
     bool relu = true;
     size_t w_off = 0, b_off = 0;     // offsets (floats) into the arenas
+    size_t ws_off = 0;               // this layer's region of the weight-gradient slab workspace (floats)
     // pool
     int k = 2;
+    void* pool_rec = nullptr;        // forward-written argmax / sign record of a single-consumer 2x2 pool (ops.h)
     // head op: index of the feature map, else -1
     int head = -1;
 };
@@ -147,7 +149,8 @@ private:
     hipStream_t wstream_ = nullptr;        // side stream of the weight gradients (SSD_OVERLAP_WGRAD=0 disables)
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
-    hipEvent_t ev_h_ = nullptr, ev_fmap_[MAX_MAPS] = {};
+    hipEvent_t ev_h_ = nullptr, ev_cast_ = nullptr, ev_fmap_[MAX_MAPS] = {};
+    bool bw_heads_side_ = false;         // head data gradients in flight on the side stream (backward)
     bool overlap_ = true;
     bool own_wstream_ = true;
 
@@ -165,6 +168,7 @@ private:
     float* result_ = nullptr;
     float *x_stage_ = nullptr, *y_stage_ = nullptr;
     float* wgrad_ws_ = nullptr;
+    ReduceBatch reduce_batch_;
     float* l2_ws_ = nullptr;
     void* pool_ws_ = nullptr;
     void* loss_ws_ = nullptr;

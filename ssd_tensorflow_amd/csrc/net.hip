@@ -242,15 +242,21 @@ void Net::alloc() {
         if (!mom_) { mom_ = (float*)dalloc(nparams_ * sizeof(float)); own_mom_ = true; }
         HIP_OK(hipMemset(grads_, 0, nparams_ * sizeof(float)));
         HIP_OK(hipMemset(mom_, 0, nparams_ * sizeof(float)));
-        size_t ws = 0;
+        // split-M slab workspace: one region per layer (the reduces of a backward stage run as one grouped launch at its
+        // end, so a layer's slabs must survive the next layer's weight gradient); sized for the worst batch <= B
+        size_t ws_total = 0;
         for (auto& op : ops_)
-            if (op.kind == OP_CONV)
-                for (int b : {1, B}) {
+            if (op.kind == OP_CONV) {
+                size_t ws = 0;
+                for (int b = 1; b <= B; ++b) {
                     const ConvDesc d = conv_desc(op, b);
                     ws = std::max(ws, (bf16_ && d.Ci % 8 == 0) ? conv_wgrad_bf16_ws_floats(d) : conv_wgrad_ws_floats(d));
                     if (bf16_ && first_layer_kernel(d)) ws = std::max(ws, conv_first_wgrad_bf16_ws_floats(d));
                 }
-        wgrad_ws_ = (float*)dalloc(ws * sizeof(float));
+                op.ws_off = ws_total;
+                ws_total += (ws + 63) / 64 * 64;
+            }
+        wgrad_ws_ = (float*)dalloc(ws_total * sizeof(float));
         l2_ws_ = (float*)dalloc(l2norm_bwd_ws_floats(B * 64 * 64, 512) * sizeof(float));
         size_t pws = 0;
         for (auto& op : ops_)
@@ -261,6 +267,15 @@ void Net::alloc() {
                 pws = std::max(pws, maxpool_bwd_ws_bytes(d));
             }
         pool_ws_ = dalloc(pws);
+        // 2x2 pools whose input has no other consumer keep a forward record for their backward (ops.h)
+        static const bool use_rec = [] { const char* v = getenv("SSD_POOL_RECORD"); return !(v && v[0] == '0'); }();      // A/B switch
+        for (auto& op : ops_)
+            if (op.kind == OP_POOL && use_rec) {
+                const Tensor& in = tensors_[op.in];
+                const Tensor& out = tensors_[op.out];
+                PoolDesc d{B, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+                if (maxpool_rec_applicable(d) && in.consumers == 1) op.pool_rec = dalloc(maxpool_rec_bytes(d));
+            }
     }
     result_ = (float*)dalloc((size_t)B * A * nv * sizeof(float));
     x_stage_ = (float*)dalloc((size_t)B * preset_->image_h * preset_->image_w * 3 * sizeof(float));
@@ -317,6 +332,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     overlap_ = !(ov && ov[0] == '0');
     HIP_OK(hipStreamCreateWithFlags(&hstream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_h_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_cast_, hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev_fmap_[i], hipEventDisableTiming));
     if (training_) {
         HIP_OK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
@@ -339,6 +355,7 @@ Net::~Net() {
     if (hstream_) {
         (void)hipStreamDestroy(hstream_);
         (void)hipEventDestroy(ev_h_);
+        (void)hipEventDestroy(ev_cast_);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev_fmap_[i]);
     }
     if (wstream_) {
@@ -358,12 +375,29 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
     g_prof = &prof_;
     bool heads_on_side = false;
+    bool cast_pending = false;
     tensors_[input_t_].data = const_cast<float*>(x);
+    const bool side = hstream_ && overlap_;
+    if (side && (bf16_ || train_mode)) {
+        HIP_OK(hipEventRecord(ev_fmap_[MAX_MAPS - 1], stream_));
+        HIP_OK(hipStreamWaitEvent(hstream_, ev_fmap_[MAX_MAPS - 1], 0));
+        heads_on_side = true;
+    }
     if (bf16_) {
         // the fp32 masters may have been updated by the optimizer, a variable load or the caller (external
-        // arena): refresh both bf16 filter mirrors, one launch
+        // arena): refresh both bf16 filter mirrors, one launch -- on the side stream, beside conv1_1 (which reads
+        // the fp32 master itself); the first layer that reads a mirror waits for it
         prof_.layer = "filters";
-        cast_filters(cast_plan_, params_, wq_io_, wq_oi_, stream_);
+        cast_filters(cast_plan_, params_, wq_io_, wq_oi_, side ? hstream_ : stream_);
+        if (side) {
+            HIP_OK(hipEventRecord(ev_cast_, hstream_));
+            cast_pending = true;
+        }
+    }
+    if (train_mode) {
+        // the l2 term reads every filter once (105 MB): on the side stream beside the first (matrix-bound) layers
+        prof_.layer = "loss";
+        l2_partials(params_, nfilters_, lw_, side ? hstream_ : stream_);
     }
     for (const Op& op : ops_) {
         const Tensor& in = tensors_[op.in];
@@ -381,6 +415,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 heads_on_side = true;
             }
             const ConvDesc d = conv_desc(op, b);
+            if (cast_pending && !in.data_f32) {
+                HIP_OK(hipStreamWaitEvent(stream_, ev_cast_, 0));
+                cast_pending = false;
+            }
             if (!bf16_)
                 conv_fwd(d, in.f(), params_ + op.w_off, params_ + op.b_off, static_cast<float*>(out.data), op.relu, cs);
             else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
@@ -393,7 +431,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         }
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-            if (bf16_) maxpool_fwd(d, in.h(), static_cast<bf16_t*>(out.data), stream_);
+            if (op.pool_rec && train_mode) {
+                if (bf16_) maxpool_fwd_rec(d, in.h(), static_cast<bf16_t*>(out.data), op.pool_rec, stream_);
+                else maxpool_fwd_rec(d, in.f(), static_cast<float*>(out.data), op.pool_rec, stream_);
+            } else if (bf16_) maxpool_fwd(d, in.h(), static_cast<bf16_t*>(out.data), stream_);
             else maxpool_fwd(d, in.f(), static_cast<float*>(out.data), stream_);
             break;
         }
@@ -409,7 +450,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
     prof_.layer = "loss";
     if (train_mode) {
-        multibox_loss(heads_, b, result_, y, lw_, params_, nfilters_, wd_, loss_bnorm_, stream_);
+        multibox_loss(heads_, b, result_, y, lw_, wd_, loss_bnorm_, stream_);
         HIP_OK(hipMemcpyAsync(losses_host_, lw_.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     } else {
         heads_result(heads_, b, result_, stream_);
@@ -425,6 +466,11 @@ void Net::backward_begin(int b, const float* y) {
     g_prof = &prof_;
     prof_.layer = "loss";
     multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
+    bw_heads_side_ = false;
+    if (hstream_ && overlap_) {      // the small maps' head data gradients run beside the two big ones (backward_step)
+        HIP_OK(hipEventRecord(ev_h_, stream_));
+        HIP_OK(hipStreamWaitEvent(hstream_, ev_h_, 0));
+    }
     for (Tensor& t : tensors_) t.done = 0;
     bw_next_ = (int)ops_.size() - 1;
     bw_b_ = b;
@@ -436,6 +482,13 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     const size_t hi = bw_done_off_;
     size_t lo = hi;
     bool side_used = false;
+    static const bool grouped = [] { const char* v = getenv("SSD_REDUCE_GROUPED"); return !(v && v[0] == '0'); }();      // A/B switch
+    struct BatchScope {      // queue this stage's slab reduces (conv.h ReduceBatch); flushed below as one launch
+        ReduceBatch* prev;
+        BatchScope(ReduceBatch* b) : prev(g_reduce_batch) { g_reduce_batch = b; }
+        ~BatchScope() { g_reduce_batch = prev; }
+    } batch_scope(grouped ? &reduce_batch_ : nullptr);
+    reduce_batch_.items.clear();
     while (bw_next_ >= 0 && hi - lo < min_floats) {
         const Op& op = ops_[bw_next_--];
         Tensor& in = tensors_[op.in];
@@ -443,6 +496,17 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         const bool need_dx = op.in != input_t_;
         const bool last = in.done + 1 == in.consumers;
         prof_.layer = op.name.c_str();
+        // The multibox heads' data gradients are independent of each other (each is the first writer of its feature
+        // map's gradient): those of the small maps (a few workgroups, latency-bound) go to the side stream and run
+        // beside the two big ones; the trunk's first backward op waits for them.
+        const bool small_head = op.kind == OP_CONV && op.head >= 2 && hstream_ && overlap_ && in.done == 0;
+        if (bw_heads_side_ && !(op.kind == OP_CONV && op.head >= 0)) {
+            HIP_OK(hipEventRecord(ev_h_, hstream_));
+            HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
+            bw_heads_side_ = false;
+        }
+        hipStream_t ds = small_head ? hstream_ : stream_;      // stream of this op's data gradient
+        if (small_head) bw_heads_side_ = true;
         switch (op.kind) {
         case OP_CONV: {
             const ConvDesc d = conv_desc(op, b);
@@ -452,6 +516,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             // of workgroups leaves idle (and vice versa).
             const bool side = wstream_ && overlap_;
             hipStream_t ws = side ? wstream_ : stream_;
+            float* slab = wgrad_ws_ + op.ws_off;
             if (side) {
                 HIP_OK(hipEventRecord(ev_dy_, stream_));
                 HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
@@ -459,17 +524,17 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             }
             const bool mask = last && in.relu_out;
             if (!bf16_) {
-                conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
-                if (need_dx) conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, stream_);
+                conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+                if (need_dx) conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
             } else if (in.data_f32) {   // conv1_1
                 if (first_layer_kernel(d))
-                    conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
+                    conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
                 else
                     conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
-                                             wgrad_ws_, ws);
+                                             slab, ws);
             } else {
-                conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, wgrad_ws_, ws);
-                if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, stream_);
+                conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+                if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
             }
             lo = op.w_off;          // conv ops own descending, adjacent filter ranges
             break;
@@ -477,7 +542,10 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         case OP_POOL: {
             PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
             void* pws = maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr;
-            if (bf16_) maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
+            if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
+                if (bf16_) maxpool_bwd_rec(d, op.pool_rec, out.gh(), in.gh(), in.relu_out, stream_);
+                else maxpool_bwd_rec(d, op.pool_rec, out.gf(), in.gf(), in.relu_out, stream_);
+            } else if (bf16_) maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
             else maxpool_bwd(d, in.f(), out.gf(), in.gf(), in.done > 0, last && in.relu_out, pws, stream_);
             break;
         }
@@ -490,6 +558,10 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             break;
         }
         in.done++;
+    }
+    if (!reduce_batch_.items.empty()) {
+        prof_.layer = "stage";
+        wgrad_reduce_flush(reduce_batch_, (wstream_ && overlap_) ? wstream_ : stream_);
     }
     // The returned range is final in the weight-gradient stream's order.  Make it final in
     // main-stream order too unless the caller consumes it on the weight-gradient stream itself

@@ -23,6 +23,16 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
 void maxpool_bwd(const PoolDesc& d, const bf16_t* x, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask,
                  void* ws, hipStream_t s);
 
+// 2x2 stride-2 pooling with a forward-written record (per window and channel: first maximum's cell + "maximum is
+// positive"): backward = record + dy -> dx without re-reading the pooled tensor.  For a pooled tensor with a single
+// consumer (dx is overwritten, not accumulated); relu_mask as above.
+bool maxpool_rec_applicable(const PoolDesc& d);
+size_t maxpool_rec_bytes(const PoolDesc& d);
+void maxpool_fwd_rec(const PoolDesc& d, const float* x, float* y, void* rec, hipStream_t s);
+void maxpool_fwd_rec(const PoolDesc& d, const bf16_t* x, bf16_t* y, void* rec, hipStream_t s);
+void maxpool_bwd_rec(const PoolDesc& d, const void* rec, const float* dy, float* dx, bool relu_mask, hipStream_t s);
+void maxpool_bwd_rec(const PoolDesc& d, const void* rec, const bf16_t* dy, bf16_t* dx, bool relu_mask, hipStream_t s);
+
 // ---- l2_normalization (ssdvgg.py:80-84): y = scale * x * rsqrt(max(sum_c x^2, 1e-12))
 void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s);
 void l2norm_fwd(int npix, int C, const bf16_t* x, const float* scale, bf16_t* y, hipStream_t s);
@@ -63,7 +73,10 @@ void loss_work_carve(LossWork& w, void* base, int B, int A);
 // bnorm: the batch size the per-sample losses are averaged over (<= 0: this step's own B).  A data-parallel
 // caller whose shards are unequal passes global_samples / world, so that the mean over ranks is the global mean.
 void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
-                   const float* filters, size_t nfilters, float weight_decay, float bnorm, hipStream_t s);
+                   float weight_decay, float bnorm, hipStream_t s);
+// sum of squares of the filter region into w.partial (the l2 term of multibox_loss, which must follow it in stream
+// order): 4 bytes per parameter, independent of the forward pass, so the step runs it beside the first layers
+void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t s);
 // d(loss)/d(head outputs) written into L.dbuf (pad columns stay zero).
 void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s);

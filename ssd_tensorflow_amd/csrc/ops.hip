@@ -170,6 +170,79 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const T
     }
 }
 
+// The same pooling with a 12-bit record per (window, 4 channels) written by the forward pass: per channel the
+// first maximum's cell (2 bits) and whether that maximum is positive (1 bit).  Backward then needs neither the
+// input tensor (argmax) nor its sign (relu mask of the producing conv): it reads record + dy and writes dx,
+// 0.58x the bytes of the kernel above.  Valid when the pooled tensor has no other consumer (nothing to accumulate).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_rec_kernel(PoolDesc d, const T* __restrict__ x, T* __restrict__ y,
+                                                                 unsigned short* __restrict__ rec) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * 2, w0 = ow * 2;
+        f32x4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            ok[q] = h < d.Hi && w < d.Wi;
+            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok[q]) v[q] = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
+        }
+        f32x4 m;
+        unsigned r = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned a = 0;
+            float mm = v[0][e];                      // cell 0 is always inside the image
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (ok[q] && v[q][e] > mm) { mm = v[q][e]; a = q; }   // strict: the first maximum wins
+            m[e] = mm;
+            r |= (a | (mm > 0.f ? 4u : 0u)) << (3 * e);
+        }
+        st4t(y + idx * 4, m);
+        rec[idx] = (unsigned short)r;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_rec_kernel(PoolDesc d, const unsigned short* __restrict__ rec,
+                                                                 const T* __restrict__ dy, T* __restrict__ dx, int relu_mask) {
+    const int C4 = d.C >> 2;
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        size_t pix = idx / C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * 2, w0 = ow * 2;
+        const unsigned r = rec[idx];
+        const f32x4 gy = ld4t(dy + idx * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            if (h >= d.Hi || w >= d.Wi) continue;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned re = (r >> (3 * e)) & 7u;
+                if ((re & 3u) == (unsigned)q && (!relu_mask || (re & 4u))) g[e] = gy[e];
+            }
+            st4t(dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4, g);
+        }
+    }
+}
+
 // Overlapping pooling (3x3 stride 1, mod_pool5): pass A finds every window's first maximum once
 // (its scan-order cell index, one byte per channel); pass B lets every input cell collect dy from
 // the <= 9 windows whose recorded maximum it is.  27 loads per cell instead of 81.
@@ -251,6 +324,35 @@ static void maxpool_fwd_t(const PoolDesc& d, const T* x, T* y, hipStream_t s) {
     ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
     hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
     HIP_OK(hipGetLastError());
+}
+
+bool maxpool_rec_applicable(const PoolDesc& d) { return d.k == 2 && d.stride == 2 && d.pad_h == 0 && d.pad_w == 0 && d.C % 4 == 0; }
+size_t maxpool_rec_bytes(const PoolDesc& d) { return (size_t)d.B * d.Ho * d.Wo * (d.C / 4) * sizeof(unsigned short); }
+
+template <typename T>
+static void maxpool_fwd_rec_t(const PoolDesc& d, const T* x, T* y, void* rec, hipStream_t s) {
+    SSD_REQUIRE(maxpool_rec_applicable(d), "maxpool record: 2x2 stride-2 pooling without leading padding only");
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+    ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo) + 2.0 * total, s);
+    hipLaunchKernelGGL(maxpool2x2_fwd_rec_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y, (unsigned short*)rec);
+    HIP_OK(hipGetLastError());
+}
+void maxpool_fwd_rec(const PoolDesc& d, const float* x, float* y, void* rec, hipStream_t s) { maxpool_fwd_rec_t(d, x, y, rec, s); }
+void maxpool_fwd_rec(const PoolDesc& d, const bf16_t* x, bf16_t* y, void* rec, hipStream_t s) { maxpool_fwd_rec_t(d, x, y, rec, s); }
+
+template <typename T>
+static void maxpool_bwd_rec_t(const PoolDesc& d, const void* rec, const T* dy, T* dx, bool relu_mask, hipStream_t s) {
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+    ProfScope prof("maxpool_bwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo) + 2.0 * total, s);
+    hipLaunchKernelGGL(maxpool2x2_bwd_rec_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, (const unsigned short*)rec, dy, dx,
+                       (int)relu_mask);
+    HIP_OK(hipGetLastError());
+}
+void maxpool_bwd_rec(const PoolDesc& d, const void* rec, const float* dy, float* dx, bool relu_mask, hipStream_t s) {
+    maxpool_bwd_rec_t(d, rec, dy, dx, relu_mask, s);
+}
+void maxpool_bwd_rec(const PoolDesc& d, const void* rec, const bf16_t* dy, bf16_t* dx, bool relu_mask, hipStream_t s) {
+    maxpool_bwd_rec_t(d, rec, dy, dx, relu_mask, s);
 }
 
 size_t maxpool_bwd_ws_bytes(const PoolDesc& d) {
@@ -390,9 +492,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
     if (wv == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-static int l2_blocks(int npix) {
+static int l2_blocks(int npix) {      // one wave per pixel at a time: enough workgroups to keep 8+ waves per SIMD in flight
     int b = (npix + 3) / 4;
-    return b > 512 ? 512 : (b < 1 ? 1 : b);
+    return b > 2048 ? 2048 : (b < 1 ? 1 : b);
 }
 
 template <typename T>
@@ -806,14 +908,20 @@ void loss_work_carve(LossWork& w, void* base, int B, int A) {
     w.losses = (float*)p;
 }
 
+void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t s) {
+    ProfScope prof("l2_partials", 0.0, 4.0 * nfilters, s);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, filters, nfilters, w.partial);
+    HIP_OK(hipGetLastError());
+}
+
 void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
-                   const float* filters, size_t nfilters, float weight_decay, float bnorm, hipStream_t s) {
+                   float weight_decay, float bnorm, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     SSD_REQUIRE(L.A <= 32 * LS_THREADS, "loss: at most %d anchors", 32 * LS_THREADS);
     const int total = B * L.A;
     const HeadGrid G = head_grid(L, B);
     if (!(bnorm > 0.f)) bnorm = (float)B;          // reduce_mean over this step's own batch (ssdvgg.py:520,559)
-    ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars + 4.0 * nfilters, s);
+    ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars, s);
     hipLaunchKernelGGL(heads_kernel<true>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B,
                        const_cast<float*>(result), labels, w.ce, w.sl1, w.pos);
     const int pt = (L.A + LS_THREADS - 1) / LS_THREADS;
@@ -823,7 +931,6 @@ void multibox_loss(const HeadLayout& L, int B, const float* result, const float*
         hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
     else
         hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, filters, nfilters, w.partial);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, B, bnorm, w.sample, w.partial, SUMSQ_BLOCKS, weight_decay,
                        w.losses);
     HIP_OK(hipGetLastError());

@@ -122,7 +122,7 @@ class TrainingData:
                 plans, gts = [], []
                 for i in idx:
                     s = sample_at(int(i))
-                    if isinstance(s, tuple):                     # synthetic: the pixels travel with the record
+                    if not isinstance(s, Sample):                # synthetic: the pixels travel with the record
                         loader.images, sample = s
                     else:
                         loader.images, sample = preset_images, s

@@ -32,3 +32,14 @@ for k in ('bf16', 'vgg512_b16', 'vgg512_b16_bf16', 'infer_b128', 'decode_b128'):
         print(k, s.get('value'), s.get('ms_per_step'), s.get('model_mfma_frac'), s.get('error'), s.get('roofline') and (s['roofline']['kernel'][:60], s['roofline']['frac']))
 print('cpu', d.get('cpu_baseline'))
 PY
+# optional extras: GPU_EXTRA="power heads" tools/gpu_round.sh <tag>
+for x in ${GPU_EXTRA:-}; do
+    case $x in
+    power) timeout 200 python tools/power_probe.py > "$O/power_clock.txt" 2>&1; cat "$O/power_clock.txt";;
+    heads) for t in -1 0 1 2 3 4 5 6 7 8; do echo "SSD_TILE_BF16=$t"; SSD_TILE_BF16=$t timeout 100 python tools/bench_conv.py head1,head0,head2 bf16; done > "$O/heads_tiles_bf16.txt" 2>&1
+           echo "SSD_GATHER_ROWS_BF16=0" >> "$O/heads_tiles_bf16.txt"; SSD_GATHER_ROWS_BF16=0 timeout 100 python tools/bench_conv.py head1,head0,head2 bf16 >> "$O/heads_tiles_bf16.txt" 2>&1
+           cat "$O/heads_tiles_bf16.txt";;
+    prof) bash tools/profile_round.sh ${TAG}_prof > "$O/profile_round.log" 2>&1; tail -5 "$O/profile_round.log";;
+    profbf16) bash tools/profile_round.sh ${TAG}_prof_bf16 --dtype bf16 > "$O/profile_round_bf16.log" 2>&1; tail -5 "$O/profile_round_bf16.log";;
+    esac
+done
