@@ -766,6 +766,12 @@ int ssd_op_maxpool_bwd(const float* x, const float* dy, float* dx, int accumulat
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));     // the scratch dies here
     API_END
 }
+int ssd_op_clock_monitor(unsigned* out_dev, int nsamples, unsigned period_ticks, void* stream) {
+    API_BEGIN
+    SSD_REQUIRE(out_dev && nsamples >= 1 && period_ticks >= 100, "bad arguments");
+    clock_monitor(out_dev, nsamples, period_ticks, (hipStream_t)stream);
+    API_END
+}
 int ssd_op_l2norm_fwd(const float* x, const float* scale, float* y, int npix, int c, void* stream) {
     API_BEGIN
     l2norm_fwd(npix, c, x, scale, y, (hipStream_t)stream);

@@ -537,6 +537,9 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
             }
             lo = op.w_off;          // conv ops own descending, adjacent filter ranges
+            // a handful of layers per grouped reduce: few launches, yet interleaved with the data gradients instead of
+            // one long pass after the last layer (which nothing would hide)
+            if (reduce_batch_.items.size() >= 6) wgrad_reduce_flush(reduce_batch_, ws);
             break;
         }
         case OP_POOL: {

@@ -492,9 +492,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
     if (wv == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-static int l2_blocks(int npix) {      // one wave per pixel at a time: enough workgroups to keep 8+ waves per SIMD in flight
+static int l2_blocks(int npix) {      // (2048 workgroups were measured: the pixel loop gains nothing, the column sums lose)
     int b = (npix + 3) / 4;
-    return b > 2048 ? 2048 : (b < 1 ? 1 : b);
+    return b > 512 ? 512 : (b < 1 ? 1 : b);
 }
 
 template <typename T>
@@ -1021,6 +1021,30 @@ __global__ __launch_bounds__(256) void null_grads_kernel(const float* __restrict
 void null_gradients(const float* w, float* g, size_t nfilters, size_t n, float wd, hipStream_t s) {
     SSD_REQUIRE(n % 4 == 0 && nfilters % 4 == 0, "arena sizes must be multiples of 4");
     hipLaunchKernelGGL(null_grads_kernel, dim3(grid_for(n / 4, 256, 256 * 16)), dim3(256), 0, s, w, g, nfilters / 4, n / 4, wd);
+    HIP_OK(hipGetLastError());
+}
+
+// Shader-clock monitor (measurement aid, tools/power_probe.py): ONE wave spins next to whatever else runs on the GPU and
+// records, every `period` ticks of the constant 100 MHz counter (s_memrealtime), how many shader-clock cycles
+// (s_memtime) went by: out[i] = cycles per period -> MHz = out[i] / period * 100.
+__global__ void clock_monitor_kernel(unsigned* __restrict__ out, int nsamples, unsigned period) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < nsamples; ++i) {
+        const unsigned long long w0 = wall_clock64();
+        const unsigned long long c0 = clock64();
+        unsigned long long w1;
+        do {
+            __builtin_amdgcn_s_sleep(32);
+            w1 = wall_clock64();
+        } while (w1 - w0 < period);
+        const unsigned long long c1 = clock64();
+        // normalise to exactly `period` wall ticks
+        out[i] = (unsigned)((double)(c1 - c0) * (double)period / (double)(w1 - w0));
+    }
+}
+
+void clock_monitor(unsigned* out, int nsamples, unsigned period, hipStream_t s) {
+    hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, s, out, nsamples, period);
     HIP_OK(hipGetLastError());
 }
 

@@ -39,6 +39,13 @@ for x in ${GPU_EXTRA:-}; do
     heads) for t in -1 0 1 2 3 4 5 6 7 8; do echo "SSD_TILE_BF16=$t"; SSD_TILE_BF16=$t timeout 100 python tools/bench_conv.py head1,head0,head2 bf16; done > "$O/heads_tiles_bf16.txt" 2>&1
            echo "SSD_GATHER_ROWS_BF16=0" >> "$O/heads_tiles_bf16.txt"; SSD_GATHER_ROWS_BF16=0 timeout 100 python tools/bench_conv.py head1,head0,head2 bf16 >> "$O/heads_tiles_bf16.txt" 2>&1
            cat "$O/heads_tiles_bf16.txt";;
+    trace) cd /tmp && export TMPDIR=/tmp
+           rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pd -o d -- python "$R/bench.py" --mode decode --batch 128 --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_decode_under_rocprof.json" 2>/dev/null
+           cp /tmp/pd/d_kernel_stats.csv "$O/rocprofv3_kernel_stats_decode.csv"
+           rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o e -- python "$R/bench.py" --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap > "$O/bench_bf16_under_rocprof_serialized.json" 2>/dev/null
+           cp /tmp/pe/e_kernel_stats.csv "$O/rocprofv3_kernel_stats_bf16_serialized.csv"
+           cd "$R"; head -3 "$O/rocprofv3_kernel_stats_decode.csv" | cut -c1-200; grep -E "heads_kernel|loss_|sumsq|detect|reduce_grouped|cast_filters|l2norm" "$O/rocprofv3_kernel_stats_bf16_serialized.csv" | cut -c1-220;;
+    headsweep) for t in 0 1 2 3 4 5 6 7 8; do echo "ROWS=0 SSD_TILE_BF16=$t"; SSD_GATHER_ROWS_BF16=0 SSD_TILE_BF16=$t timeout 100 python tools/bench_conv.py head1,head0 bf16; done > "$O/heads_tiles2_bf16.txt" 2>&1; cat "$O/heads_tiles2_bf16.txt";;
     prof) bash tools/profile_round.sh ${TAG}_prof > "$O/profile_round.log" 2>&1; tail -5 "$O/profile_round.log";;
     profbf16) bash tools/profile_round.sh ${TAG}_prof_bf16 --dtype bf16 > "$O/profile_round_bf16.log" 2>&1; tail -5 "$O/profile_round_bf16.log";;
     esac

@@ -79,23 +79,42 @@ def stats(vals):
     return 'n/a' if not vals else f'mean {sum(vals) / len(vals):7.1f}  min {min(vals):7.1f}  max {max(vals):7.1f}  ({len(vals)} samples)'
 
 
+MON_STREAM = None
+
+
 def phase(name, fn, flops, seconds=3.0):
+    """fn back to back for `seconds`; meanwhile (a) the sysfs / rocm-smi sensors are polled from a thread (they lag by
+    seconds on this box) and (b) ONE wave of a monitor kernel on a second stream samples the shader clock itself every
+    100 us (s_memtime cycles per 10,000 ticks of the constant 100 MHz counter): that is the clock the kernels ran at."""
+    global MON_STREAM
+    if MON_STREAM is None:
+        MON_STREAM = torch.cuda.Stream()
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    nsamp = int(seconds * 1e4 * 0.6)              # the monitor ends before the load does
+    mon = torch.zeros(nsamp, dtype=torch.int32, device='cuda')
     s = Sampler(); s.start()
-    time.sleep(0.2)
     t0 = time.perf_counter(); n = 0
+    for _ in range(20):
+        fn()
+    check(lib.ssd_op_clock_monitor(mon.data_ptr(), nsamp, 10000, MON_STREAM.cuda_stream))
     while time.perf_counter() - t0 < seconds:
         for _ in range(50):
             fn()
-        torch.cuda.synchronize()
         n += 50
+        if n % 500 == 0:
+            torch.cuda.current_stream().synchronize()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s.on = False; s.join()
     rows = s.rows[2:] or s.rows
-    tf = flops * n / dt / 1e12 if flops else 0.0
-    print(f'{name:44s} {tf:8.1f} TFLOP/s | sclk MHz {stats([r[0] for r in rows])} | power W {stats([r[1] for r in rows])}', flush=True)
+    tf = flops * (n + 20) / dt / 1e12 if flops else 0.0
+    mhz = mon.cpu().numpy().astype(float) / 10000 * 100
+    mhz = mhz[mhz > 0]
+    q = lambda p: float(__import__('numpy').percentile(mhz, p)) if len(mhz) else float('nan')
+    print(f'{name:44s} {tf:8.1f} TFLOP/s | in-kernel shader clock MHz: mean {mhz.mean() if len(mhz) else float("nan"):7.1f}  p5 {q(5):7.1f}  p50 {q(50):7.1f}  '
+          f'p95 {q(95):7.1f} ({len(mhz)} x 100 us) | sensors: sclk MHz {stats([r[0] for r in rows])} | power W {stats([r[1] for r in rows])}', flush=True)
 
 
 def conv_fns(hw, ci, co, k, bf16, zero=False, B=32):
@@ -129,7 +148,7 @@ def conv_fns(hw, ci, co, k, bf16, zero=False, B=32):
 
 def main():
     print('sensors:', (CARD + ' + ' + HWMON) if CARD else 'rocm-smi --showclocks --showpower --json', '| first reading', read_sensors())
-    phase('idle (no kernels)', lambda: time.sleep(0.001), 0.0, 1.5)
+    phase('idle (monitor wave only)', lambda: time.sleep(0.001), 0.0, 1.5)
     for label, bf16, zero in (('fp32', False, False), ('bf16 (post-relu operands)', True, False), ('bf16 all-zero operands', True, True)):
         fl, keep, fns = conv_fns(38, 512, 512, 3, bf16, zero)
         for tag in ('fwd', 'dgrad', 'wgrad'):
