@@ -500,7 +500,18 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         seg_off[tid + 1] = p.bcount[blk * 2 + (tail_of_prev ? 1 : 0)];
     }
     __syncthreads();
-    if (tid == 0) {
+    if (nseg <= 64) {                       // inclusive scan of the segment counts by one wave
+        if (tid < 64) {
+            int v = tid < nseg ? seg_off[tid + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o, 64);
+                if (lane >= o) v += t;
+            }
+            if (tid < nseg) seg_off[tid + 1] = v;
+            if (tid == 0) seg_off[0] = 0;
+        }
+    } else if (tid == 0) {
         int acc = 0;
         seg_off[0] = 0;
         for (int i = 1; i <= nseg; ++i) { acc += seg_off[i]; seg_off[i] = acc; }
@@ -558,23 +569,21 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             }
         }
         __syncthreads();
-        if (tid < 32) {
-            int r = 0;
-            for (int c = 0; c < 32; ++c)
-                if (firstpos[c] < firstpos[tid]) ++r;
-            crank[tid] = r;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int np = 0;
-            if (p.do_nms) {     // decode-only mode: one group in confidence order, no suppression
-                for (int c = 0; c < 32; ++c)
-                    if (firstpos[c] != INT_MAX) { order_cls[crank[c]] = c; ++np; }
-                int acc = 0;
-                for (int r = 0; r < np; ++r) { segstart[r] = acc; acc += ccount[order_cls[r]]; }
-                segstart[np] = acc;
+        if (tid < 64) {         // one lane per class: its rank among the present classes and where its segment starts
+            const int mine = tid < 32 ? firstpos[tid] : INT_MAX;
+            int r = 0, start = 0;
+            for (int c = 0; c < 32; ++c) {
+                const bool before = firstpos[c] < mine;
+                r += before ? 1 : 0;
+                start += before ? ccount[c] : 0;
             }
-            s_npresent = np;
+            const int np = __popcll(__ballot(mine != INT_MAX));
+            if (tid < 32) crank[tid] = r;
+            if (p.do_nms && mine != INT_MAX) segstart[r] = start;
+            if (tid == 0) {     // decode-only mode: one group in confidence order, no suppression
+                s_npresent = p.do_nms ? np : 0;
+                segstart[p.do_nms ? np : 0] = m;
+            }
         }
         __syncthreads();
         // place, decode

@@ -66,6 +66,7 @@ struct LossWork {                    // per-step scratch, all device
     float* sample;                   // [B][4]: conf_b, loc_b, weight_b (1/(pos_n*B) or 0), pos_n
     float* partial;                  // [1024] sum-of-squares partials
     float* losses;                   // [4] total, localization, confidence, l2
+    unsigned* ticket;                // completion ticket of the per-sample workgroups (zero between launches)
 };
 size_t loss_work_bytes(int B, int A);
 void loss_work_carve(LossWork& w, void* base, int B, int A);

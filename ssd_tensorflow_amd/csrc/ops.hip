@@ -641,16 +641,21 @@ __global__ __launch_bounds__(HTHREADS) void heads_kernel(HeadLayout L, HeadGrid 
             y[c] = (TRAIN && c < nv) ? r[c] : 0.f;
             if (c < nc) m = fmaxf(m, z[c]);
         }
-        // accurate expf/logf (not the fast intrinsics): softmax must match an fp32 reference
-        // to 1e-3 rel even for tiny probabilities
+        // softmax = e_c / sum(e), e_c = exp(z_c - max) evaluated ONCE per class with the hardware exponential
+        // (v_exp_f32 on (z - max) * log2 e: relative error ~ |z - max| * 2^-24 <= 1e-5 over the fp32 range, against
+        // the 1e-3 bar; 42 libm expf calls per anchor made this kernel VALU-bound at 44 us); log once, accurately
+        float e[MAXV];
         float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXV; ++c)
-            if (c < nc) se += expf(z[c] - m);
+        for (int c = 0; c < MAXV; ++c) {
+            e[c] = c < nc ? __expf(z[c] - m) : 0.f;
+            se += e[c];
+        }
         const float lse = m + logf(se);
+        const float inv = 1.f / se;
 #pragma unroll
         for (int c = 0; c < MAXV; ++c)
-            if (c < nv) r[c] = c < nc ? expf(z[c] - lse) : z[c];
+            if (c < nv) r[c] = c < nc ? e[c] * inv : z[c];
         if constexpr (TRAIN) {
             float ce = 0.f, sl = 0.f;
             const bool pos = y[nc - 1] == 0.f;
@@ -692,6 +697,7 @@ void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s) {
 // One workgroup per sample holds the sample's A cross-entropy values in registers (PT per thread): every
 // pass of the MSB-first radix select (8 bits per pass over the float bit pattern, values are >= 0) runs from
 // registers into an LDS histogram, the bin holding the k-th largest is found by a parallel suffix scan.
+constexpr int SUMSQ_BLOCKS = 1024;
 constexpr int LS_THREADS = 1024;
 constexpr int LS_WAVES = LS_THREADS / 64;
 
@@ -708,12 +714,37 @@ __device__ __forceinline__ void block_sum3_1024(float& a, float& b, float& c, fl
     a = ta; b = tb; c = tc;
 }
 
+// the four losses from the per-sample results and the l2 partial sums: run by the LAST workgroup of loss_sample_kernel
+// to finish (an integer ticket), always in the same order, so the result does not depend on which one that is
+__device__ void loss_final_block(int B, float bnorm, const float* sample, const float* partial, int npartial, float wd,
+                                 float* losses, double* dred) {
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += LS_THREADS) ss += (double)__builtin_nontemporal_load(partial + i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    ss = 0.0;
+    for (int i = 0; i < LS_WAVES; ++i) ss += dred[i];
+    float conf = 0.f, loc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        conf += __builtin_nontemporal_load(sample + b * 4 + 0);
+        loc += __builtin_nontemporal_load(sample + b * 4 + 1);
+    }
+    conf /= bnorm;
+    loc /= bnorm;
+    const float l2 = wd * (float)(0.5 * ss);
+    losses[0] = conf + loc + l2;
+    losses[1] = loc;
+    losses[2] = conf;
+    losses[3] = l2;
+}
+
 template <int PT>
-__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, float bnorm, const float* __restrict__ ce,
-                                                                 const float* __restrict__ sl1,
-                                                                 const unsigned char* __restrict__ pos,
-                                                                 unsigned char* __restrict__ sel,
-                                                                 float* __restrict__ sample) {
+__device__ __forceinline__ void loss_sample_body(int B, int A, float bnorm, const float* __restrict__ ce,
+                                                 const float* __restrict__ sl1, const unsigned char* __restrict__ pos,
+                                                 unsigned char* __restrict__ sel, float* __restrict__ sample) {
     __shared__ float red[3 * LS_WAVES];
     __shared__ unsigned hist[256];
     __shared__ unsigned sh_prefix, sh_k, sh_ties, sh_wsum[4], sh_wtot[LS_WAVES];
@@ -848,6 +879,31 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, f
     }
 }
 
+template <int PT>
+__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, float bnorm, const float* __restrict__ ce,
+                                                                 const float* __restrict__ sl1,
+                                                                 const unsigned char* __restrict__ pos,
+                                                                 unsigned char* __restrict__ sel,
+                                                                 float* __restrict__ sample, const float* __restrict__ partial,
+                                                                 int npartial, float wd, float* __restrict__ losses,
+                                                                 unsigned* __restrict__ ticket) {
+    __shared__ double dred[LS_WAVES];
+    __shared__ unsigned sh_last;
+    loss_sample_body<PT>(B, A, bnorm, ce, sl1, pos, sel, sample);
+    // the workgroup that draws the last ticket reduces everything (loss_final_block); the ticket resets itself
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                   // this sample's results before the ticket
+        const unsigned t = atomicAdd(ticket, 1u);
+        sh_last = t == (unsigned)B - 1u ? 1u : 0u;
+        if (sh_last) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence();
+    loss_final_block(B, bnorm, sample, partial, npartial, wd, losses, dred);
+}
+
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ w, size_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
@@ -862,37 +918,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void loss_final_kernel(int B, float bnorm, const float* __restrict__ sample, const float* __restrict__ partial,
-                                  int npartial, float wd, float* __restrict__ losses) {
-    // one wave; lane-strided partial sums then a fixed-order shuffle tree
-    const int lane = threadIdx.x;
-    double ss = 0.0;
-    for (int i = lane; i < npartial; i += 64) ss += (double)partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (lane != 0) return;
-    float conf = 0.f, loc = 0.f;
-    for (int b = 0; b < B; ++b) {
-        conf += sample[b * 4 + 0];
-        loc += sample[b * 4 + 1];
-    }
-    conf /= bnorm;
-    loc /= bnorm;
-    const float l2 = wd * (float)(0.5 * ss);
-    losses[0] = conf + loc + l2;
-    losses[1] = loc;
-    losses[2] = conf;
-    losses[3] = l2;
-}
-
-constexpr int SUMSQ_BLOCKS = 1024;
 
 size_t loss_work_bytes(int B, int A) {
     const size_t n = (size_t)B * A;
     size_t bytes = 0;
     bytes += n * 4 * 2;                       // ce, sl1
     bytes += ((n + 15) / 16) * 16 * 2;        // pos, sel
-    bytes += (size_t)B * 4 * 4 + SUMSQ_BLOCKS * 4 + 64;
+    bytes += (size_t)B * 4 * 4 + SUMSQ_BLOCKS * 4 + 64 + 64;
     return bytes + 256;
 }
 
@@ -905,7 +937,8 @@ void loss_work_carve(LossWork& w, void* base, int B, int A) {
     w.sel = (unsigned char*)p; p += ((n + 15) / 16) * 16;
     w.sample = (float*)p; p += (size_t)B * 4 * 4;
     w.partial = (float*)p; p += SUMSQ_BLOCKS * 4;
-    w.losses = (float*)p;
+    w.losses = (float*)p; p += 64;
+    w.ticket = (unsigned*)p;          // zero at allocation, resets itself
 }
 
 void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t s) {
@@ -926,13 +959,14 @@ void multibox_loss(const HeadLayout& L, int B, const float* result, const float*
                        const_cast<float*>(result), labels, w.ce, w.sl1, w.pos);
     const int pt = (L.A + LS_THREADS - 1) / LS_THREADS;
     if (pt <= 9)
-        hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
+        hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
+                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     else if (pt <= 24)
-        hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
+        hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
+                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     else
-        hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, B, bnorm, w.sample, w.partial, SUMSQ_BLOCKS, weight_decay,
-                       w.losses);
+        hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
+                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     HIP_OK(hipGetLastError());
 }
 
