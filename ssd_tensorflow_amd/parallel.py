@@ -14,8 +14,10 @@ import torch.distributed as dist
 
 
 def env():
-    """(rank, local_rank, world_size) from the launcher's environment."""
-    return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    """(rank, local_rank, world_size) from the launcher's environment.  SSD_FORCE_DEVICE pins the GPU ordinal of
+    every rank (plumbing tests on a one-GPU box: all ranks on GPU 0, backend gloo)."""
+    local = int(os.environ.get('SSD_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    return int(os.environ.get('RANK', '0')), local, int(os.environ.get('WORLD_SIZE', '1'))
 
 
 def init(backend=None):
@@ -24,7 +26,7 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('SSD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
             torch.cuda.set_device(local)

@@ -222,6 +222,8 @@ def main(argv=None):
             print('[i] Checkpoint saved:', path)
         if writer is not None:
             writer.close()
+        if os.environ.get('SSD_PRINT_CHECKSUM'):      # replica agreement check of the multi-rank tests
+            print('[checksum] rank %d step %d params %.12e' % (rank, net.global_step, float(net.params_flat.double().sum())), flush=True)
     if world > 1:
         torch.distributed.barrier()
     return 0

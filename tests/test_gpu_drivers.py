@@ -143,3 +143,73 @@ def test_real_dataset_directory_feeds_training_and_inference(tmp_path, capsys):
     files = sorted(str(p) for p in (voc / 'test' / 'VOCdevkit' / 'VOC2007' / 'JPEGImages').iterdir())
     assert infer.main(['--name', run, '--output-dir', odir] + files) == 0
     assert '[i] Number of files:    2' in capsys.readouterr().out
+
+
+def test_two_rank_training_on_one_gpu_matches_single_process(tmp_path):
+    """The data-parallel train.py with two ranks (both on GPU 0, gloo: the plumbing of rank-sharded batches, device
+    guards, bucketed all-reduce behind the weight-gradient stream, loss normaliser, an EMPTY shard in the short last
+    batch, rank-summed summaries) against one process at the global batch size: same samples per step, so the weights
+    must agree to fp32 summation-order accuracy and the two replicas bit for bit."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    common = ['--epochs', '2', '--synthetic-train', '9', '--synthetic-valid', '3', '--checkpoint-interval', '1',
+              '--lr-values', '0.0001', '--lr-boundaries', '', '--tensorboard-dir', str(tmp_path / 'tb')]
+    env = dict(os.environ, SSD_FORCE_DEVICE='0', SSD_DIST_BACKEND='gloo', SSD_PRINT_CHECKSUM='1', PYTHONPATH=root)
+    dp = str(tmp_path / 'dp')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), '-m', 'ssd_tensorflow_amd.train', '--name', dp, '--batch-size', '2'] + common,
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    sums = dict(re.findall(r'\[checksum\] rank (\d) step \d+ params (\S+)', r.stdout))
+    assert set(sums) == {'0', '1'} and sums['0'] == sums['1'], r.stdout[-2000:]
+    assert '[i] Batch size:            2 x 2 GPU(s)' in r.stdout and '[i] Train  2/2' in r.stdout
+    one = str(tmp_path / 'one')
+    assert train.main(['--name', one, '--batch-size', '4'] + common) == 0
+    a, b = np.load(dp + '/final.npz'), np.load(one + '/final.npz')
+    assert int(a['__global_step__']) == int(b['__global_step__']) == 6        # 2 epochs x ceil(9 / 4): the 1-sample batch included
+    worst = 0.0
+    for k in b.files:
+        if k.startswith('__') and not k.startswith('__momentum__/'):
+            continue
+        d = float(np.abs(a[k].astype(np.float64) - b[k]).max()); scale = float(np.abs(b[k]).max()) + 1e-30
+        worst = max(worst, d / scale)
+    assert worst < 2e-4, worst
+
+
+def test_build_from_vgg_directory(tmp_path):
+    """N3: a VGG-16 export (13 conv layers + full-size fc6 / fc7) -> weights.save_vgg_npz (a-trous decimation,
+    ssdvgg.py:245-253,273-280) -> build_from_vgg(vgg_dir): the trunk carries the file's tensors, mod_conv6/7 the
+    decimated ones (checked against the loop restatement), the new layers stay Xavier-initialised."""
+    from oracle import boxes as ob, ssdvgg_ref as ref
+    from ssd_tensorflow_amd import weights
+    from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+    rng = np.random.default_rng(9)
+    shapes = ref.param_shapes(ob.get_preset('vgg300'), 20)
+    vgg = {}
+    for n in weights.VGG_CONVS:
+        vgg[n + '/filter'] = (rng.normal(0, 0.02, shapes[n + '/filter'])).astype(np.float32)
+        vgg[n + '/biases'] = rng.normal(0, 0.1, shapes[n + '/biases']).astype(np.float32)
+    vgg['fc6/weights'] = rng.normal(0, 0.01, (7, 7, 512, 4096)).astype(np.float32); vgg['fc6/biases'] = rng.normal(size=4096).astype(np.float32)
+    vgg['fc7/weights'] = rng.normal(0, 0.01, (1, 1, 4096, 4096)).astype(np.float32); vgg['fc7/biases'] = rng.normal(size=4096).astype(np.float32)
+    vdir = tmp_path / 'vgg_graph'; os.makedirs(vdir)
+    weights.save_vgg_npz(str(vdir / 'vgg16_ssd.npz'), vgg)
+    sess = Session(0)
+    net = SSDVGG(sess, 'vgg300')
+    net.build_from_vgg(str(vdir), 20, max_batch=1, training=False, seed=3)
+    got = net.save_variables()
+    w6, b6, w7, b7 = ref.decimate_fc_loops(vgg['fc6/weights'], vgg['fc6/biases'], vgg['fc7/weights'], vgg['fc7/biases'])
+    assert np.array_equal(got['mod_conv6/filter'], w6.astype(np.float32)) and np.array_equal(got['mod_conv6/biases'], b6.astype(np.float32))
+    assert np.array_equal(got['mod_conv7/filter'], w7.astype(np.float32)) and np.array_equal(got['mod_conv7/biases'], b7.astype(np.float32))
+    for n in weights.VGG_CONVS:
+        assert np.array_equal(got[n + '/filter'], vgg[n + '/filter']) and np.array_equal(got[n + '/biases'], vgg[n + '/biases'])
+    lib_init = ref.init_params_lib(ob.get_preset('vgg300'), 20, seed=3)
+    for n in ('conv8_1/filter', 'conv11_2/filter', 'classifiers/classifier2_4/filter', 'l2_norm_conv4_3/scale'):
+        assert np.array_equal(got[n], lib_init[n]), n
+    x = rng.integers(0, 256, (1, 300, 300, 3)).astype(np.float32)
+    res = sess.run(net.result, feed_dict={net.image_input: x, net.keep_prob: 1})
+    assert res.shape == (1, 8732, 25) and np.isfinite(res).all()
+    sess.close()
