@@ -150,6 +150,7 @@ private:
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
     hipEvent_t ev_h_ = nullptr, ev_cast_ = nullptr, ev_fmap_[MAX_MAPS] = {};
+    int tail_first_ = 0;                 // op index of conv8_1: the extra layers behind it form backward's side chain
     bool bw_heads_side_ = false;         // head data gradients in flight on the side stream (backward)
     bool overlap_ = true;
     bool own_wstream_ = true;

@@ -132,6 +132,9 @@ void Net::build_graph() {
         for (int t : head_t_) tensors_[t].data_f32 = true;   // the loss reads fp32 logits / offsets
     }
 
+    tail_first_ = (int)ops_.size();
+    for (size_t i = 0; i < ops_.size(); ++i)
+        if (ops_[i].name == "conv8_1") tail_first_ = (int)i;
     // ---- arena layout: all filters (forward order), all biases, the l2-norm scale ----
     size_t off = 0;
     for (auto& op : ops_)
@@ -496,16 +499,24 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         const bool need_dx = op.in != input_t_;
         const bool last = in.done + 1 == in.consumers;
         prof_.layer = op.name.c_str();
-        // The multibox heads' data gradients are independent of each other (each is the first writer of its feature
-        // map's gradient): those of the small maps (a few workgroups, latency-bound) go to the side stream and run
-        // beside the two big ones; the trunk's first backward op waits for them.
-        const bool small_head = op.kind == OP_CONV && op.head >= 2 && hstream_ && overlap_ && in.done == 0;
-        if (bw_heads_side_ && !(op.kind == OP_CONV && op.head >= 0)) {
+        // Side region of backward.  (1) The multibox heads' data gradients are independent of each other (each is the
+        // first writer of its feature map's gradient): those of the small maps (a few workgroups, latency-bound) go to
+        // the side stream.  (2) So does the chain of extra layers behind them (conv11_2 ... conv8_2: eight dependent,
+        // latency-bound launches): it only needs the small heads' results and runs beside the two big heads' data
+        // gradients and the l2-norm backward on the main stream.  conv8_1 (which needs the chain's result and
+        // accumulates into mod_conv7's gradient after head 1) joins the streams.
+        const int op_index = bw_next_ + 1;
+        const bool side_ok = hstream_ && overlap_;
+        const bool small_head = side_ok && op.kind == OP_CONV && op.head >= 2 && in.done == 0;
+        const bool in_tail = side_ok && op.kind == OP_CONV && op.head < 0 && op_index > tail_first_ && bw_heads_side_;
+        const bool independent = (op.kind == OP_CONV && op.head >= 0) || op.kind == OP_L2NORM;      // main-stream ops beside the region
+        if (bw_heads_side_ && !small_head && !in_tail && !independent) {
             HIP_OK(hipEventRecord(ev_h_, hstream_));
             HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
             bw_heads_side_ = false;
         }
-        hipStream_t ds = small_head ? hstream_ : stream_;      // stream of this op's data gradient
+        hipStream_t ds = (small_head || in_tail) ? hstream_ : stream_;      // stream of this op's data gradient
+        hipStream_t dys = in_tail ? hstream_ : stream_;                    // stream on which this op's dy became final
         if (small_head) bw_heads_side_ = true;
         switch (op.kind) {
         case OP_CONV: {
@@ -518,7 +529,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             hipStream_t ws = side ? wstream_ : stream_;
             float* slab = wgrad_ws_ + op.ws_off;
             if (side) {
-                HIP_OK(hipEventRecord(ev_dy_, stream_));
+                HIP_OK(hipEventRecord(ev_dy_, dys));
                 HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
                 side_used = true;
             }

@@ -438,36 +438,59 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    f32x4 ds[L2_MAXJ];
+    constexpr int PX = 2;            // pixels per wave and iteration: their loads and shuffle trees overlap
+    f32x4 ds[L2_MAXJ], sc[L2_MAXJ];
 #pragma unroll
-    for (int j = 0; j < L2_MAXJ; ++j) ds[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pix = wave; pix < npix; pix += nwaves) {
-        f32x4 v[L2_MAXJ], g[L2_MAXJ], sc[L2_MAXJ];
-        float ss = 0.f, t = 0.f;
+    for (int j = 0; j < L2_MAXJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        ds[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sc[j] = c < C ? ld4(scale + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int pix0 = wave * PX; pix0 < npix; pix0 += nwaves * PX) {
+        f32x4 v[PX][L2_MAXJ], g[PX][L2_MAXJ];
+        float ss[PX], t[PX];
 #pragma unroll
-        for (int j = 0; j < L2_MAXJ; ++j) {
-            const int c = lane * 4 + 256 * j;
-            v[j] = g[j] = sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < C) {
-                v[j] = ld4t(x + (size_t)pix * C + c);
-                g[j] = ld4t(dy + (size_t)pix * C + c);
-                sc[j] = ld4(scale + c);
-            }
+        for (int q = 0; q < PX; ++q) {
+            const int pix = pix0 + q;
+            ss[q] = t[q] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ss += v[j][e] * v[j][e];
-                t += sc[j][e] * g[j][e] * v[j][e];
+            for (int j = 0; j < L2_MAXJ; ++j) {
+                const int c = lane * 4 + 256 * j;
+                v[q][j] = g[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < C && pix < npix) {
+                    v[q][j] = ld4t(x + (size_t)pix * C + c);
+                    g[q][j] = ld4t(dy + (size_t)pix * C + c);
+                }
             }
         }
-        ss = wave_sum(ss);
-        t = wave_sum(t);
-        const float r = rsqrtf(fmaxf(ss, 1e-12f));
-        const float k = ss > 1e-12f ? t * r * r * r : 0.f;
 #pragma unroll
-        for (int j = 0; j < L2_MAXJ; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (c < C) st4t(dx + (size_t)pix * C + c, sc[j] * g[j] * r - v[j] * k);
-            ds[j] += g[j] * v[j] * r;
+        for (int q = 0; q < PX; ++q)
+#pragma unroll
+            for (int j = 0; j < L2_MAXJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ss[q] += v[q][j][e] * v[q][j][e];
+                    t[q] += sc[j][e] * g[q][j][e] * v[q][j][e];
+                }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                ss[q] += __shfl_xor(ss[q], o, 64);
+                t[q] += __shfl_xor(t[q], o, 64);
+            }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const int pix = pix0 + q;
+            if (pix >= npix) continue;
+            const float r = rsqrtf(fmaxf(ss[q], 1e-12f));
+            const float k = ss[q] > 1e-12f ? t[q] * r * r * r : 0.f;
+#pragma unroll
+            for (int j = 0; j < L2_MAXJ; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < C) st4t(dx + (size_t)pix * C + c, sc[j] * g[q][j] * r - v[q][j] * k);
+                ds[j] += g[q][j] * v[q][j] * r;
+            }
         }
     }
 #pragma unroll

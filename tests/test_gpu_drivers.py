@@ -171,13 +171,15 @@ def test_two_rank_training_on_one_gpu_matches_single_process(tmp_path):
     assert train.main(['--name', one, '--batch-size', '4'] + common) == 0
     a, b = np.load(dp + '/final.npz'), np.load(one + '/final.npz')
     assert int(a['__global_step__']) == int(b['__global_step__']) == 6        # 2 epochs x ceil(9 / 4): the 1-sample batch included
-    worst = 0.0
+    errs = {}
     for k in b.files:
         if k.startswith('__') and not k.startswith('__momentum__/'):
             continue
         d = float(np.abs(a[k].astype(np.float64) - b[k]).max()); scale = float(np.abs(b[k]).max()) + 1e-30
-        worst = max(worst, d / scale)
-    assert worst < 2e-4, worst
+        errs[k] = d / scale
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    print('    worst DP-vs-single deviations:', top)
+    assert top[0][1] < 2e-4, top
 
 
 def test_build_from_vgg_directory(tmp_path):
