@@ -186,7 +186,7 @@ def test_two_rank_training_on_one_gpu_matches_single_process(tmp_path):
     top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     print('    worst DP-vs-single deviation, relative to the distance the filter moved:', top)
     assert all(e < 0.6 for _, e in top), top
-    assert max(errs[k] for k in errs if k.startswith(('conv1', 'conv2', 'conv3', 'conv4', 'classifiers/classifier0', 'classifiers/classifier1'))) < 0.05
+    assert max(errs[k] for k in errs if k.startswith(('conv1_', 'conv2_', 'conv3_', 'conv4_', 'classifiers/classifier0_', 'classifiers/classifier1_'))) < 0.05
 
 
 def test_build_from_vgg_directory(tmp_path):
