@@ -506,8 +506,7 @@ int ssd_null_gradients_dev(ssd_handle h) {
 int ssd_train_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
     API_BEGIN_NET(h)
     n.forward(x_dev, b, true, y_dev);
-    n.backward(b, y_dev);
-    n.apply_gradients(1.f);
+    n.backward_apply(b, y_dev, 1.f);
     API_END
 }
 int ssd_eval_step_dev(ssd_handle h, const float* x_dev, const float* y_dev, int b) {
@@ -558,8 +557,7 @@ int ssd_train_step(ssd_handle h, const float* x, const float* y, int b, float* r
     API_BEGIN_NET(h)
     n.upload_xy(x, y, b);
     n.forward(n.x_stage(), b, true, n.y_stage());
-    n.backward(b, n.y_stage());
-    n.apply_gradients(1.f);
+    n.backward_apply(b, n.y_stage(), 1.f);
     if (result_out) n.copy_result(result_out, b);
     if (losses_out) n.get_losses(losses_out);
     HIP_OK(hipStreamSynchronize(n.stream()));

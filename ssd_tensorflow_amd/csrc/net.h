@@ -87,6 +87,7 @@ public:
     bool backward_step(size_t min_floats, size_t* off, size_t* count, bool sync_main);
     void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
+    void backward_apply(int b, const float* y, float grad_scale);      // backward + update, the optimizer overlapped with backward's tail
     void set_loss_normalizer(float bnorm) { loss_bnorm_ = bnorm; }      // <= 0: every step's own batch size
     void null_gradients_step();                                         // gradient arena of a step without samples
     void set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd);

@@ -624,6 +624,38 @@ void Net::apply_gradients(float grad_scale) {
     ++global_step;
 }
 
+// backward + update of a single-GPU step with the optimizer overlapped: the filter region of the arena completes from its
+// end (heads, conv11 ... conv1), so once the bulk of it is final its momentum update runs on the weight-gradient stream
+// beside the data gradients of the first layers; only the small remainder (conv1_x / conv2_x filters, biases, scale) is
+// updated after the last layer.  Same arithmetic as backward() + apply_gradients().
+void Net::backward_apply(int b, const float* y, float grad_scale) {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    backward_begin(b, y);
+    const float lr = current_lr();
+    size_t off = 0, count = 0, o2, c2;
+    const bool more = backward_step(nfilters_ / 2, &off, &count, false);
+    const bool early = more && count > 0 && wstream_ && overlap_;
+    if (early) {
+        // the updated filters must no longer be read by a data gradient still running on the main stream
+        HIP_OK(hipEventRecord(ev_dy_, stream_));
+        HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+        g_prof = &prof_;
+        prof_.layer = "optimizer";
+        momentum_update(params_ + off, mom_ + off, grads_ + off, count, lr, momentum_, grad_scale, wstream_);
+    }
+    if (more)
+        while (backward_step(nparams_, &o2, &c2, true)) {}
+    g_prof = &prof_;
+    prof_.layer = "optimizer";
+    if (early) {
+        if (off > 0) momentum_update(params_, mom_, grads_, off, lr, momentum_, grad_scale, stream_);
+        momentum_update(params_ + nfilters_, mom_ + nfilters_, grads_ + nfilters_, nparams_ - nfilters_, lr, momentum_, grad_scale, stream_);
+    } else {
+        momentum_update(params_, mom_, grads_, nparams_, lr, momentum_, grad_scale, stream_);
+    }
+    ++global_step;
+}
+
 void Net::null_gradients_step() {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     null_gradients(params_, grads_, nfilters_, nparams_, wd_, stream_);

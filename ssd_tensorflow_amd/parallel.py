@@ -108,8 +108,7 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
     if world <= 1 and not force_collectives:
         if b == 0:
             return
-        net.forward_backward_dev(x_dev, y_dev)
-        net.apply_gradients_dev(1.0)
+        net.train_step_dev(x_dev, y_dev)        # forward + backward + update, the optimizer overlapped with backward's tail
         return
     if global_count is not None:
         net.set_loss_normalizer(global_count / world)
