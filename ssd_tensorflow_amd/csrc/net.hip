@@ -506,7 +506,8 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         // gradients and the l2-norm backward on the main stream.  conv8_1 (which needs the chain's result and
         // accumulates into mod_conv7's gradient after head 1) joins the streams.
         const int op_index = bw_next_ + 1;
-        const bool side_ok = hstream_ && overlap_;
+        static const bool bw_side_on = [] { const char* v = getenv("SSD_BW_SIDE"); return !(v && v[0] == '0'); }();      // A/B switch
+        const bool side_ok = hstream_ && overlap_ && bw_side_on;
         const bool small_head = side_ok && op.kind == OP_CONV && op.head >= 2 && in.done == 0;
         const bool in_tail = side_ok && op.kind == OP_CONV && op.head < 0 && op_index > tail_first_ && bw_heads_side_;
         const bool independent = (op.kind == OP_CONV && op.head >= 0) || op.kind == OP_L2NORM;      // main-stream ops beside the region
@@ -634,7 +635,8 @@ void Net::backward_apply(int b, const float* y, float grad_scale) {
     const float lr = current_lr();
     size_t off = 0, count = 0, o2, c2;
     const bool more = backward_step(nfilters_ / 2, &off, &count, false);
-    const bool early = more && count > 0 && wstream_ && overlap_;
+    static const bool early_on = [] { const char* v = getenv("SSD_EARLY_UPDATE"); return !(v && v[0] == '0'); }();      // A/B switch
+    const bool early = early_on && more && count > 0 && wstream_ && overlap_;
     if (early) {
         // the updated filters must no longer be read by a data gradient still running on the main stream
         HIP_OK(hipEventRecord(ev_dy_, stream_));
