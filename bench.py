@@ -452,7 +452,11 @@ def run_config(a, rank, world, local):
             'roofline': roofline,
         }
         if roofline is not None and world == 1:
-            tr, src = pmc_traffic(roofline.get('dominant_by_time', roofline['kernel']), a.dtype, a.mode)
+            if a.mode == 'decode':      # the whole pass is priced: traffic of all its kernels
+                parts = [pmc_traffic(k, a.dtype, a.mode) for k in kernels]
+                tr, src = (sum(p[0] for p in parts), parts[0][1]) if parts and all(p[0] is not None for p in parts) else (None, None)
+            else:
+                tr, src = pmc_traffic(roofline['kernel'], a.dtype, a.mode)
             if tr is not None:
                 roofline['traffic'] = tr
                 roofline['traffic_source'] = src

@@ -38,6 +38,17 @@ for k in sorted(tot, key=lambda k: -tot[k]):
     print(f'{k}\t{name}\tlaunches={cnt[k]}\tavg={tot[k] / cnt[k]:.4g}\tsum={tot[k]:.4g}')
 EOF
 done
+# 3b. the same counters and the kernel trace for the decode + NMS pass (config 5)
+if [ -z "$EXTRA" ]; then
+for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pdc_$C -o c -- \
+        python "$R/bench.py" --mode decode --batch 128 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events >/dev/null 2>&1
+    python "$R/tools/pmc_table.py" "$C" /tmp/pdc_$C/c_counter_collection.csv > "$O/decode_pmc_$C.txt"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pdd -o d -- \
+    python "$R/bench.py" --mode decode --batch 128 --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_decode_under_rocprof.json" 2>/dev/null
+cp /tmp/pdd/d_kernel_stats.csv "$O/rocprofv3_kernel_stats_decode_b128.csv"
+fi
 # 4. per-layer event table + the headline line (with the CPU baseline)
 cd "$R"
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap --per-layer $EXTRA > /dev/null 2> "$O/per_layer_events.txt"
