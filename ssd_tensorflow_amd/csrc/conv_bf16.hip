@@ -1549,9 +1549,9 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
         launch_gather_c64<MODE_FWD>(a, "conv_fwd_bf16_c64", fl, by, s);
         return;
     }
-    // (small maps: a handful of workgroups, latency-bound -- the per-tap kernel's shorter units win: head of the 10x10 map
-    // 45 -> 36 us, gpurun r02_b heads_tiles_bf16)
-    if (gather_rows_applicable(d, false) && d.Co >= 128 && a.M >= 4096) {
+    // (multibox heads of the small maps: a handful of workgroups, latency-bound -- the per-tap kernel's shorter units win:
+    // head of the 10x10 map 45 -> 36 us, gpurun r02_b heads_tiles_bf16)
+    if (gather_rows_applicable(d, false) && d.Co >= 128 && !(y_f32 && a.M < 4096)) {
         if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
         else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
         return;
