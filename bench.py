@@ -332,10 +332,18 @@ def run_config(a, rank, world, local):
                 print(f'[bench] bucketed all-reduce failed ({type(e).__name__}: {e}); falling back to a single all-reduce', file=sys.stderr)
             state['bucket'] = 0
             allreduce_mode = 'single, after backward (FALLBACK: the bucketed path failed)'
+    use_events = not a.no_kernel_events
+    events_in_timed_region = use_events and not (a.mode == 'train' and not a.no_overlap)
+    if events_in_timed_region:
+        # the per-launch events are created on first use (a fresh process pays ~0.5 ms for each): the warmup steps run
+        # with the profiler on so that the timed region re-uses its pool
+        check(lib.ssd_profile_enable(net._h, 1))
     for _ in range(a.warmup):
         step()
     drain()
-    use_events = not a.no_kernel_events
+    if events_in_timed_region:
+        torch.cuda.synchronize()
+        check(lib.ssd_profile_report(net._h, C.create_string_buffer(1 << 16), 1 << 16))      # discard, keep the pool
     # In training the weight gradients run on a side stream next to the data gradients, so kernels of
     # the timed region overlap and a per-launch event interval is not one kernel's own duration.  The
     # timed region therefore runs WITHOUT per-launch events; the roofline block comes from an equal
