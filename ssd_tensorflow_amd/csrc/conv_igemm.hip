@@ -1269,9 +1269,16 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     return p;
 }
 
+static bool use_first_wgrad(const ConvDesc& d) {
+    static const int on = env_int("SSD_FIRST_WGRAD_F32", 1);        // A/B switch
+    return on && conv_first_wgrad_f32_applicable(d);
+}
+
 size_t conv_wgrad_ws_floats(const ConvDesc& d) {
     WgradPlan p = plan_wgrad(d);
-    return (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
+    size_t n = (size_t)p.nsplit * ((size_t)d.KH * d.KW * d.Ci * d.Co + d.Co);
+    if (conv_first_wgrad_f32_applicable(d)) n = std::max(n, conv_first_wgrad_f32_ws_floats(d));
+    return n;
 }
 
 template <int WM, int WN, int TM, int TN, bool SMALLC, bool YBF = false>
@@ -1417,6 +1424,11 @@ static void conv_wgrad_any(const ConvDesc& d, const float* x, const void* dy, bo
 
 void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
                 float weight_decay, float* ws, hipStream_t s) {
+    if (use_first_wgrad(d)) {
+        check_desc(d);
+        conv_first_wgrad_f32(d, x, dy, dw, dbias, w, weight_decay, ws, s);
+        return;
+    }
     conv_wgrad_any(d, x, dy, false, dw, dbias, w, weight_decay, ws, s);
 }
 

@@ -16,6 +16,7 @@ TOL = 1e-3
 # (name, b, hi, wi, ci, co, k, stride, dil, padding, relu)
 CONV_CASES = [
     ('conv1_1-like smallC', 2, 37, 41, 3, 64, 3, 1, 1, 'SAME', True),
+    ('conv1_1-like smallC, 1-wide image rows, many pixels', 3, 130, 1, 3, 64, 3, 1, 1, 'SAME', True),
     ('conv1_2-like 64->64', 2, 40, 33, 64, 64, 3, 1, 1, 'SAME', True),
     ('conv2_1-like 64->128', 1, 30, 30, 64, 128, 3, 1, 1, 'SAME', True),
     ('conv4-like 256->512', 1, 19, 19, 256, 512, 3, 1, 1, 'SAME', True),
@@ -126,7 +127,7 @@ FP32_VARIANTS = [
     dict(SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_GLDS_WGRAD='2'),                        # 64x64 / 128x64, DMA weight gradient on every tile
     dict(SSD_GLDS='0', SSD_TILE='0', SSD_WGRAD_CFG='0', SSD_GLDS_WGRAD='0'),          # register-staged kernels
     dict(SSD_GLDS='0', SSD_TILE='1', SSD_WGRAD_CFG='1'),
-    dict(SSD_GLDS='0', SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_FIRST_F32='0'),
+    dict(SSD_GLDS='0', SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_FIRST_F32='0', SSD_FIRST_WGRAD_F32='0'),
     dict(SSD_GLDS='0', SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_DGRAD_PARITY='0', SSD_WGRAD_ROUNDS='0'),
 ]
 
