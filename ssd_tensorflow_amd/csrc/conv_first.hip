@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 
-    float av[2][U];
-    f32x2 bv[2][U];
+    // ring of three groups of U pixel pairs: two groups of loads in flight while the third multiplies (the layer is
+    // bound by memory-level parallelism: 16 resident waves per CU x 2 groups x 8 x 512 B of dy in flight)
+    float av[3][U];
+    f32x2 bv[3][U];
     auto load_group = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -212,15 +214,27 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
                 }
         }
     };
-    const int ngroups = (p1 - p0 + 2 * U - 1) / (2 * U);
-    if (ngroups > 0) load_group(0);
-    for (int g = 0; g < ngroups; ++g) {
-        const int cur = g & 1;
-        if (g + 1 < ngroups) load_group(cur ^ 1);
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], bv[cur][u][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], bv[cur][u][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u][1], acc1, 0, 0, 0);
+        }
+    };
+    const int ngroups = (p1 - p0 + 2 * U - 1) / (2 * U);
+    if (ngroups > 0) load_group(0);
+    if (ngroups > 1) load_group(1);
+    // the ring index is compile-time inside each of the three unrolled bodies (dynamic indexing would spill the ring)
+    for (int g = 0; g < ngroups; g += 3) {
+        if (g + 2 < ngroups) load_group(2);
+        multiply(0);
+        if (g + 1 < ngroups) {
+            if (g + 3 < ngroups) load_group(0);
+            multiply(1);
+        }
+        if (g + 2 < ngroups) {
+            if (g + 4 < ngroups) load_group(1);
+            multiply(2);
         }
     }
     // D rows = k index (r&3) + 8*(r>>2) + 4*lh, D column li = channel 2*li (acc0) / 2*li + 1 (acc1)
@@ -248,7 +262,7 @@ bool conv_first_wgrad_f32_applicable(const ConvDesc& d) {
 static int first_wgrad_f32_plan(const ConvDesc& d, int* chunk) {
     const int M = d.B * d.Ho * d.Wo;
     int nwg = cdiv(M, 1024);                   // >= 256 pixels per wave
-    if (nwg > 2048) nwg = 2048;
+    if (nwg > 1024) nwg = 1024;                // 4 workgroups per CU are resident: one round of the chip
     if (nwg < 1) nwg = 1;
     *chunk = cdiv(cdiv(M, nwg), 8) * 8;
     return cdiv(M, *chunk);

@@ -1378,6 +1378,12 @@ void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw,
         return;
     }
     const size_t total = wcount + Co;
+    if (nsplit >= 256) {        // hundreds of slabs of a small filter (conv1_1): 64 threads share an element
+        ReduceBatch one;
+        one.items.push_back(ReduceItem{ws, w, dw, db, (unsigned long long)wcount, nsplit, Co, wd, 64});
+        wgrad_reduce_flush(one, s);
+        return;
+    }
     int blocks = cdiv((long long)total, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     ProfScope prof("wgrad_reduce", 0.0, 4.0 * (double)total * (nsplit + 2), s);
