@@ -33,7 +33,7 @@ void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, f
 // dedicated fp32 first-layer forward (conv_first.hip): Ci*taps <= 32, Co == 64
 bool conv_first_fwd_f32_applicable(const ConvDesc& d);
 void conv_first_fwd_f32(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s);
-// dedicated fp32 first-layer weight gradient (conv_first.hip): Ci*taps <= 31, Co == 64; operands straight from global memory
+// dedicated fp32 first-layer weight gradient (conv_first.hip): Ci*taps <= 30, Co == 64; operands straight from global memory
 bool conv_first_wgrad_f32_applicable(const ConvDesc& d);
 size_t conv_first_wgrad_f32_ws_floats(const ConvDesc& d);
 void conv_first_wgrad_f32(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,

@@ -138,9 +138,8 @@ void conv_first_fwd_f32(const ConvDesc& d, const float* x, const float* w, const
 // v_mfma_f32_32x32x2_f32 the reduction index is the PIXEL (two per instruction), so every lane feeds the matrix
 // core straight from two global loads per pixel pair -- one gathered image value (its fixed k, zero padding by an
 // out-of-range buffer offset) and one 8-byte piece of dy (channels 2*li, 2*li+1: a wave reads 512 contiguous
-// bytes; the two components feed two accumulators = the even / odd output channels).  Row k = K of the image
-// operand is the constant 1: that row of the result is the bias gradient.  Loads of the next group of pixel pairs
-// are in flight while the current group multiplies.  Four waves of a workgroup add their accumulators through LDS
+// bytes; the two components feed two accumulators = the even / odd output channels) -- and sums those two dy values
+// for the bias gradient.  Loads of the next two groups of pixel pairs are in flight while the current group multiplies.  Four waves of a workgroup add their accumulators through LDS
 // and leave one slab; the fixed-order slab reduce (wgrad_reduce) finishes.  Exact fp32 products, fixed order.
 // (The packed small-C path of the generic weight gradient ran this layer at 0.44 ms = 1.7 TB/s.)
 // ---------------------------------------------------------------------------------
@@ -164,7 +163,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
     const int tp = kvalid ? li / p.Ci : 0, c = kvalid ? li - tp * p.Ci : 0;
     const int dh = p.tap_dh[tp], dw = p.tap_dw[tp];
     const unsigned koff = (unsigned)(((dh * p.Wi + dw) * p.Ci + c) * 4);
-    const bool ones_row = li == K;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x), 0, (unsigned)((size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc =
@@ -188,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
 
     // ring of three groups of U pixel pairs: two groups of loads in flight while the third multiplies (the layer is
     // bound by memory-level parallelism: 16 resident waves per CU x 2 groups x 8 x 512 B of dy in flight)
@@ -200,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
             const int sh = oh * p.stride + dh, sw = ow * p.stride + dw;
             const bool ok = valid && kvalid && (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
             const unsigned xo = (unsigned)((((b * p.Hi + oh * p.stride) * p.Wi + ow * p.stride) * p.Ci) * 4) + koff;
-            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)(ok ? xo : OOB), 0, 0));
-            av[buf][u] = ones_row ? (valid ? 1.f : 0.f) : a;
+            // (nothing may CONSUME a loaded value in here: a select on it would wait for every load in turn)
+            av[buf][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)(ok ? xo : OOB), 0, 0));
             const unsigned yo = (unsigned)((pix * p.Co + 2 * li) * 4);
             bv[buf][u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(y_rsrc, (int)(valid ? yo : OOB), 0, 0));
             pix += 2;
@@ -219,6 +218,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
         for (int u = 0; u < U; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u][0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u][1], acc1, 0, 0, 0);
+            bs0 += bv[buf][u][0];          // bias gradient: this lane's two channels over its pixels (zeros past the end)
+            bs1 += bv[buf][u][1];
         }
     };
     const int ngroups = (p1 - p0 + 2 * U - 1) / (2 * U);
@@ -244,6 +245,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
         *reinterpret_cast<f32x2*>(&red[wave][k][2 * li]) = f32x2{acc0[r], acc1[r]};
     }
     __syncthreads();
+    // rows K.. of the tile are unused by the filter: rows 30 / 31 carry the bias partial sums of the two pixel parities
+    *reinterpret_cast<f32x2*>(&red[wave][30 + lh][2 * li]) = f32x2{bs0, bs1};
+    __syncthreads();
     const size_t wcount = (size_t)K * p.Co;
     float* slab = p.ws + (size_t)blockIdx.x * (wcount + p.Co);
 #pragma unroll
@@ -251,12 +255,17 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_f32_kernel(FirstWgradF32
         const int e = tid + 256 * q, k = e >> 6, n = e & 63;
         const float sum = (red[0][k][n] + red[1][k][n]) + (red[2][k][n] + red[3][k][n]);
         if (k < K) slab[(size_t)k * p.Co + n] = sum;
-        else if (k == K) slab[wcount + n] = sum;
+    }
+    if (tid < 64) {
+        float bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) bsum += red[w][30][tid] + red[w][31][tid];
+        slab[wcount + tid] = bsum;
     }
 }
 
 bool conv_first_wgrad_f32_applicable(const ConvDesc& d) {
-    return d.Ci * d.KH * d.KW <= 31 && d.Co == 64 && d.Ci % 4 != 0 && d.dil == 1 && d.Wo >= 1;
+    return d.Ci * d.KH * d.KW <= 30 && d.Co == 64 && d.Ci % 4 != 0 && d.dil == 1 && d.Wo >= 1;
 }
 
 static int first_wgrad_f32_plan(const ConvDesc& d, int* chunk) {
@@ -276,7 +285,7 @@ size_t conv_first_wgrad_f32_ws_floats(const ConvDesc& d) {
 
 void conv_first_wgrad_f32(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
                           float weight_decay, float* ws, hipStream_t s) {
-    SSD_REQUIRE(conv_first_wgrad_f32_applicable(d), "first-layer weight gradient: Ci*taps <= 31, Co == 64, dilation 1");
+    SSD_REQUIRE(conv_first_wgrad_f32_applicable(d), "first-layer weight gradient: Ci*taps <= 30, Co == 64, dilation 1");
     SSD_REQUIRE((long long)d.B * d.Ho * d.Wo * d.Co < (1LL << 30) - 4 && (long long)d.B * d.Hi * d.Wi * d.Ci < (1LL << 30) - 4,
                 "first-layer kernel: tensor exceeds 4 GiB");
     FirstWgradF32Args a{};
