@@ -534,20 +534,37 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         int4* box = reinterpret_cast<int4*>(okey + DET_FAST);
         int4* nbox = box + DET_FAST;
         volatile unsigned char* alive = reinterpret_cast<unsigned char*>(nbox + DET_FAST);
-        for (int i = tid; i < n; i += DET_THREADS) skey[i] = candidate(i);
+        // every candidate's key, then (addressed by the key's anchor) its offsets and anchor: all global loads of the
+        // workgroup are in flight together and land while the ranking sweep below runs.  Indices are clamped instead of
+        // predicated: a select on a loaded value would make each load wait in turn.
+        constexpr int PER = DET_FAST / DET_THREADS;
+        u64 mykey[PER];
+        float loc[PER][4];
+        double anc[PER][4];
+        int pos[PER], cpos[PER];
+        if (n > 0) {
+#pragma unroll
+            for (int r = 0; r < PER; ++r) mykey[r] = candidate(min(tid + DET_THREADS * r, n - 1));
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int a = 32767 - (int)((mykey[r] >> 8) & 0xFFFFull);
+                const float* lp = p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4);
+                const double* ap = p.anchors + (size_t)a * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { loc[r][e] = lp[e]; anc[r][e] = ap[e]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int i = tid + DET_THREADS * r;
+            if (i < n) skey[i] = mykey[r];
+            else mykey[r] = ~0ull;
+            pos[r] = cpos[r] = 0;
+        }
         if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
         __syncthreads();
         // rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and
         // among those of its own class, in one sweep over the list (each read is an LDS broadcast)
-        constexpr int PER = DET_FAST / DET_THREADS;
-        u64 mykey[PER];
-        int pos[PER], cpos[PER];
-#pragma unroll
-        for (int r = 0; r < PER; ++r) {
-            const int i = tid + DET_THREADS * r;
-            mykey[r] = i < n ? skey[i] : ~0ull;
-            pos[r] = cpos[r] = 0;
-        }
         for (int j = 0; j < n; ++j) {
             const u64 kj = skey[j];
 #pragma unroll
@@ -595,7 +612,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
                 const int q = p.do_nms ? segstart[crank[(int)(key & 31ull)]] + cpos[r] : pos[r];
                 const int a = 32767 - (int)((key >> 8) & 0xFFFFull);
                 int bx[4], nb[4];
-                decode_box(p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4), p.anchors + (size_t)a * 4, bx);
+                decode_box(loc[r], anc[r], bx);
                 nms_roundtrip(bx, nb);
                 okey[q] = key;
                 box[q] = make_int4(bx[0], bx[1], bx[2], bx[3]);

@@ -825,17 +825,28 @@ __device__ __forceinline__ void loss_sample_body(int B, int A, float bnorm, cons
     unsigned u[PT];          // negatives[a] = pos ? 0 : ce  (ssdvgg.py:459) as bit patterns
     unsigned pmask = 0, vmask = 0;
     float npos = 0.f, psum = 0.f, lsum = 0.f;
+    {   // pass 1 issues every load, pass 2 consumes: a consumer between two loads would make each load wait in turn
+        float cv[PT], lv[PT];
+        unsigned char pv[PT];
 #pragma unroll
-    for (int r = 0; r < PT; ++r) {
-        const int a = tid + LS_THREADS * r;
-        u[r] = 0u;
-        if (a < A) {
-            const float c = cb[a];
-            const bool p = pb[a] != 0;
-            lsum += lb[a];
-            vmask |= 1u << r;
-            if (p) { pmask |= 1u << r; npos += 1.f; psum += c; }
-            else u[r] = __float_as_uint(c);
+        for (int r = 0; r < PT; ++r) {
+            const int a = tid + LS_THREADS * r;
+            const int ac = a < A ? a : 0;           // unconditional loads from a clamped index (a select on the loaded
+            cv[r] = cb[ac];                         // value would be a consumer again); masked in pass 2
+            lv[r] = lb[ac];
+            pv[r] = pb[ac];
+        }
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int a = tid + LS_THREADS * r;
+            u[r] = 0u;
+            if (a < A) {
+                const bool p = pv[r] != 0;
+                lsum += lv[r];
+                vmask |= 1u << r;
+                if (p) { pmask |= 1u << r; npos += 1.f; psum += cv[r]; }
+                else u[r] = __float_as_uint(cv[r]);
+            }
         }
     }
     block_sum3_1024(npos, psum, lsum, red);
