@@ -491,6 +491,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     u64* g1 = p.keys1 + (size_t)b * p.A2;
     // ---- the image's candidate segments (one per scan workgroup that touched the image) ----------------
     __shared__ int seg_off[DET_MAX_SEGS + 1], seg_base[DET_MAX_SEGS];
+    __shared__ int s_pos[DET_FAST], s_cpos[DET_FAST];
     const int row_lo = b * p.A, row_hi = row_lo + p.A;
     const int first_blk = row_lo / SCAN_ROWS, nseg = (row_hi - 1) / SCAN_ROWS - first_blk + 1;
     if (tid < nseg) {
@@ -559,20 +560,43 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             const int i = tid + DET_THREADS * r;
             if (i < n) skey[i] = mykey[r];
             else mykey[r] = ~0ull;
-            pos[r] = cpos[r] = 0;
+            s_pos[i] = 0; s_cpos[i] = 0;
         }
         if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
         __syncthreads();
-        // rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and
-        // among those of its own class, in one sweep over the list (each read is an LDS broadcast)
-        for (int j = 0; j < n; ++j) {
-            const u64 kj = skey[j];
+        // Rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and among those of
+        // its own class: the n x n comparison is the bulk of this kernel's arithmetic, so it is spread over ALL thread
+        // slots -- with n candidates rounded up to n2 (a power of two) each candidate gets 1024 / n2 slots, each sweeping
+        // its share of the list (every read an LDS broadcast); the partial counts meet in LDS.
+        {
+            const int n2 = next_pow2(n > 1 ? n : 1);
+            const int lg = 31 - __builtin_clz(n2);
+            const int nsweep = (DET_THREADS * PER) >> lg;
+            const int jchunk = (n + nsweep - 1) / nsweep;
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const bool gt = kj > mykey[r];
-                pos[r] += gt ? 1 : 0;
-                cpos[r] += (gt && ((kj ^ mykey[r]) & 31ull) == 0ull) ? 1 : 0;
+                const int slot = tid + DET_THREADS * r;
+                const int i = slot & (n2 - 1), sw = slot >> lg;
+                if (i >= n) continue;
+                const u64 ki = skey[i];
+                const int j0 = sw * jchunk, j1 = min(n, j0 + jchunk);
+                int gt = 0, cgt = 0;
+#pragma unroll 4
+                for (int j = j0; j < j1; ++j) {
+                    const u64 kj = skey[j];
+                    const bool g = kj > ki;
+                    gt += g ? 1 : 0;
+                    cgt += (g && ((kj ^ ki) & 31ull) == 0ull) ? 1 : 0;
+                }
+                if (gt) atomicAdd(&s_pos[i], gt);
+                if (cgt) atomicAdd(&s_cpos[i], cgt);
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int i = tid + DET_THREADS * r;
+            pos[r] = s_pos[i]; cpos[r] = s_cpos[i];
         }
         const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
         // class groups in first-appearance order (defaultdict, ssdutils.py:311-314)
