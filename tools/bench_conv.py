@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 from gpu_util import lib, check, ptr, conv_geom
 
-LAYERS = [('conv1_2', 300, 64, 64, 3, 1, 1), ('conv2_2', 150, 128, 128, 3, 1, 1), ('conv3_2', 75, 256, 256, 3, 1, 1),
+LAYERS = [('conv1_2', 300, 64, 64, 3, 1, 1), ('conv2_1', 150, 64, 128, 3, 1, 1), ('conv2_2', 150, 128, 128, 3, 1, 1), ('conv3_1', 75, 128, 256, 3, 1, 1),
+          ('conv3_2', 75, 256, 256, 3, 1, 1), ('conv4_1', 38, 256, 512, 3, 1, 1),
           ('conv4_2', 38, 512, 512, 3, 1, 1), ('conv5_2', 19, 512, 512, 3, 1, 1), ('mod_conv6', 19, 512, 1024, 3, 1, 6),
           ('mod_conv7', 19, 1024, 1024, 1, 1, 1), ('head1', 19, 1024, 152, 3, 1, 1), ('head0', 38, 512, 100, 3, 1, 1),
           # the small tail of the network (latency-bound: a handful of workgroups each)
