@@ -1232,8 +1232,14 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     if (p.smallc || (d.Ci <= 64 && d.Co <= 64)) p.cfg = 1;
     else if (d.Ci <= 64) p.cfg = 2;
     else if (waste64 < waste128) p.cfg = 3;      // fused heads: Co = 100 / 152
-    else if (M < 100000) p.cfg = 3;              // conv4 and deeper: 128x64 tiles (3 workgroups / CU) measured
-                                                 // 116 vs 107 TFLOP/s; conv2/conv3 are as fast on 128x128
+    else if (M < 100000) {
+        // conv4 and deeper: 3 workgroups / CU.  Round 1 took 128x64 tiles (116 vs 107 TFLOP/s on 128x128); re-measured on the
+        // round-2 kernels (tools/bench_conv.py sweep, gpurun r02): 64 input channels x 128 output channels is 1-5 % faster on
+        // every one of these layers (conv4_1 0.923 -> 0.907, conv4_2 1.800 -> 1.782, conv5_2 0.498 -> 0.475, mod_conv6
+        // 0.954 -> 0.907 ms).  SSD_WGRAD_DEEP_CFG=3 selects the old tile.
+        static const int deep = env_int("SSD_WGRAD_DEEP_CFG", 2);
+        p.cfg = deep == 3 ? 3 : 2;
+    }
     else p.cfg = 0;
     static const int forced = env_int("SSD_WGRAD_CFG", -1);      // tuning override
     if (forced >= 0 && forced < 4 && !p.smallc) p.cfg = forced;
