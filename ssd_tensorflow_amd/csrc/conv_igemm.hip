@@ -1061,7 +1061,7 @@ static int use_wgrad_dma() {
 // per-tile efficiency (bigger tiles re-use LDS fragments better).  0:128x128 1:128x64 2:64x128 3:64x64
 static int pick_tile(long long M, int N, int mode) {
     static const int forced = env_int("SSD_TILE", -1);      // tuning override
-    if (forced >= 0 && forced < 5) return forced;
+    if (forced >= 0 && forced < 4) return forced;
     static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
     // relative per-tile efficiency measured on vgg300 layers at batch 32 (tools/bench_conv.py):
     // forward runs 116-125 TF/s on every tile; the data-gradient is fastest on 64x64
@@ -1115,7 +1115,6 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
         case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2>(a, "conv_fwd_128x128", fl, by, s); break;
         case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2>(a, "conv_fwd_128x64", fl, by, s); break;
         case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2>(a, "conv_fwd_64x128", fl, by, s); break;
-        case 4: launch_gather_dma<MODE_FWD, 4, 1, 2, 2>(a, "conv_fwd_256x64", fl, by, s); break;
         default: launch_gather_dma<MODE_FWD, 2, 2, 1, 1>(a, "conv_fwd_64x64", fl, by, s); break;
         }
         return;
@@ -1206,7 +1205,6 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
         case 0: launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2>(a, "conv_dgrad_128x128", fl, by, s); break;
         case 1: launch_gather_dma<MODE_DGRAD, 4, 1, 1, 2>(a, "conv_dgrad_128x64", fl, by, s); break;
         case 2: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2>(a, "conv_dgrad_64x128", fl, by, s); break;
-        case 4: launch_gather_dma<MODE_DGRAD, 4, 1, 2, 2>(a, "conv_dgrad_256x64", fl, by, s); break;
         default: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1>(a, "conv_dgrad_64x64", fl, by, s); break;
         }
     } else {
