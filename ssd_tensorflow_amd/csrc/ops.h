@@ -73,7 +73,9 @@ void loss_work_carve(LossWork& w, void* base, int B, int A);
 // Forward of the loss; labels [B][A][nvars] device.  result must hold heads_result's output.
 // bnorm: the batch size the per-sample losses are averaged over (<= 0: this step's own B).  A data-parallel
 // caller whose shards are unequal passes global_samples / world, so that the mean over ranks is the global mean.
-void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
+// A step may compute its loss in several launches over disjoint sample ranges (forward lanes): L.buf, result and labels
+// point at the range's first sample, B = samples of this launch, b_off = index of its first sample, B_total = the step's.
+void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const float* result, const float* labels, LossWork& w,
                    float weight_decay, float bnorm, hipStream_t s);
 // sum of squares of the filter region into w.partial (the l2 term of multibox_loss, which must follow it in stream
 // order): 4 bytes per parameter, independent of the forward pass, so the step runs it beside the first layers

@@ -809,13 +809,13 @@ __device__ void loss_final_block(int B, float bnorm, const float* sample, const 
 }
 
 template <int PT>
-__device__ __forceinline__ void loss_sample_body(int B, int A, float bnorm, const float* __restrict__ ce,
+__device__ __forceinline__ void loss_sample_body(int b, int A, float bnorm, const float* __restrict__ ce,
                                                  const float* __restrict__ sl1, const unsigned char* __restrict__ pos,
                                                  unsigned char* __restrict__ sel, float* __restrict__ sample) {
     __shared__ float red[3 * LS_WAVES];
     __shared__ unsigned hist[256];
     __shared__ unsigned sh_prefix, sh_k, sh_ties, sh_wsum[4], sh_wtot[LS_WAVES];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* cb = ce + (size_t)b * A;
     const float* lb = sl1 + (size_t)b * A;
     const unsigned char* pb = pos + (size_t)b * A;
@@ -957,8 +957,10 @@ __device__ __forceinline__ void loss_sample_body(int B, int A, float bnorm, cons
     }
 }
 
+// One workgroup per sample.  A step may run the samples in several launches (forward lanes, net.hip): b_off is this launch's
+// first sample, B the step's total -- the workgroup that draws ticket B - 1, whichever launch it belongs to, finishes.
 template <int PT>
-__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, float bnorm, const float* __restrict__ ce,
+__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int b_off, int A, float bnorm, const float* __restrict__ ce,
                                                                  const float* __restrict__ sl1,
                                                                  const unsigned char* __restrict__ pos,
                                                                  unsigned char* __restrict__ sel,
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(int B, int A, f
                                                                  unsigned* __restrict__ ticket) {
     __shared__ double dred[LS_WAVES];
     __shared__ unsigned sh_last;
-    loss_sample_body<PT>(B, A, bnorm, ce, sl1, pos, sel, sample);
+    loss_sample_body<PT>((int)blockIdx.x + b_off, A, bnorm, ce, sl1, pos, sel, sample);
     // the workgroup that draws the last ticket reduces everything (loss_final_block); the ticket resets itself
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1025,27 +1027,28 @@ void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t
     HIP_OK(hipGetLastError());
 }
 
-void multibox_loss(const HeadLayout& L, int B, const float* result, const float* labels, LossWork& w,
+void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const float* result, const float* labels, LossWork& w,
                    float weight_decay, float bnorm, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     SSD_REQUIRE(L.A <= 32 * LS_THREADS, "loss: at most %d anchors", 32 * LS_THREADS);
-    SSD_REQUIRE(B <= LS_THREADS / 2, "loss: at most %d images per step", LS_THREADS / 2);
+    SSD_REQUIRE(B_total <= LS_THREADS / 2, "loss: at most %d images per step", LS_THREADS / 2);
     const int total = B * L.A;
     const HeadGrid G = head_grid(L, B);
-    if (!(bnorm > 0.f)) bnorm = (float)B;          // reduce_mean over this step's own batch (ssdvgg.py:520,559)
+    if (!(bnorm > 0.f)) bnorm = (float)B_total;          // reduce_mean over this step's own batch (ssdvgg.py:520,559)
+    const size_t o = (size_t)b_off * L.A;                // this launch's slice of the per-anchor work arrays
     ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars, s);
     hipLaunchKernelGGL(heads_kernel<true>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B,
-                       const_cast<float*>(result), labels, w.ce, w.sl1, w.pos);
+                       const_cast<float*>(result), labels, w.ce + o, w.sl1 + o, w.pos + o);
     const int pt = (L.A + LS_THREADS - 1) / LS_THREADS;
     if (pt <= 9)
-        hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
-                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
+        hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B_total, b_off, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample,
+                           w.partial, SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     else if (pt <= 24)
-        hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
-                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
+        hipLaunchKernelGGL(loss_sample_kernel<24>, dim3(B), dim3(LS_THREADS), 0, s, B_total, b_off, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample,
+                           w.partial, SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     else
-        hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample, w.partial,
-                           SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
+        hipLaunchKernelGGL(loss_sample_kernel<32>, dim3(B), dim3(LS_THREADS), 0, s, B_total, b_off, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample,
+                           w.partial, SUMSQ_BLOCKS, weight_decay, w.losses, w.ticket);
     HIP_OK(hipGetLastError());
 }
 
