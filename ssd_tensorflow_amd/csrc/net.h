@@ -152,7 +152,13 @@ private:
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
     hipEvent_t ev_h_ = nullptr, ev_cast_ = nullptr, ev_fmap_[MAX_MAPS] = {};
     hipStream_t s2_ = nullptr, h2_ = nullptr;   // second forward lane: its main and head streams (net.hip Net::forward)
-    hipEvent_t ev2_h_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
+    hipEvent_t ev2_h_ = nullptr, ev2_dy_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
+    struct BwLane {                             // a lane of the data-gradient chain (net.hip Net::backward_begin)
+        hipStream_t s, h;
+        hipEvent_t ev_dy, ev_h;
+        int b0, nb;
+    } bw_lane_[2] = {};
+    int bw_nl_ = 1;
     int tail_first_ = 0;                 // op index of conv8_1: the extra layers behind it form backward's side chain
     bool bw_heads_side_ = false;         // head data gradients in flight on the side stream (backward)
     bool overlap_ = true;

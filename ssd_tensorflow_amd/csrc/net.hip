@@ -339,6 +339,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&h2_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev2_h_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev2_dy_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_l2_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev2_fmap_[i], hipEventDisableTiming));
@@ -368,6 +369,7 @@ Net::~Net() {
         (void)hipStreamDestroy(s2_);
         (void)hipStreamDestroy(h2_);
         (void)hipEventDestroy(ev2_h_);
+        (void)hipEventDestroy(ev2_dy_);
         (void)hipEventDestroy(ev_l2_);
         (void)hipEventDestroy(ev_join_);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev2_fmap_[i]);
@@ -388,17 +390,16 @@ Net::~Net() {
 // ---------------------------------------------------------------------------------
 // Forward runs the op list on up to two LANES: the batch is cut in two halves that walk the network on two sets of
 // streams, so that the tail of one half's kernel (its last, partial round of workgroups) is filled by the other half's
-// kernel instead of idle CUs.  Measured with two independent batch-16 nets on two streams against one batch-32 net
-// (tools/two_streams_probe.py): +2.1 % in fp32, -5 % in bf16 (those kernels are power-limited, not tail-limited), so the
-// default is two lanes for fp32 and one for bf16 (SSD_FWD_LANES overrides).  Nothing in forward couples the samples
-// except the loss's final reduction, which the last per-sample workgroup of either lane performs (ops.hip).
+// kernel instead of idle CUs.  Measured on one box (SSD_FWD_LANES=1 / 2, gpurun r02): training step +0.5 % fp32 and
+// +2.7 % bf16, inference at batch 128 +1.6 %.  Nothing in forward couples the samples except the loss's final
+// reduction, which the last per-sample workgroup of either lane performs (ops.hip).
 void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
     g_prof = &prof_;
     tensors_[input_t_].data = const_cast<float*>(x);
     const bool side = hstream_ && overlap_;
     static const int lanes_env = [] { const char* v = getenv("SSD_FWD_LANES"); return v ? atoi(v) : 0; }();
-    const int want_lanes = lanes_env > 0 ? lanes_env : (bf16_ ? 1 : 2);
+    const int want_lanes = lanes_env > 0 ? lanes_env : 2;
     const int nl = (want_lanes >= 2 && side && s2_ && b >= 8) ? 2 : 1;
     struct Lane {
         hipStream_t s, h;
@@ -517,16 +518,39 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
 // start all-reducing finished gradient ranges while the rest of backward still runs: filters sit
 // in the arena in forward order, so reverse execution completes them from the END of the filter
 // region towards its beginning, always as one contiguous, growing suffix.
+// The data-gradient chain CAN run on the same two lanes as forward (SSD_BWD_LANES=2: half batches on two sets of streams;
+// a layer's data gradient, pooling backward and the loss gradient are per-sample work, while what couples the samples
+// stays ONE full-batch launch: every weight gradient, on the weight-gradient stream after both lanes' dy, and the l2-norm
+// backward, whose scale gradient sums over the batch).  Default is ONE lane: backward already has the weight-gradient
+// stream filling the data gradients' tails, a third concurrent half-batch kernel only shrinks the tiles' reuse --
+// measured on one box (profiles/r02_l_ab_bwd_lanes_*.txt): fp32 -0.3 %, bf16 -7 %.
 void Net::backward_begin(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
     prof_.layer = "loss";
-    multibox_loss_grad(heads_, b, result_, y, lw_, stream_);
-    bw_heads_side_ = false;
-    if (hstream_ && overlap_) {      // the small maps' head data gradients run beside the two big ones (backward_step)
-        HIP_OK(hipEventRecord(ev_h_, stream_));
-        HIP_OK(hipStreamWaitEvent(hstream_, ev_h_, 0));
+    const bool side = hstream_ && overlap_;
+    static const int lanes_env = [] { const char* v = getenv("SSD_BWD_LANES"); return v ? atoi(v) : 0; }();
+    const int want_lanes = lanes_env > 0 ? lanes_env : 1;
+    bw_nl_ = (want_lanes >= 2 && side && s2_ && b >= 8) ? 2 : 1;
+    bw_lane_[0] = BwLane{stream_, hstream_, ev_dy_, ev_h_, 0, bw_nl_ == 2 ? (b + 1) / 2 : b};
+    bw_lane_[1] = BwLane{s2_, h2_, ev2_dy_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2};
+    const int A = preset_->num_anchors, nv = C_ + 5;
+    if (bw_nl_ == 2) {      // lane 1 starts behind everything issued on the main stream so far (forward, the loss)
+        HIP_OK(hipEventRecord(ev_join_, stream_));
+        HIP_OK(hipStreamWaitEvent(s2_, ev_join_, 0));
     }
+    for (int li = 0; li < bw_nl_; ++li) {
+        const BwLane& ln = bw_lane_[li];
+        HeadLayout hl = heads_;
+        for (int i = 0; i < hl.nmaps; ++i)
+            hl.dbuf[i] = static_cast<char*>(heads_.dbuf[i]) + (size_t)ln.b0 * hl.hw[i] * hl.ld[i] * (hl.grad_bf16 ? 2 : 4);
+        multibox_loss_grad(hl, ln.nb, ln.b0, result_ + (size_t)ln.b0 * A * nv, y + (size_t)ln.b0 * A * nv, lw_, ln.s);
+        if (side) {      // the small maps' head data gradients run beside the two big ones (backward_step)
+            HIP_OK(hipEventRecord(ln.ev_h, ln.s));
+            HIP_OK(hipStreamWaitEvent(ln.h, ln.ev_h, 0));
+        }
+    }
+    bw_heads_side_ = false;
     for (Tensor& t : tensors_) t.done = 0;
     bw_next_ = (int)ops_.size() - 1;
     bw_b_ = b;
@@ -547,6 +571,9 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         ~BatchScope() { g_reduce_batch = prev; }
     } batch_scope(grouped ? &reduce_batch_ : nullptr);
     reduce_batch_.items.clear();
+    auto at = [](const Tensor& t, int b0, bool grad) -> char* {      // first element of sample b0
+        return static_cast<char*>(grad ? t.grad : t.data) + (size_t)b0 * t.per_image() * ((grad ? t.grad_f32 : t.data_f32) ? 4 : 2);
+    };
     while (bw_next_ >= 0 && hi - lo < min_floats) {
         const Op& op = ops_[bw_next_--];
         Tensor& in = tensors_[op.in];
@@ -559,7 +586,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         // the side stream.  (2) So does the chain of extra layers behind them (conv11_2 ... conv8_2: eight dependent,
         // latency-bound launches): it only needs the small heads' results and runs beside the two big heads' data
         // gradients and the l2-norm backward on the main stream.  conv8_1 (which needs the chain's result and
-        // accumulates into mod_conv7's gradient after head 1) joins the streams.
+        // accumulates into mod_conv7's gradient after head 1) joins the streams.  (Per lane: each has its side stream.)
         const int op_index = bw_next_ + 1;
         static const bool bw_side_on = [] { const char* v = getenv("SSD_BW_SIDE"); return !(v && v[0] == '0'); }();      // A/B switch
         const bool side_ok = hstream_ && overlap_ && bw_side_on;
@@ -567,12 +594,13 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         const bool in_tail = side_ok && op.kind == OP_CONV && op.head < 0 && op_index > tail_first_ && bw_heads_side_;
         const bool independent = (op.kind == OP_CONV && op.head >= 0) || op.kind == OP_L2NORM;      // main-stream ops beside the region
         if (bw_heads_side_ && !small_head && !in_tail && !independent) {
-            HIP_OK(hipEventRecord(ev_h_, hstream_));
-            HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
+            for (int li = 0; li < bw_nl_; ++li) {
+                HIP_OK(hipEventRecord(bw_lane_[li].ev_h, bw_lane_[li].h));
+                HIP_OK(hipStreamWaitEvent(bw_lane_[li].s, bw_lane_[li].ev_h, 0));
+            }
             bw_heads_side_ = false;
         }
-        hipStream_t ds = (small_head || in_tail) ? hstream_ : stream_;      // stream of this op's data gradient
-        hipStream_t dys = in_tail ? hstream_ : stream_;                    // stream on which this op's dy became final
+        const bool on_side = small_head || in_tail;      // this op's data gradient runs on the lanes' side streams
         if (small_head) bw_heads_side_ = true;
         switch (op.kind) {
         case OP_CONV: {
@@ -580,19 +608,21 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             // The weight gradient only feeds the optimizer; the data gradient is on the critical
             // path.  They read the same dy and write disjoint buffers, so the weight gradient goes
             // to a side stream: its workgroups fill the CUs the data-gradient's last partial wave
-            // of workgroups leaves idle (and vice versa).
+            // of workgroups leaves idle (and vice versa).  It is ONE launch over the whole batch: it waits for the dy
+            // of every lane (final on the lane's side stream inside the tail chain, on its main stream elsewhere).
             const bool side = wstream_ && overlap_;
             hipStream_t ws = side ? wstream_ : stream_;
             float* slab = wgrad_ws_ + op.ws_off;
             if (side) {
-                HIP_OK(hipEventRecord(ev_dy_, dys));
-                HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+                for (int li = 0; li < bw_nl_; ++li) {
+                    HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, in_tail ? bw_lane_[li].h : bw_lane_[li].s));
+                    HIP_OK(hipStreamWaitEvent(wstream_, bw_lane_[li].ev_dy, 0));
+                }
                 side_used = true;
             }
             const bool mask = last && in.relu_out;
             if (!bf16_) {
                 conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
-                if (need_dx) conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
             } else if (in.data_f32) {   // conv1_1
                 if (first_layer_kernel(d))
                     conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
@@ -601,30 +631,61 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                                              slab, ws);
             } else {
                 conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
-                if (need_dx) conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
             }
+            if (need_dx)
+                for (int li = 0; li < bw_nl_; ++li) {
+                    const BwLane& ln = bw_lane_[li];
+                    const ConvDesc dl = conv_desc(op, ln.nb);
+                    hipStream_t ds = on_side ? ln.h : ln.s;
+                    if (!bf16_)
+                        conv_dgrad(dl, reinterpret_cast<const float*>(at(out, ln.b0, true)), params_ + op.w_off,
+                                   reinterpret_cast<float*>(at(in, ln.b0, true)), mask ? reinterpret_cast<const float*>(at(in, ln.b0, false)) : nullptr,
+                                   in.done > 0, ds);
+                    else
+                        conv_dgrad_bf16(dl, reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)), wq_io_ + op.w_off,
+                                        reinterpret_cast<bf16_t*>(at(in, ln.b0, true)),
+                                        mask ? reinterpret_cast<const bf16_t*>(at(in, ln.b0, false)) : nullptr, in.done > 0, ds);
+                }
             lo = op.w_off;          // conv ops own descending, adjacent filter ranges
             // a handful of layers per grouped reduce: few launches, yet interleaved with the data gradients instead of
             // one long pass after the last layer (which nothing would hide)
             if (reduce_batch_.items.size() >= 6) wgrad_reduce_flush(reduce_batch_, ws);
             break;
         }
-        case OP_POOL: {
-            PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-            void* pws = maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr;
-            if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
-                if (bf16_) maxpool_bwd_rec(d, op.pool_rec, out.gh(), in.gh(), in.relu_out, stream_);
-                else maxpool_bwd_rec(d, op.pool_rec, out.gf(), in.gf(), in.relu_out, stream_);
-            } else if (bf16_) maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
-            else maxpool_bwd(d, in.f(), out.gf(), in.gf(), in.done > 0, last && in.relu_out, pws, stream_);
+        case OP_POOL:
+            for (int li = 0; li < bw_nl_; ++li) {
+                const BwLane& ln = bw_lane_[li];
+                PoolDesc d{ln.nb, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+                const size_t win = (size_t)ln.b0 * out.H * out.W * (in.C / 4);        // windows x 4 channels before this lane
+                void* pws = maxpool_bwd_ws_bytes(d) ? static_cast<char*>(pool_ws_) + win * sizeof(unsigned) : nullptr;
+                if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
+                    const void* rec = static_cast<const char*>(op.pool_rec) + win * sizeof(unsigned short);
+                    if (bf16_) maxpool_bwd_rec(d, rec, reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)), reinterpret_cast<bf16_t*>(at(in, ln.b0, true)), in.relu_out, ln.s);
+                    else maxpool_bwd_rec(d, rec, reinterpret_cast<const float*>(at(out, ln.b0, true)), reinterpret_cast<float*>(at(in, ln.b0, true)), in.relu_out, ln.s);
+                } else if (bf16_)
+                    maxpool_bwd(d, reinterpret_cast<const bf16_t*>(at(in, ln.b0, false)), reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)),
+                                reinterpret_cast<bf16_t*>(at(in, ln.b0, true)), in.done > 0, last && in.relu_out, pws, ln.s);
+                else
+                    maxpool_bwd(d, reinterpret_cast<const float*>(at(in, ln.b0, false)), reinterpret_cast<const float*>(at(out, ln.b0, true)),
+                                reinterpret_cast<float*>(at(in, ln.b0, true)), in.done > 0, last && in.relu_out, pws, ln.s);
+            }
             break;
-        }
         case OP_L2NORM:
             SSD_REQUIRE(in.done == 0 && !last, "l2norm backward must be the first of several consumers");
+            // the scale gradient sums over the batch: one launch on lane 0 behind lane 1's head gradient; lane 1 continues
+            // (pool4's backward accumulates into the same tensor) behind it
+            if (bw_nl_ == 2) {
+                HIP_OK(hipEventRecord(bw_lane_[1].ev_dy, bw_lane_[1].s));
+                HIP_OK(hipStreamWaitEvent(stream_, bw_lane_[1].ev_dy, 0));
+            }
             if (bf16_)
                 l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, stream_);
             else
                 l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, stream_);
+            if (bw_nl_ == 2) {
+                HIP_OK(hipEventRecord(ev_l2_, stream_));
+                HIP_OK(hipStreamWaitEvent(s2_, ev_l2_, 0));
+            }
             break;
         }
         in.done++;
@@ -632,6 +693,10 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     if (!reduce_batch_.items.empty()) {
         prof_.layer = "stage";
         wgrad_reduce_flush(reduce_batch_, (wstream_ && overlap_) ? wstream_ : stream_);
+    }
+    if (bw_next_ < 0 && bw_nl_ == 2) {      // the end of backward: lane 1 joins the main stream
+        HIP_OK(hipEventRecord(ev_join_, s2_));
+        HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
     // The returned range is final in the weight-gradient stream's order.  Make it final in
     // main-stream order too unless the caller consumes it on the weight-gradient stream itself

@@ -81,7 +81,8 @@ void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const flo
 // order): 4 bytes per parameter, independent of the forward pass, so the step runs it beside the first layers
 void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t s);
 // d(loss)/d(head outputs) written into L.dbuf (pad columns stay zero).
-void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
+// (lane form like multibox_loss: L.dbuf, result and labels point at sample b_off, B samples)
+void multibox_loss_grad(const HeadLayout& L, int B, int b_off, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s);
 
 // ---- MomentumOptimizer without Nesterov (ssdvgg.py:586-588): acc = m*acc + g; w -= lr*acc

@@ -1058,7 +1058,7 @@ void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const flo
 // [HCH][ld] tile of the gradient buffer in LDS, the few flagged anchors fetch their result / label records and
 // fill their columns, and the tile leaves as one contiguous run of 16-byte stores (pad columns included).
 template <typename T>
-__global__ __launch_bounds__(HTHREADS) void loss_grad_kernel(HeadLayout L, HeadGrid G, int B, const float* __restrict__ result,
+__global__ __launch_bounds__(HTHREADS) void loss_grad_kernel(HeadLayout L, HeadGrid G, int B, int b_off, const float* __restrict__ result,
                                                              const float* __restrict__ labels,
                                                              const unsigned char* __restrict__ pos,
                                                              const unsigned char* __restrict__ sel,
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(HTHREADS) void loss_grad_kernel(HeadLayout L, HeadG
         const size_t idx = (size_t)k.b * L.A + L.off[k.map] + (size_t)j * hw + k.cell0 + cell;
         const bool isel = sel[idx], ipos = pos[idx];
         if (isel || ipos) {
-            const float wb = sample[k.b * 4 + 2];
+            const float wb = sample[(k.b + b_off) * 4 + 2];
             const float* r = result + idx * nv;
             const float* y = labels + idx * nv;
             float* dst = gsm + cell * ld + j * nv;
@@ -1090,18 +1090,19 @@ __global__ __launch_bounds__(HTHREADS) void loss_grad_kernel(HeadLayout L, HeadG
     for (int i = threadIdx.x; i < n4; i += HTHREADS) st4t(out + 4 * i, *reinterpret_cast<const f32x4*>(gsm + 4 * i));
 }
 
-void multibox_loss_grad(const HeadLayout& L, int B, const float* result, const float* labels, const LossWork& w,
+void multibox_loss_grad(const HeadLayout& L, int B, int b_off, const float* result, const float* labels, const LossWork& w,
                         hipStream_t s) {
     const int total = B * L.A;
     const HeadGrid G = head_grid(L, B);
     const size_t lds = (size_t)HCH * (G.ldp_max - 1) * sizeof(float);
+    const size_t o = (size_t)b_off * L.A;
     ProfScope prof("multibox_loss_grad", 0.0, (L.grad_bf16 ? 10.0 : 12.0) * total * L.nvars, s);
     if (L.grad_bf16)
-        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, result, labels, w.pos,
-                           w.sel, w.sample);
+        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, b_off, result, labels,
+                           w.pos + o, w.sel + o, w.sample);
     else
-        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, result, labels, w.pos,
-                           w.sel, w.sample);
+        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), lds, s, L, G, B, b_off, result, labels,
+                           w.pos + o, w.sel + o, w.sample);
     HIP_OK(hipGetLastError());
 }
 
