@@ -135,3 +135,49 @@ def test_end_to_end_gradient_error_is_flips_not_bias():
         assert e_gpu < max(4.0 * e_32, 2e-5), (k, e_gpu, e_32)
     print(f'    worst GPU-vs-f64 gradient rel-L2 {worst_gpu:.3e}; worst ratio to the fp32 oracle\'s own error {worst_ratio:.2f}')
     sess.close()
+
+
+LANE_CHILD = r'''
+import sys, os, json
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+from test_gpu_bench_config import bench_inputs
+from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+dtype, b = sys.argv[1], int(sys.argv[2])
+preset, x, y = bench_inputs('vgg300', b)
+sess = Session(0)
+net = SSDVGG(sess, 'vgg300')
+net.build_from_vgg(None, 20, max_batch=b, seed=42, dtype=dtype)
+net.build_optimizer(learning_rate=0.00075, weight_decay=0.0005, momentum=0.9)
+x_, y_ = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+out = []
+for step in range(2):
+    net.train_step_dev(x_, y_)
+    L = net.get_losses()
+    out.append([L['total'], L['localization'], L['confidence'], L['l2']])
+w = net.save_variables()
+print('LANES ' + json.dumps({'losses': out, 'w': {k: float(np.abs(v.astype(np.float64)).sum()) for k, v in w.items()}}))
+'''
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_step_lane_settings_agree(dtype):
+    """The step schedule's lane switches (net.hip: forward on one or two half-batch lanes, SSD_FWD_LANES; the data-gradient
+    chain likewise, SSD_BWD_LANES) only change WHICH stream runs WHICH samples: two training steps at batch 9 (odd: the
+    lanes get 5 and 4 samples) give the same losses and the same weights in all four settings."""
+    import subprocess, sys
+    got = {}
+    for fwd, bwd in ((1, 1), (2, 1), (1, 2), (2, 2)):
+        env = dict(os.environ, SSD_FWD_LANES=str(fwd), SSD_BWD_LANES=str(bwd))
+        r = subprocess.run([sys.executable, '-c', LANE_CHILD, dtype, '9'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('LANES ')][-1]
+        got[(fwd, bwd)] = json.loads(line[6:])
+    base = got[(1, 1)]
+    tol = 1e-5 if dtype == 'f32' else 2e-3      # half batches may pick another tile / kernel variant: summation order, bf16 roundings
+    for key, g in got.items():
+        for a, c in zip(np.ravel(base['losses']), np.ravel(g['losses'])):
+            assert abs(a - c) <= tol * abs(a), (key, base['losses'], g['losses'])
+        for k in base['w']:
+            assert abs(base['w'][k] - g['w'][k]) <= tol * max(abs(base['w'][k]), 1e-6), (key, k, base['w'][k], g['w'][k])
+        print(f'    lanes fwd={key[0]} bwd={key[1]}: losses {g["losses"][1]}', 'identical' if g == base else 'within tolerance')
