@@ -1688,7 +1688,10 @@ static RowsPlan plan_rows(const ConvDesc& d) {
     p.CT = cdiv(d.Ci, 64 * p.tm);
     p.NT = cdiv(d.Co, 64 * p.tn);
     p.nslots = (long long)d.B * d.Ho * (d.Wo + 2);
-    static const int target = env_int("SSD_WGRAD_ROWS_WGS_BF16", 2048);      // tuning override (conv1_2: 768 workgroups 0.42 ms, >= 1024 0.38 ms)
+    // tuning override.  Re-measured on the round-2 kernels incl. the slab reduce (gpurun r02_m): conv1_2 0.515 / 0.424 / 0.374 /
+    // 0.383 / 0.399 / 0.381 ms and conv2_1 0.207 / 0.203 / 0.202 / 0.217 / 0.240 / 0.247 ms at 512 / 768 / 1024 / 1536 / 2048 /
+    // 3072 workgroups (beyond ~1024 the slabs' write + reduce traffic outgrows the layer's own); step 1024 vs 2048: +0.4 %
+    static const int target = env_int("SSD_WGRAD_ROWS_WGS_BF16", 1024);
     int want = cdiv(target, 3 * p.CT * p.NT);
     if (want > 1024) want = 1024;
     const int maxs = cdiv(p.nslots, 64 * 16);

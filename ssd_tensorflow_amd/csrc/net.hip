@@ -286,8 +286,16 @@ void Net::alloc() {
     loss_ws_ = dalloc(loss_work_bytes(B, A));
     loss_work_carve(lw_, loss_ws_, B, A);
     HIP_OK(hipMemset(loss_ws_, 0, loss_work_bytes(B, A)));
-    HIP_OK(hipHostMalloc((void**)&losses_host_, 4 * sizeof(float)));
+    // The four losses are written by the loss kernel's final block straight into pinned, device-mapped host memory: a
+    // 16-byte device-to-host copy would be a blit kernel of its own on the critical path between the loss and its
+    // gradient (12 us of launch gap + the kernel in the rocprofv3 trace, tools/trace_gaps.py).
+    HIP_OK(hipHostMalloc((void**)&losses_host_, 4 * sizeof(float), hipHostMallocMapped));
     for (int i = 0; i < 4; ++i) losses_host_[i] = 0.f;
+    {
+        void* dp = nullptr;
+        HIP_OK(hipHostGetDevicePointer(&dp, losses_host_, 0));
+        lw_.losses = static_cast<float*>(dp);
+    }
     anchors_dev_ = (double*)dalloc((size_t)A * 4 * sizeof(double));
     anchors_abs_dev_ = (int*)dalloc((size_t)A * 4 * sizeof(int));
     anchors_device(*preset_, anchors_dev_, anchors_abs_dev_, nullptr);
@@ -511,7 +519,6 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
-    if (train_mode) HIP_OK(hipMemcpyAsync(losses_host_, lw_.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
 }
 
 // Backward runs the op list in reverse.  It can be driven in stages so a data-parallel caller can
@@ -562,6 +569,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     const size_t hi = bw_done_off_;
     size_t lo = hi;
     bool side_used = false;
+    bw_lane_[0].s = stream_;      // (a caller may have moved the handle to another stream between two stages)
     // A/B switch, default off: one grouped reduce per ~6 layers measured -0.7 % on the bf16 step, +-0 in fp32 (gpurun
     // r02_h): the per-layer reduces hide behind the next layer's data gradient, a grouped one is long enough to be exposed
     static const bool grouped = [] { const char* v = getenv("SSD_REDUCE_GROUPED"); return v && v[0] == '1'; }();

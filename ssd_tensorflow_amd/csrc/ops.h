@@ -65,7 +65,7 @@ struct LossWork {                    // per-step scratch, all device
     unsigned char* sel;              // [B][A] 1 = contributes to the confidence loss
     float* sample;                   // [B][4]: conf_b, loc_b, weight_b (1/(pos_n*B) or 0), pos_n
     float* partial;                  // [1024] sum-of-squares partials
-    float* losses;                   // [4] total, localization, confidence, l2
+    float* losses;                   // [4] total, localization, confidence, l2 (the executor points this at mapped host memory)
     unsigned* ticket;                // completion ticket of the per-sample workgroups (zero between launches)
 };
 size_t loss_work_bytes(int B, int A);

@@ -806,6 +806,7 @@ __device__ void loss_final_block(int B, float bnorm, const float* sample, const 
     losses[1] = loc;
     losses[2] = conf;
     losses[3] = l2;
+    __threadfence_system();      // the executor's buffer is host memory
 }
 
 template <int PT>

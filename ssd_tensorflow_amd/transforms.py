@@ -198,33 +198,21 @@ class ReorderChannelsTransform(Transform):
 
 
 def transform_box(box, orig_size, new_size, h_off, w_off):
-    """transforms.py:236-259"""
-    xmin, xmax, ymin, ymax = prop2abs(box.center, box.size, orig_size)
-    xmin += w_off
-    xmax += w_off
-    ymin += h_off
-    ymax += h_off
-    width = xmax - xmin
-    height = ymax - ymin
-    new_cx = xmin + int(width / 2)
-    new_cy = ymin + int(height / 2)
-    if new_cx < 0 or new_cx >= new_size.w:
+    """A ground-truth box after the image was shifted by (w_off, h_off) pixels into a canvas of new_size; None when
+    the box's centre pixel leaves the canvas (transforms.py:236-259: integer pixel box, centre = corner + int(extent / 2))."""
+    x0, x1, y0, y1 = prop2abs(box.center, box.size, orig_size)
+    x0, x1, y0, y1 = x0 + w_off, x1 + w_off, y0 + h_off, y1 + h_off
+    centre_x = x0 + int((x1 - x0) / 2)
+    centre_y = y0 + int((y1 - y0) / 2)
+    if not (0 <= centre_x < new_size.w and 0 <= centre_y < new_size.h):
         return None
-    if new_cy < 0 or new_cy >= new_size.h:
-        return None
-    center, size = abs2prop(xmin, xmax, ymin, ymax, new_size)
-    return Box(box.label, box.labelid, center, size)
+    return Box(box.label, box.labelid, *abs2prop(x0, x1, y0, y1, new_size))
 
 
 def transform_gt(gt, new_size, h_off, w_off):
-    """transforms.py:262-270"""
-    boxes = []
-    for box in gt.boxes:
-        box = transform_box(box, gt.imgsize, new_size, h_off, w_off)
-        if box is None:
-            continue
-        boxes.append(box)
-    return Sample(gt.filename, boxes, new_size)
+    """The sample record on the new canvas, boxes whose centre left it dropped (transforms.py:262-270)."""
+    moved = (transform_box(b, gt.imgsize, new_size, h_off, w_off) for b in gt.boxes)
+    return Sample(gt.filename, [b for b in moved if b is not None], new_size)
 
 
 class ExpandTransform(Transform):
@@ -260,43 +248,41 @@ def _jaccard_plus1(box_arr, others):
 
 class SamplerTransform(Transform):
     """Params: sample, min_scale, max_scale, min_aspect_ratio, max_aspect_ratio, min_jaccard_overlap, max_trials
-    (transforms.py:304-359).  Returns None when no window satisfies the overlap constraint."""
+    (transforms.py:304-359).  Returns None when no window satisfies the overlap constraint.
+
+    A trial consumes four uniform draws in the reference's order (scale, aspect ratio, then the window's x and y
+    slack); the window counts when its best IoU (+1 pixel convention, ssdutils.py:139-149) with a ground-truth box is
+    positive and at least min_jaccard_overlap."""
+
+    def _draw_window(self, imgsize):
+        scale = random.uniform(self.min_scale, self.max_scale)
+        ratio = random.uniform(self.min_aspect_ratio, self.max_aspect_ratio)
+        ratio = min(max(ratio, scale ** 2), 1 / (scale ** 2))          # keeps both sides of the window inside the unit square
+        width, height = scale * sqrt(ratio), scale / sqrt(ratio)
+        cx = 0.5 * width + random.uniform(0, 1 - width)
+        cy = 0.5 * height + random.uniform(0, 1 - height)
+        return np.array(prop2abs(Point(cx, cy), Size(width, height), imgsize))
+
     def __call__(self, data, label, gt):
         if not self.sample:
             return data, label, gt
-        source_boxes = np.zeros((len(gt.boxes), 4))
-        for i, b in enumerate(gt.boxes):
-            source_boxes[i] = prop2abs(b.center, b.size, gt.imgsize)
-        box_arr = None
-        found = False
+        gt_px = np.array([prop2abs(b.center, b.size, gt.imgsize) for b in gt.boxes], dtype=np.float64).reshape(-1, 4)
         for _ in range(self.max_trials):
-            scale = random.uniform(self.min_scale, self.max_scale)
-            aspect_ratio = random.uniform(self.min_aspect_ratio, self.max_aspect_ratio)
-            aspect_ratio = max(aspect_ratio, scale ** 2)
-            aspect_ratio = min(aspect_ratio, 1 / (scale ** 2))
-            width = scale * sqrt(aspect_ratio)
-            height = scale / sqrt(aspect_ratio)
-            cx = 0.5 * width + random.uniform(0, 1 - width)
-            cy = 0.5 * height + random.uniform(0, 1 - height)
-            box_arr = np.array(prop2abs(Point(cx, cy), Size(width, height), gt.imgsize))
-            iou = _jaccard_plus1(box_arr, source_boxes)
-            best = int(np.argmax(iou))
-            if iou[best] > 0 and iou[best] >= self.min_jaccard_overlap:      # compute_overlap(.., 0).best and its score
-                found = True
+            window = self._draw_window(gt.imgsize)
+            best = _jaccard_plus1(window, gt_px).max()
+            if best > 0 and best >= self.min_jaccard_overlap:
                 break
-        if not found:
+        else:
             return None
-        new_size = Size(int(box_arr[1] - box_arr[0]), int(box_arr[3] - box_arr[2]))
-        w_off = -int(box_arr[0])
-        h_off = -int(box_arr[2])
+        left, top = int(window[0]), int(window[2])
+        new_size = Size(int(window[1] - window[0]), int(window[3] - window[2]))
         out = _copy_plan(data)
         out._geometric_ok('SamplerTransform')
         if out.flip:
             raise NotImplementedError('the batch kernel crops before it flips')
         x0, y0 = (out.crop[0], out.crop[1]) if out.crop is not None else (0, 0)
-        out.crop = (x0 + int(box_arr[0]), y0 + int(box_arr[2]), new_size.w, new_size.h)
-        gt = transform_gt(gt, new_size, h_off, w_off)
-        return out, label, gt
+        out.crop = (x0 + left, y0 + top, new_size.w, new_size.h)
+        return out, label, transform_gt(gt, new_size, -top, -left)
 
 
 def _copy_plan(p):
