@@ -117,55 +117,92 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolDesc d, const T* _
     }
 }
 
-// 2x2 stride-2 SAME pooling never overlaps and never pads before the image: one thread owns one
-// window (x 4 channels), finds its first maximum and writes all (<= 4) input gradients.
-template <typename T>
+// ---- 2x2 stride-2 SAME pooling: never overlaps and never pads before the image -----------------------------------------
+// One workgroup per output row (b, oh); a thread owns one window x V channels, V = 16 bytes' worth (4 fp32 / 8 bf16).
+// All of a window's loads are issued up front, unconditionally, from clamped coordinates (a cell outside the image re-reads
+// its in-image neighbour and is ignored by the `ok` test afterwards): a predicated load makes the loads wait for each other
+// (s_waitcnt vmcnt(0) after each).  Index math is 32-bit, the row split is per workgroup (scalar).
+template <typename T, int V> struct RawV;
+template <> struct RawV<float, 4> { typedef f32x4 type; };
+template <> struct RawV<bf16_t, 4> { typedef u32x2 type; };
+template <> struct RawV<bf16_t, 8> { typedef u32x4 type; };
+__device__ __forceinline__ void unpack(f32x4 r, float (&f)[4]) { f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3]; }
+__device__ __forceinline__ void unpack(u32x2 r, float (&f)[4]) { f[0] = lo2f(r[0]); f[1] = hi2f(r[0]); f[2] = lo2f(r[1]); f[3] = hi2f(r[1]); }
+__device__ __forceinline__ void unpack(u32x4 r, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = lo2f(r[i]); f[2 * i + 1] = hi2f(r[i]); }
+}
+__device__ __forceinline__ void pack(const float (&f)[4], f32x4& r) { r = f32x4{f[0], f[1], f[2], f[3]}; }
+__device__ __forceinline__ void pack(const float (&f)[4], u32x2& r) { r = u32x2{pack2(f[0], f[1]), pack2(f[2], f[3])}; }
+__device__ __forceinline__ void pack(const float (&f)[8], u32x4& r) {
+    r = u32x4{pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+}
+
+struct PoolRow {      // the output row of this workgroup
+    int b, oh, h0, h1;
+    bool okh;
+    __device__ __forceinline__ PoolRow(const PoolDesc& d) {
+        oh = blockIdx.x % d.Ho; b = blockIdx.x / d.Ho;
+        h0 = oh * 2; okh = h0 + 1 < d.Hi; h1 = okh ? h0 + 1 : h0;
+    }
+};
+
+template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const T* __restrict__ x,
                                                              const T* __restrict__ dy, T* __restrict__ dx,
                                                              int accumulate, int relu_mask) {
-    const int C4 = d.C >> 2;
-    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        size_t pix = idx / C4;
-        const int ow = (int)(pix % d.Wo);
-        pix /= d.Wo;
-        const int oh = (int)(pix % d.Ho);
-        const int b = (int)(pix / d.Ho);
-        const int h0 = oh * 2, w0 = ow * 2;
-        f32x4 v[4];
-        bool ok[4];
+    typedef typename RawV<T, V>::type raw_t;
+    const PoolRow R(d);
+    const unsigned CV = d.C / V, items = d.Wo * CV;
+    const size_t in0 = ((size_t)R.b * d.Hi + R.h0) * d.Wi * d.C, in1 = ((size_t)R.b * d.Hi + R.h1) * d.Wi * d.C;
+    const T* dyr = dy + (size_t)blockIdx.x * d.Wo * d.C;
+    for (unsigned i = threadIdx.x; i < items; i += 256) {
+        const unsigned ow = i / CV, cv = i - ow * CV;
+        const int w0 = ow * 2;
+        const bool okw = w0 + 1 < d.Wi;
+        const int w1 = okw ? w0 + 1 : w0;
+        const size_t o[4] = {in0 + (size_t)w0 * d.C + cv * V, in0 + (size_t)w1 * d.C + cv * V,
+                             in1 + (size_t)w0 * d.C + cv * V, in1 + (size_t)w1 * d.C + cv * V};
+        const bool ok[4] = {true, okw, R.okh, R.okh && okw};
+        raw_t rx[4], ro[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const raw_t*>(x + o[q]);
+        const raw_t rg = *reinterpret_cast<const raw_t*>(dyr + (size_t)i * V);
+        if (accumulate) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ro[q] = *reinterpret_cast<const raw_t*>(dx + o[q]);
+        }
+        float v[4][V], gy[V], g[4][V];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unpack(rx[q], v[q]);
+        unpack(rg, gy);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            ok[q] = h < d.Hi && w < d.Wi;
-            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok[q]) v[q] = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
-        }
-        const f32x4 gy = ld4t(dy + idx * 4);
-        int arg[4];
+            if (accumulate) unpack(ro[q], g[q]);
+            else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < V; ++e) g[q][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
             int a = 0;
             float m = v[0][e];                       // cell 0 is always inside the image
 #pragma unroll
             for (int q = 1; q < 4; ++q)
                 if (ok[q] && v[q][e] > m) { m = v[q][e]; a = q; }   // strict: the first maximum wins
-            arg[e] = a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (a == q) g[q][e] += gy[e];
+                if (relu_mask && !(v[q][e] > 0.f)) g[q][e] = 0.f;   // every component is masked whatever arrives
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (!ok[q]) continue;
-            const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            T* o = dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4;
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            if (accumulate) g = ld4t(o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (arg[e] == q) g[e] += gy[e];
-                if (relu_mask && !(v[q][e] > 0.f)) g[e] = 0.f;
-            }
-            st4t(o, g);
+            raw_t out;
+            pack(g[q], out);
+            *reinterpret_cast<raw_t*>(dx + o[q]) = out;
         }
     }
 }
@@ -174,71 +211,84 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(PoolDesc d, const T
 // first maximum's cell (2 bits) and whether that maximum is positive (1 bit).  Backward then needs neither the
 // input tensor (argmax) nor its sign (relu mask of the producing conv): it reads record + dy and writes dx,
 // 0.58x the bytes of the kernel above.  Valid when the pooled tensor has no other consumer (nothing to accumulate).
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool2x2_fwd_rec_kernel(PoolDesc d, const T* __restrict__ x, T* __restrict__ y,
                                                                  unsigned short* __restrict__ rec) {
-    const int C4 = d.C >> 2;
-    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        size_t pix = idx / C4;
-        const int ow = (int)(pix % d.Wo);
-        pix /= d.Wo;
-        const int oh = (int)(pix % d.Ho);
-        const int b = (int)(pix / d.Ho);
-        const int h0 = oh * 2, w0 = ow * 2;
-        f32x4 v[4];
-        bool ok[4];
+    typedef typename RawV<T, V>::type raw_t;
+    const PoolRow R(d);
+    const unsigned CV = d.C / V, items = d.Wo * CV;
+    const T* x0 = x + ((size_t)R.b * d.Hi + R.h0) * d.Wi * d.C;
+    const T* x1 = x + ((size_t)R.b * d.Hi + R.h1) * d.Wi * d.C;
+    T* yr = y + (size_t)blockIdx.x * d.Wo * d.C;
+    unsigned short* rr = rec + (size_t)blockIdx.x * d.Wo * (d.C / 4);
+    for (unsigned i = threadIdx.x; i < items; i += 256) {
+        const unsigned ow = i / CV, cv = i - ow * CV;
+        const int w0 = ow * 2;
+        const bool okw = w0 + 1 < d.Wi;
+        const int w1 = okw ? w0 + 1 : w0;
+        const bool ok[4] = {true, okw, R.okh, R.okh && okw};
+        raw_t rx[4];
+        rx[0] = *reinterpret_cast<const raw_t*>(x0 + (size_t)w0 * d.C + cv * V);
+        rx[1] = *reinterpret_cast<const raw_t*>(x0 + (size_t)w1 * d.C + cv * V);
+        rx[2] = *reinterpret_cast<const raw_t*>(x1 + (size_t)w0 * d.C + cv * V);
+        rx[3] = *reinterpret_cast<const raw_t*>(x1 + (size_t)w1 * d.C + cv * V);
+        float v[4][V], m[V];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            ok[q] = h < d.Hi && w < d.Wi;
-            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok[q]) v[q] = ld4t(x + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4);
-        }
-        f32x4 m;
-        unsigned r = 0;
+        for (int q = 0; q < 4; ++q) unpack(rx[q], v[q]);
+        unsigned r[V / 4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int gq = 0; gq < V / 4; ++gq) r[gq] = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
             unsigned a = 0;
             float mm = v[0][e];                      // cell 0 is always inside the image
 #pragma unroll
             for (int q = 1; q < 4; ++q)
                 if (ok[q] && v[q][e] > mm) { mm = v[q][e]; a = q; }   // strict: the first maximum wins
             m[e] = mm;
-            r |= (a | (mm > 0.f ? 4u : 0u)) << (3 * e);
+            r[e / 4] |= (a | (mm > 0.f ? 4u : 0u)) << (3 * (e & 3));
         }
-        st4t(y + idx * 4, m);
-        rec[idx] = (unsigned short)r;
+        raw_t out;
+        pack(m, out);
+        *reinterpret_cast<raw_t*>(yr + (size_t)i * V) = out;
+        if constexpr (V == 8) *reinterpret_cast<unsigned*>(rr + (size_t)i * 2) = r[0] | (r[1] << 16);
+        else rr[i] = (unsigned short)r[0];
     }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool2x2_bwd_rec_kernel(PoolDesc d, const unsigned short* __restrict__ rec,
                                                                  const T* __restrict__ dy, T* __restrict__ dx, int relu_mask) {
-    const int C4 = d.C >> 2;
-    const size_t total = (size_t)d.B * d.Ho * d.Wo * C4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        size_t pix = idx / C4;
-        const int ow = (int)(pix % d.Wo);
-        pix /= d.Wo;
-        const int oh = (int)(pix % d.Ho);
-        const int b = (int)(pix / d.Ho);
-        const int h0 = oh * 2, w0 = ow * 2;
-        const unsigned r = rec[idx];
-        const f32x4 gy = ld4t(dy + idx * 4);
+    typedef typename RawV<T, V>::type raw_t;
+    const PoolRow R(d);
+    const unsigned CV = d.C / V, items = d.Wo * CV;
+    T* d0 = dx + ((size_t)R.b * d.Hi + R.h0) * d.Wi * d.C;
+    T* d1 = dx + ((size_t)R.b * d.Hi + R.h1) * d.Wi * d.C;
+    const T* dyr = dy + (size_t)blockIdx.x * d.Wo * d.C;
+    const unsigned short* rr = rec + (size_t)blockIdx.x * d.Wo * (d.C / 4);
+    for (unsigned i = threadIdx.x; i < items; i += 256) {
+        const unsigned ow = i / CV, cv = i - ow * CV;
+        const int w0 = ow * 2;
+        const bool okw = w0 + 1 < d.Wi;
+        unsigned rw;
+        if constexpr (V == 8) rw = *reinterpret_cast<const unsigned*>(rr + (size_t)i * 2);
+        else rw = rr[i];
+        const raw_t rg = *reinterpret_cast<const raw_t*>(dyr + (size_t)i * V);
+        float gy[V];
+        unpack(rg, gy);
+        const bool ok[4] = {true, okw, R.okh, R.okh && okw};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            if (h >= d.Hi || w >= d.Wi) continue;
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (!ok[q]) continue;
+            float g[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned re = (r >> (3 * e)) & 7u;
-                if ((re & 3u) == (unsigned)q && (!relu_mask || (re & 4u))) g[e] = gy[e];
+            for (int e = 0; e < V; ++e) {
+                const unsigned re = (rw >> (16 * (e / 4) + 3 * (e & 3))) & 7u;
+                g[e] = ((re & 3u) == (unsigned)q && (!relu_mask || (re & 4u))) ? gy[e] : 0.f;
             }
-            st4t(dx + (((size_t)b * d.Hi + h) * d.Wi + w) * d.C + c4 * 4, g);
+            raw_t out;
+            pack(g, out);
+            *reinterpret_cast<raw_t*>((q >> 1 ? d1 : d0) + (size_t)(w0 + (q & 1)) * d.C + cv * V) = out;
         }
     }
 }
@@ -274,6 +324,53 @@ __global__ __launch_bounds__(256) void maxpool_argmax_kernel(PoolDesc d, const T
             }
         }
         arg[idx] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+    }
+}
+
+// K x K windows (K = 2, 3) with every tap's load issued before the first comparison: coordinates outside the image are
+// clamped for the address and excluded by `ok` afterwards.  Writes the maxima (y != nullptr) and / or the first
+// maximum's scan-order tap per channel (arg != nullptr: the record pass A of the backward below).  32-bit index math.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void maxpool_taps_kernel(PoolDesc d, const T* __restrict__ x, T* __restrict__ y,
+                                                           unsigned* __restrict__ arg) {
+    typedef typename RawV<T, 4>::type raw_t;
+    const unsigned C4 = d.C >> 2, total = (unsigned)d.B * d.Ho * d.Wo * C4;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        unsigned pix = idx / C4;
+        const unsigned c4 = idx - pix * C4;
+        const int ow = (int)(pix % d.Wo);
+        pix /= d.Wo;
+        const int oh = (int)(pix % d.Ho);
+        const int b = (int)(pix / d.Ho);
+        const int h0 = oh * d.stride - d.pad_h, w0 = ow * d.stride - d.pad_w;
+        raw_t r[K * K];
+        bool ok[K * K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int h = h0 + kh, w = w0 + kw;
+                ok[kh * K + kw] = (unsigned)h < (unsigned)d.Hi && (unsigned)w < (unsigned)d.Wi;
+                const int hc = min(max(h, 0), d.Hi - 1), wc = min(max(w, 0), d.Wi - 1);
+                r[kh * K + kw] = *reinterpret_cast<const raw_t*>(x + (((size_t)b * d.Hi + hc) * d.Wi + wc) * d.C + c4 * 4);
+            }
+        const float ninf = -__builtin_inff();
+        float m[4] = {ninf, ninf, ninf, ninf};
+        unsigned a[4] = {255u, 255u, 255u, 255u};
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            float v[4];
+            unpack(r[t], v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ok[t] && (v[e] > m[e] || a[e] == 255u)) { m[e] = v[e]; a[e] = (unsigned)t; }   // strict: first maximum
+        }
+        if (y) {
+            raw_t out;
+            pack(m, out);
+            *reinterpret_cast<raw_t*>(y + (size_t)idx * 4) = out;
+        }
+        if (arg) arg[idx] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
     }
 }
 
@@ -317,12 +414,77 @@ __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(PoolDesc d, const 
     }
 }
 
+// Pass B for stride 1 (mod_pool5): input cell (h, w) is tap (j, i) of window (h + pad - j, w + pad - i).  The K x K records
+// and gradients are loaded up front from clamped window coordinates, then summed in the order of the kernel above
+// (windows ascending = taps descending).
+template <typename T, int K>
+__global__ __launch_bounds__(256) void maxpool_bwd_arg_s1_kernel(PoolDesc d, const T* __restrict__ x, const unsigned* __restrict__ arg,
+                                                                 const T* __restrict__ dy, T* __restrict__ dx,
+                                                                 int accumulate, int relu_mask) {
+    typedef typename RawV<T, 4>::type raw_t;
+    const unsigned C4 = d.C >> 2, total = (unsigned)d.B * d.Hi * d.Wi * C4;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        unsigned pix = idx / C4;
+        const unsigned c4 = idx - pix * C4;
+        const int w = (int)(pix % d.Wi);
+        pix /= d.Wi;
+        const int h = (int)(pix % d.Hi);
+        const int b = (int)(pix / d.Hi);
+        raw_t rg[K * K], rself, rold;
+        unsigned ra[K * K];
+        bool ok[K * K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int oh = h + d.pad_h - j, ow = w + d.pad_w - i;
+                ok[j * K + i] = (unsigned)oh < (unsigned)d.Ho && (unsigned)ow < (unsigned)d.Wo;
+                const int ohc = min(max(oh, 0), d.Ho - 1), owc = min(max(ow, 0), d.Wo - 1);
+                const size_t o = (((size_t)b * d.Ho + ohc) * d.Wo + owc) * C4 + c4;
+                ra[j * K + i] = arg[o];
+                rg[j * K + i] = *reinterpret_cast<const raw_t*>(dy + o * 4);
+            }
+        if (relu_mask) rself = *reinterpret_cast<const raw_t*>(x + (size_t)idx * 4);
+        if (accumulate) rold = *reinterpret_cast<const raw_t*>(dx + (size_t)idx * 4);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = K * K - 1; t >= 0; --t) {
+            float gy[4];
+            unpack(rg[t], gy);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ok[t] && ((ra[t] >> (8 * e)) & 255u) == (unsigned)t) g[e] += gy[e];
+        }
+        if (accumulate) {
+            float old[4];
+            unpack(rold, old);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += old[e];
+        }
+        if (relu_mask) {
+            float self[4];
+            unpack(rself, self);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = self[e] > 0.f ? g[e] : 0.f;
+        }
+        raw_t out;
+        pack(g, out);
+        *reinterpret_cast<raw_t*>(dx + (size_t)idx * 4) = out;
+    }
+}
+
 template <typename T>
 static void maxpool_fwd_t(const PoolDesc& d, const T* x, T* y, hipStream_t s) {
     SSD_REQUIRE(d.C % 4 == 0, "maxpool: C must be a multiple of 4");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
     ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
-    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
+    const bool small_idx = (double)d.B * d.Hi * d.Wi * d.C < 2.0e9;
+    if (d.k == 3 && small_idx)
+        hipLaunchKernelGGL((maxpool_taps_kernel<T, 3>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y, (unsigned*)nullptr);
+    else if (d.k == 2 && small_idx)
+        hipLaunchKernelGGL((maxpool_taps_kernel<T, 2>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y, (unsigned*)nullptr);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y);
     HIP_OK(hipGetLastError());
 }
 
@@ -334,7 +496,10 @@ static void maxpool_fwd_rec_t(const PoolDesc& d, const T* x, T* y, void* rec, hi
     SSD_REQUIRE(maxpool_rec_applicable(d), "maxpool record: 2x2 stride-2 pooling without leading padding only");
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
     ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo) + 2.0 * total, s);
-    hipLaunchKernelGGL(maxpool2x2_fwd_rec_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y, (unsigned short*)rec);
+    if (sizeof(T) == 2 && d.C % 8 == 0)
+        hipLaunchKernelGGL((maxpool2x2_fwd_rec_kernel<T, sizeof(T) == 2 ? 8 : 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, x, y, (unsigned short*)rec);
+    else
+        hipLaunchKernelGGL((maxpool2x2_fwd_rec_kernel<T, 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, x, y, (unsigned short*)rec);
     HIP_OK(hipGetLastError());
 }
 void maxpool_fwd_rec(const PoolDesc& d, const float* x, float* y, void* rec, hipStream_t s) { maxpool_fwd_rec_t(d, x, y, rec, s); }
@@ -344,8 +509,11 @@ template <typename T>
 static void maxpool_bwd_rec_t(const PoolDesc& d, const void* rec, const T* dy, T* dx, bool relu_mask, hipStream_t s) {
     const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
     ProfScope prof("maxpool_bwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo) + 2.0 * total, s);
-    hipLaunchKernelGGL(maxpool2x2_bwd_rec_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, (const unsigned short*)rec, dy, dx,
-                       (int)relu_mask);
+    if (sizeof(T) == 2 && d.C % 8 == 0)
+        hipLaunchKernelGGL((maxpool2x2_bwd_rec_kernel<T, sizeof(T) == 2 ? 8 : 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, (const unsigned short*)rec, dy,
+                           dx, (int)relu_mask);
+    else
+        hipLaunchKernelGGL((maxpool2x2_bwd_rec_kernel<T, 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, (const unsigned short*)rec, dy, dx, (int)relu_mask);
     HIP_OK(hipGetLastError());
 }
 void maxpool_bwd_rec(const PoolDesc& d, const void* rec, const float* dy, float* dx, bool relu_mask, hipStream_t s) {
@@ -369,17 +537,25 @@ static void maxpool_bwd_t(const PoolDesc& d, const T* x, const T* dy, T* dx, boo
     const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
     ProfScope prof("maxpool_bwd", 0.0, sizeof(T) * (double)d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
     if (d.k == 2 && d.stride == 2 && d.pad_h == 0 && d.pad_w == 0) {
-        const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
-        hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, dy, dx,
-                           (int)accumulate, (int)relu_mask);
+        if (sizeof(T) == 2 && d.C % 8 == 0)
+            hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T, sizeof(T) == 2 ? 8 : 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, x, dy, dx, (int)accumulate,
+                               (int)relu_mask);
+        else
+            hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T, 4>), dim3(d.B * d.Ho), dim3(256), 0, s, d, x, dy, dx, (int)accumulate, (int)relu_mask);
         HIP_OK(hipGetLastError());
         return;
     }
     if (ws) {
         const size_t nwin = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
-        hipLaunchKernelGGL(maxpool_argmax_kernel<T>, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (unsigned*)ws);
-        hipLaunchKernelGGL(maxpool_bwd_arg_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
-                           (const unsigned*)ws, dy, dx, (int)accumulate, (int)relu_mask);
+        if (d.k == 3 && d.stride == 1 && (double)d.B * d.Hi * d.Wi * d.C < 2.0e9) {      // mod_pool5: every load up front
+            hipLaunchKernelGGL((maxpool_taps_kernel<T, 3>), dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (T*)nullptr, (unsigned*)ws);
+            hipLaunchKernelGGL((maxpool_bwd_arg_s1_kernel<T, 3>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
+                               (const unsigned*)ws, dy, dx, (int)accumulate, (int)relu_mask);
+        } else {
+            hipLaunchKernelGGL(maxpool_argmax_kernel<T>, dim3(grid_for(nwin, 256, 256 * 32)), dim3(256), 0, s, d, x, (unsigned*)ws);
+            hipLaunchKernelGGL(maxpool_bwd_arg_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x,
+                               (const unsigned*)ws, dy, dx, (int)accumulate, (int)relu_mask);
+        }
         HIP_OK(hipGetLastError());
         return;
     }
@@ -402,76 +578,118 @@ void maxpool_bwd(const PoolDesc& d, const bf16_t* x, const bf16_t* dy, bf16_t* d
 // =================================================================================
 constexpr int L2_MAXJ = 4;   // C <= 1024
 
+// Four channels as they lie in memory (fp32: 16 bytes, bf16: 8 bytes).  The kernels below load RAW values for all their
+// pixels first (unconditionally, from clamped addresses) and convert / mask them in a second pass: a conversion or a select
+// on a loaded value inside the load group makes every load wait for the one before it (s_waitcnt vmcnt(0) each; the first
+// version of l2norm_bwd ran its 8 loads per iteration as 8 dependent round trips: 80 us for 142 MB).
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16_t> { typedef u32x2 type; };
 template <typename T>
+__device__ __forceinline__ typename Raw4<T>::type ld4raw(const T* p) { return *reinterpret_cast<const typename Raw4<T>::type*>(p); }
+__device__ __forceinline__ f32x4 cvt4(f32x4 r) { return r; }
+__device__ __forceinline__ f32x4 cvt4(u32x2 w) { return f32x4{lo2f(w[0]), hi2f(w[0]), lo2f(w[1]), hi2f(w[1])}; }
+
+template <typename T, int J>      // J = ceil(C / 256) chunks of 4 channels per lane
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(int npix, int C, const T* __restrict__ x,
                                                          const float* __restrict__ scale, T* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int pix = wave; pix < npix; pix += nwaves) {
-        f32x4 v[L2_MAXJ];
-        float ss = 0.f;
+    constexpr int PX = 2;
+    int cc[J];
+    f32x4 sc[J];
 #pragma unroll
-        for (int j = 0; j < L2_MAXJ; ++j) {
-            const int c = lane * 4 + 256 * j;
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < C) v[j] = ld4t(x + (size_t)pix * C + c);
-            ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+    for (int j = 0; j < J; ++j) {
+        const int c = lane * 4 + 256 * j;
+        cc[j] = c < C ? c : 0;
+        sc[j] = ld4(scale + cc[j]);
+    }
+    for (int pix0 = wave * PX; pix0 < npix; pix0 += nwaves * PX) {
+        typename Raw4<T>::type raw[PX][J];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const int pix = min(pix0 + q, npix - 1);
+#pragma unroll
+            for (int j = 0; j < J; ++j) raw[q][j] = ld4raw(x + (size_t)pix * C + cc[j]);
         }
-        ss = wave_sum(ss);
-        const float r = rsqrtf(fmaxf(ss, 1e-12f));
+        f32x4 v[PX][J];
+        float ss[PX];
 #pragma unroll
-        for (int j = 0; j < L2_MAXJ; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (c < C) st4t(y + (size_t)pix * C + c, ld4(scale + c) * v[j] * r);
+        for (int q = 0; q < PX; ++q) {
+            ss[q] = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                v[q][j] = cvt4(raw[q][j]);
+                if (lane * 4 + 256 * j >= C) v[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ss[q] += v[q][j][0] * v[q][j][0] + v[q][j][1] * v[q][j][1] + v[q][j][2] * v[q][j][2] + v[q][j][3] * v[q][j][3];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) ss[q] += __shfl_xor(ss[q], o, 64);
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const int pix = pix0 + q;
+            if (pix >= npix) continue;
+            const float r = rsqrtf(fmaxf(ss[q], 1e-12f));
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (lane * 4 + 256 * j < C) st4t(y + (size_t)pix * C + cc[j], sc[j] * v[q][j] * r);
         }
     }
 }
 
 // dx = scale*dy*r - x * (sum_c scale*dy*x) * r^3  (when sum x^2 > eps; else the norm is the
 // constant sqrt(eps) and only the first term remains).  dscale partials per block -> ws.
-template <typename T>
+template <typename T, int J>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const T* __restrict__ x,
                                                          const float* __restrict__ scale, const T* __restrict__ dy,
                                                          T* __restrict__ dx, float* __restrict__ ws) {
-    __shared__ float red[4][1024];
+    __shared__ float red[4][256 * J];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    constexpr int PX = 2;            // pixels per wave and iteration: their loads and shuffle trees overlap
-    f32x4 ds[L2_MAXJ], sc[L2_MAXJ];
+    constexpr int PX = J <= 2 ? 4 : 2;      // pixels per wave and iteration: 2 PX J loads in flight, their shuffle trees overlap
+    int cc[J];
+    f32x4 ds[J], sc[J];
 #pragma unroll
-    for (int j = 0; j < L2_MAXJ; ++j) {
+    for (int j = 0; j < J; ++j) {
         const int c = lane * 4 + 256 * j;
+        cc[j] = c < C ? c : 0;
         ds[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sc[j] = c < C ? ld4(scale + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sc[j] = ld4(scale + cc[j]);
+        if (c >= C) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int pix0 = wave * PX; pix0 < npix; pix0 += nwaves * PX) {
-        f32x4 v[PX][L2_MAXJ], g[PX][L2_MAXJ];
+        typename Raw4<T>::type rx[PX][J], rg[PX][J];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const int pix = min(pix0 + q, npix - 1);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                rx[q][j] = ld4raw(x + (size_t)pix * C + cc[j]);
+                rg[q][j] = ld4raw(dy + (size_t)pix * C + cc[j]);
+            }
+        }
+        f32x4 v[PX][J], g[PX][J];
         float ss[PX], t[PX];
 #pragma unroll
         for (int q = 0; q < PX; ++q) {
-            const int pix = pix0 + q;
             ss[q] = t[q] = 0.f;
 #pragma unroll
-            for (int j = 0; j < L2_MAXJ; ++j) {
-                const int c = lane * 4 + 256 * j;
-                v[q][j] = g[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (c < C && pix < npix) {
-                    v[q][j] = ld4t(x + (size_t)pix * C + c);
-                    g[q][j] = ld4t(dy + (size_t)pix * C + c);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < PX; ++q)
-#pragma unroll
-            for (int j = 0; j < L2_MAXJ; ++j)
+            for (int j = 0; j < J; ++j) {
+                v[q][j] = cvt4(rx[q][j]);
+                g[q][j] = cvt4(rg[q][j]);
+                if (lane * 4 + 256 * j >= C) v[q][j] = g[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ss[q] += v[q][j][e] * v[q][j][e];
                     t[q] += sc[j][e] * g[q][j][e] * v[q][j][e];
                 }
+            }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
@@ -486,15 +704,14 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
             const float r = rsqrtf(fmaxf(ss[q], 1e-12f));
             const float k = ss[q] > 1e-12f ? t[q] * r * r * r : 0.f;
 #pragma unroll
-            for (int j = 0; j < L2_MAXJ; ++j) {
-                const int c = lane * 4 + 256 * j;
-                if (c < C) st4t(dx + (size_t)pix * C + c, sc[j] * g[q][j] * r - v[q][j] * k);
+            for (int j = 0; j < J; ++j) {
+                if (lane * 4 + 256 * j < C) st4t(dx + (size_t)pix * C + cc[j], sc[j] * g[q][j] * r - v[q][j] * k);
                 ds[j] += g[q][j] * v[q][j] * r;
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < L2_MAXJ; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wib][lane * 4 + 256 * j + e] = ds[j][e];
     __syncthreads();
@@ -502,17 +719,31 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int npix, int C, const 
         ws[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// column sums of ws[nrows][C]: one wave per 64 columns x row-slices, fixed-order tree in LDS
+// column sums of ws[nrows][C] in a fixed order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < C)
-        for (int r = wv; r < nrows; r += 4) s += ws[(size_t)r * C + c];
-    red[wv][lane] = s;
+    // a workgroup = 16 columns x 16 row groups; a thread sums its rows (r = group, group + 16, ...) four independent loads at a
+    // time (the first version walked 128 rows per wave with one dependent load each: 25 us for 1 MB), fixed order throughout
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = rg;
+        for (; r + 48 < nrows; r += 64) {
+            const float a0 = ws[(size_t)r * C + c], a1 = ws[(size_t)(r + 16) * C + c];
+            const float a2 = ws[(size_t)(r + 32) * C + c], a3 = ws[(size_t)(r + 48) * C + c];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; r < nrows; r += 16) s0 += ws[(size_t)r * C + c];
+    }
+    red[rg][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wv == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        out[c] = t;
+    }
 }
 
 static int l2_blocks(int npix) {      // (2048 workgroups were measured: the pixel loop gains nothing, the column sums lose)
@@ -523,10 +754,14 @@ static int l2_blocks(int npix) {      // (2048 workgroups were measured: the pix
 template <typename T>
 static void l2norm_fwd_t(int npix, int C, const T* x, const float* scale, T* y, hipStream_t s) {
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
-    int b = (npix + 3) / 4;
+    int b = (npix + 7) / 8;      // 4 waves x 2 pixels per workgroup and iteration
     if (b > 4096) b = 4096;
     ProfScope prof("l2norm_fwd", 0.0, 2.0 * sizeof(T) * npix * C, s);
-    hipLaunchKernelGGL(l2norm_fwd_kernel<T>, dim3(b), dim3(256), 0, s, npix, C, x, scale, y);
+    switch ((C + 255) / 256) {
+    case 1: hipLaunchKernelGGL((l2norm_fwd_kernel<T, 1>), dim3(b), dim3(256), 0, s, npix, C, x, scale, y); break;
+    case 2: hipLaunchKernelGGL((l2norm_fwd_kernel<T, 2>), dim3(b), dim3(256), 0, s, npix, C, x, scale, y); break;
+    default: hipLaunchKernelGGL((l2norm_fwd_kernel<T, L2_MAXJ>), dim3(b), dim3(256), 0, s, npix, C, x, scale, y); break;
+    }
     HIP_OK(hipGetLastError());
 }
 void l2norm_fwd(int npix, int C, const float* x, const float* scale, float* y, hipStream_t s) { l2norm_fwd_t(npix, C, x, scale, y, s); }
@@ -540,8 +775,12 @@ static void l2norm_bwd_t(int npix, int C, const T* x, const float* scale, const 
     SSD_REQUIRE(C % 4 == 0 && C <= 1024, "l2norm: C must be a multiple of 4 and <= 1024");
     const int nb = l2_blocks(npix);
     ProfScope prof("l2norm_bwd", 0.0, 3.0 * sizeof(T) * npix * C, s);
-    hipLaunchKernelGGL(l2norm_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nb, C, dscale);
+    switch ((C + 255) / 256) {
+    case 1: hipLaunchKernelGGL((l2norm_bwd_kernel<T, 1>), dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws); break;
+    case 2: hipLaunchKernelGGL((l2norm_bwd_kernel<T, 2>), dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws); break;
+    default: hipLaunchKernelGGL((l2norm_bwd_kernel<T, L2_MAXJ>), dim3(nb), dim3(256), 0, s, npix, C, x, scale, dy, dx, ws); break;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(256), 0, s, ws, nb, C, dscale);
     HIP_OK(hipGetLastError());
 }
 void l2norm_bwd(int npix, int C, const float* x, const float* scale, const float* dy, float* dx, float* dscale, float* ws,
