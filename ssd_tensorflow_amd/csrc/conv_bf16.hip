@@ -94,8 +94,45 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (MODE == MODE_FWD && p.bias && ncol) ? p.bias[n + e] : 0.f;
+    constexpr int NPS = BMH / RPP;            // rows of this thread per pass over the C tile
+    // pixel of C-tile row ml in pass h (-1: nothing to write): wave row block ml / (32 TMH), pass h inside the wave's 32 TM rows
+    auto row_offset = [&](int h, int ml, bool& ok) -> size_t {
+        const int tr = HALVES == 1 ? ml : (ml / (32 * TMH)) * (32 * TM) + h * (32 * TMH) + ml % (32 * TMH);
+        const int m = m0 + tr;
+        ok = ncol && tr < rows_valid && m < (PARITY ? om->M : p.M);
+        if (!ok) return 0;
+        size_t pix = (size_t)m;
+        if constexpr (PARITY) {
+            const int c = m % om->DW, t2 = m / om->DW;
+            const int a = t2 % om->DH, b = t2 / om->DH;
+            pix = ((size_t)b * om->ODH + 2 * a + om->ph) * om->ODW + 2 * c + om->pw;
+        }
+        return pix * p.DN + n;
+    };
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
+    // data gradient: the relu mask / old values of this thread's rows are requested BEFORE the accumulators take their trip
+    // through LDS (two barriers), all of them at once: fetched row by row inside the write-out loop, every row waited for
+    // its own round trip (8 per tile: as long as the main loop of a 64- or 128-channel layer)
+    u32x4 pre_mask[NPS], pre_old[NPS];
+    if constexpr (MODE != MODE_FWD) {
+        if (p.mask) {
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                bool ok;
+                const size_t o = row_offset(h, r0 + ps * RPP, ok);      // (row 0 of the tensor when there is nothing to write)
+                pre_mask[ps] = *reinterpret_cast<const u32x4*>(p.mask + o);
+            }
+        }
+        if (p.accum) {
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                bool ok;
+                const size_t o = row_offset(h, r0 + ps * RPP, ok);
+                pre_old[ps] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
+            }
+        }
+    }
     if (h) __syncthreads();                   // the previous pass has been read out
 #pragma unroll
     for (int mi = 0; mi < TMH; ++mi)
@@ -109,23 +146,15 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                 *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
             }
     __syncthreads();
-#pragma unroll 2
-    for (int ps = 0; ps < BMH / RPP; ++ps) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
         const int ml = r0 + ps * RPP;
-        // C-tile row -> tile row: wave row block ml / (32 TMH), pass h inside the wave's 32 TM rows
-        const int tr = HALVES == 1 ? ml : (ml / (32 * TMH)) * (32 * TM) + h * (32 * TMH) + ml % (32 * TMH);
-        const int m = m0 + tr;
-        if (!ncol || tr >= rows_valid || m >= (PARITY ? om->M : p.M)) continue;
-        size_t pix = (size_t)m;
-        if constexpr (PARITY) {
-            const int c = m % om->DW, t2 = m / om->DW;
-            const int a = t2 % om->DH, b = t2 / om->DH;
-            pix = ((size_t)b * om->ODH + 2 * a + om->ph) * om->ODW + 2 * c + om->pw;
-        }
+        bool ok;
+        const size_t o = row_offset(h, ml, ok);
+        if (!ok) continue;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + cg * 8 + 4);
         float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const size_t o = pix * p.DN + n;
         if constexpr (MODE == MODE_FWD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -134,7 +163,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
             }
         } else {
             if (p.accum) {
-                const u32x4 old = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
+                const u32x4 old = pre_old[ps];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] += lo2f(old[e]);
@@ -142,7 +171,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                 }
             }
             if (p.mask) {
-                const u32x4 y = *reinterpret_cast<const u32x4*>(p.mask + o);
+                const u32x4 y = pre_mask[ps];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] = lo2f(y[e]) > 0.f ? v[2 * e] : 0.f;

@@ -319,22 +319,43 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
             if (n >= p.DN) continue;
             float bv = 0.f;
             if constexpr (MODE == MODE_FWD) bv = p.bias ? p.bias[n] : 0.f;
+            // data gradient: the 16 mask values (and old values) of this block are fetched before the first one is used,
+            // from clamped rows -- the plain per-element form made every load wait for the previous element's store
+            // (32 - 64 dependent round trips per tile: as long as the whole main loop of a 64-channel layer)
+            unsigned o[16];                          // element offsets: every tensor is below 2^30 elements (check_desc)
+            bool ok[16];
+            float mk[16], old[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                const size_t o = (size_t)m * p.DN + n;
+                ok[r] = m < p.M;
+                o[r] = (unsigned)(ok[r] ? m : p.M - 1) * (unsigned)p.DN + (unsigned)n;
+            }
+            if constexpr (MODE != MODE_FWD) {
+                if (p.mask) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = p.mask[o[r]];
+                }
+                if (p.accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p.dst[o[r]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[mi][ni][r];
                 if constexpr (MODE == MODE_FWD) {
                     v += bv;
                     if (p.relu) v = v > 0.f ? v : 0.f;
                 } else {
-                    if (p.accum) v += p.dst[o];
-                    if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
+                    if (p.accum) v += old[r];
+                    if (p.mask) v = mk[r] > 0.f ? v : 0.f;
                 }
-                if constexpr (OBF) reinterpret_cast<unsigned short*>(p.dst)[o] = f2bf(v);
-                else p.dst[o] = v;
+                if (!ok[r]) continue;
+                if constexpr (OBF) reinterpret_cast<unsigned short*>(p.dst)[o[r]] = f2bf(v);
+                else p.dst[o[r]] = v;
             }
+            __builtin_amdgcn_sched_barrier(0);      // one block's addresses and values live at a time
         }
     }
 }
@@ -547,27 +568,46 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
             if (n >= p.DN) continue;
             float bv = 0.f;
             if constexpr (MODE == MODE_FWD) bv = p.bias ? p.bias[n] : 0.f;
+            // (data gradient: mask / old values of the block fetched up front from clamped rows, see conv_gather_kernel)
+            unsigned o[16];                          // element offsets: every tensor is below 2^30 elements (check_desc)
+            bool ok[16];
+            float mk[16], old[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= P_M) continue;
-                size_t pix = (size_t)m;
+                int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ok[r] = m < P_M;
+                if (!ok[r]) m = P_M - 1;
+                unsigned pix = (unsigned)m;
                 if (PARITY) {                           // parity class: virtual pixel (b, a, c) -> real pixel
                     const int c = m % P_DW, t2 = m / P_DW;
                     const int a = t2 % P_DH, b = t2 / P_DH;
-                    pix = ((size_t)b * p.ODH + a * p.out_mul + P_out_ph) * p.ODW + c * p.out_mul + P_out_pw;
+                    pix = (unsigned)((b * p.ODH + a * p.out_mul + P_out_ph) * p.ODW + c * p.out_mul + P_out_pw);
                 }
-                const size_t o = pix * p.DN + n;
+                o[r] = pix * (unsigned)p.DN + (unsigned)n;
+            }
+            if constexpr (MODE != MODE_FWD) {
+                if (p.mask) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = p.mask[o[r]];
+                }
+                if (p.accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p.dst[o[r]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[mi][ni][r];
                 if constexpr (MODE == MODE_FWD) {
                     v += bv;
                     if (p.relu) v = v > 0.f ? v : 0.f;
                 } else {
-                    if (p.accum) v += p.dst[o];
-                    if (p.mask) v = p.mask[o] > 0.f ? v : 0.f;
+                    if (p.accum) v += old[r];
+                    if (p.mask) v = mk[r] > 0.f ? v : 0.f;
                 }
-                p.dst[o] = v;
+                if (ok[r]) p.dst[o[r]] = v;
             }
+            __builtin_amdgcn_sched_barrier(0);      // one block's addresses and values live at a time
         }
     }
 }
@@ -958,6 +998,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p) {
 }
 
 // Fixed-order reduce of the split slabs: dw = sum_s slab_s + wd*w ; db = sum_s bias_s.
+// sum_{k = k0, k0 + step, ... < n} ws[k * stride + i .. i + 3], added in that order; the loads of 8 slabs are issued before
+// their first add (the plain loop waited for every slab's load in turn: s_waitcnt vmcnt(0) per iteration)
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ ws, size_t stride, size_t i, int k0, int step, int n) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = k0;
+    for (; k + 7 * step < n; k += 8 * step) {
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = ld4(ws + (size_t)(k + u * step) * stride + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+    }
+    if (k + 3 * step < n) {
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = ld4(ws + (size_t)(k + u * step) * stride + i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += a[u];
+        k += 4 * step;
+    }
+    for (; k < n; k += step) s += ld4(ws + (size_t)k * stride + i);
+    return s;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t wcount,
                                                            int Co, float* __restrict__ dw, float* __restrict__ db,
                                                            const float* __restrict__ w, float wd) {
@@ -965,8 +1029,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t stride = total;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
         // wcount and Co are multiples of 4: a float4 never straddles the weight/bias boundary
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nsplit; ++k) s += ld4(ws + (size_t)k * stride + i);
+        f32x4 s = slab_sum(ws, stride, i, 0, 1, nsplit);
         if (i < wcount) {
             if (wd != 0.f) s += wd * ld4(w + i);
             *reinterpret_cast<f32x4*>(dw + i) = s;
@@ -986,8 +1049,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
     const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const size_t i = ((size_t)blockIdx.x * 16 + e) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (i < total)
-        for (int k = sl; k < nsplit; k += 16) s += ld4(ws + (size_t)k * total + i);
+    if (i < total) s = slab_sum(ws, total, i, sl, 16, nsplit);
     part[sl][e] = s;
     __syncthreads();
     if (sl == 0 && i < total) {
@@ -1332,8 +1394,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(GroupedReduce
     const size_t total = it.wcount + it.Co;
     const size_t idx = ((size_t)(blockIdx.x - g.blk_off[i]) * per + e) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (idx < total)
-        for (int k = sl; k < it.nsplit; k += lanes) s += ld4(it.ws + (size_t)k * total + idx);
+    if (idx < total) s = slab_sum(it.ws, total, idx, sl, lanes, it.nsplit);
     part[sl * per + e] = s;
     __syncthreads();
     if (sl == 0 && idx < total) {
