@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 // straight from the accumulators (4 consecutive channels of one pixel per register quad = one 8-byte store).
 // =================================================================================
 template <int MODE>
-__global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles) {
+__global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks) {
     constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
     constexpr int ZROW = (AROWS - 1) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -604,9 +604,18 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[ni][g][e] = (MODE == MODE_FWD && p.bias) ? p.bias[ni * 32 + 8 * g + 4 * lh + e] : 0.f;
 
-    int tile = blockIdx.x, gunit = 0;
-    if (tile < ntiles) issue(tile, 0, 0);
-    for (; tile < ntiles; tile += gridDim.x) {
+    // Which tiles: workgroup w runs on XCD w % 8.  An input pixel row is fetched three times (once per kernel row, by the
+    // output tiles W pixels before / at / after it = neighbouring tiles): with xcd_chunks the tile range is cut in 8
+    // contiguous chunks, one per XCD, so the three fetches meet in ONE L2 instead of three (plain round robin otherwise).
+    int tile = blockIdx.x, tstep = gridDim.x, tend = ntiles, gunit = 0;
+    if (xcd_chunks) {
+        const int chunk = (ntiles + 7) >> 3, x = blockIdx.x & 7;
+        tile = x * chunk + (blockIdx.x >> 3);
+        tstep = gridDim.x >> 3;
+        tend = min(ntiles, (x + 1) * chunk);
+    }
+    if (tile < tend) issue(tile, 0, 0);
+    for (; tile < tend; tile += tstep) {
         const int m0 = tile * BMV;
         const int rr = wave * 32 + li, m = m0 + rr;
         unsigned fmsk = 0;
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                     }
             }
             if (kr < 2) issue(tile, kr + 1, (gunit + 1) & 1);
-            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0, (gunit + 1) & 1);
+            else if (tile + tstep < tend) issue(tile + tstep, 0, (gunit + 1) & 1);
             const unsigned char* A = smem + A_BASE + (gunit & 1) * A_BYTES;
             int ua[3];
 #pragma unroll
@@ -1530,13 +1539,17 @@ static bool gather_c64_applicable(const ConvDesc& d, bool y_f32) {
 }
 template <int MODE>
 static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s) {
+    // (Measured and not kept, gpurun r02_s: a 7-wave variant with THREE 28-KB activation buffers, two units in flight.
+    // Same time to +-2 % -- the kernel is not waiting for its DMA; like the other bf16 gather kernels its time moves with
+    // the DATA: 0.33 ms on random operands, 0.25 ms on the step's post-relu activations, i.e. with power and clock.)
+    static const int xcd_on = env_int("SSD_C64_XCD", 1);      // A/B switch: XCD-contiguous tile chunks (forward +2..7 %, step +0.3 %)
     constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128;
     auto kern = conv_gather_bf16_c64_kernel<MODE>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int ntiles = cdiv(a.M, 253);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles);
+    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
     HIP_OK(hipGetLastError());
 }
 
