@@ -200,7 +200,7 @@ def test_maxpool(case):
     assert np.abs(host(dx_) - xt.grad.permute(0, 2, 3, 1).numpy()).max() < 1e-6
 
 
-@pytest.mark.parametrize('npix,c', [(2 * 38 * 38, 512), (77, 512), (5, 256)])
+@pytest.mark.parametrize('npix,c', [(2 * 38 * 38, 512), (77, 512), (5, 256), (9, 260), (7, 1000), (130, 1024), (6, 64)])
 def test_l2norm(npix, c):
     rng = np.random.default_rng(2)
     x = np.maximum(rng.normal(0, 1, (npix, c)), 0).astype(np.float32)

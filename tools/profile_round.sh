@@ -22,6 +22,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- \
     python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary $EXTRA \
     > "$O/bench_under_rocprof_overlapped.json" 2>/dev/null
 cp /tmp/pb/b_kernel_stats.csv "$O/rocprofv3_kernel_stats_overlapped.csv"
+# 2b. GPU idle time per step: a trace of overlapped steps only (no per-launch events, no serialized second half)
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pg -o g -- \
+    python "$R/bench.py" --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-kernel-events $EXTRA > /dev/null 2>&1
+python "$R/tools/trace_gaps.py" /tmp/pg/g_kernel_trace.csv > "$O/trace_gaps_overlapped.txt" 2>&1
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pc_$C -o c -- \
