@@ -202,7 +202,7 @@ def bench_augment(args, rank, world, local):
         cpu = dict(value=round(ncpu / (time.perf_counter() - t1), 2), unit='images/s', cores=1, kind='port',
                    sample=f'{ncpu} images through oracle/augment.py (numpy restatement of the recipe; OpenCV is not installed)')
     if rank == 0:
-        print(json.dumps({
+        _OUT.emit(json.dumps({
             'metric': 'images/sec (train augmentation recipe -> %dx%d float32 batch) %s batch%d' % (W, H, args.preset, b),
             'value': round(b * args.steps / dt, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -211,7 +211,7 @@ def bench_augment(args, rank, world, local):
             'roofline': {'bound': 'hbm', 'kernel': 'augment_gather', 'achieved': round(ach, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
                          'frac': round(ach / PEAK_HBM, 4), 'traffic': None, 'avg_launch_us': round(gpu_ms * 1e3, 2), 'bytes_per_launch': bytes_launch,
                          'measured': 'HIP events around %d back-to-back batches (taps + gather launches)' % args.steps},
-            'cpu_baseline': cpu}), flush=True)
+            'cpu_baseline': cpu}))
 
 
 EXPECT_PATH = os.path.join(ROOT, 'tests', 'golden', 'bench_expect.json')
@@ -304,7 +304,7 @@ def run_config(a, rank, world, local):
             return
         if a.mode == 'train':
             # N > 1: bucketed all-reduce (sum over ranks, RCCL over xGMI) overlapped with backward
-            parallel.train_step_dp(net, x, y, world, state['bucket'])
+            parallel.train_step_dp(net, x, y, world, state['bucket'], force_collectives=getattr(a, 'force_collectives', False))
         elif a.mode == 'infer':
             net.infer_dev(x)
         else:
@@ -318,6 +318,8 @@ def run_config(a, rank, world, local):
     if a.no_overlap and a.mode == 'train':
         check(lib.ssd_set_overlap(net._h, 0))
     allreduce_mode = 'none' if world == 1 else ('bucketed, overlapped with backward' if bucket > 0 else 'single, after backward')
+    if world == 1 and getattr(a, 'force_collectives', False):
+        allreduce_mode = ('bucketed, overlapped with backward' if bucket > 0 else 'single, after backward') + ' (single-rank group: the data-parallel plumbing alone)'
     if world > 1 and a.mode == 'train' and bucket > 0:
         # the overlapped path is exercised once up front.  A failure is fatal: a scaling line produced by a
         # silently downgraded collective would read like a measurement of the shipped path.  --allow-fallback
@@ -508,6 +510,25 @@ SECONDARY = [
 ]
 
 
+_OUT = None
+
+
+class _QuietStdout:
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when a
+    communicator is created): while the benchmark runs, file descriptor 1 points at stderr; `emit` restores it for the line."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, text):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        print(text, flush=True)
+        os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -523,6 +544,8 @@ def main():
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='one GPU: run the data-parallel step (staged backward + bucketed all-reduce on a single-rank RCCL group) to price its plumbing')
     ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     ap.add_argument('--allow-fallback', action='store_true', help='N > 1: downgrade a failing bucketed all-reduce to a single one / report diverged replicas instead of aborting')
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
@@ -537,6 +560,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    global _OUT
+    _OUT = _QuietStdout()
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
@@ -544,8 +569,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     _lib.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29533'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
@@ -566,8 +593,8 @@ def main():
             except (Exception, SystemExit) as e:      # noqa: BLE001 -- a secondary block never costs the headline line
                 out[name] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        _OUT.emit(json.dumps(out))
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

@@ -163,6 +163,7 @@ private:
     bool bw_heads_side_ = false;         // head data gradients in flight on the side stream (backward)
     bool overlap_ = true;
     bool own_wstream_ = true;
+    bool h2_is_s2_ = false;                // the second lane's heads run on its main stream (no side stream of its own)
     bool s2_is_w_ = false;                 // the second forward lane's stream IS the weight-gradient stream (four streams in all)
 
     std::vector<Tensor> tensors_;

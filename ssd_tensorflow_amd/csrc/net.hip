@@ -344,7 +344,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     HIP_OK(hipStreamCreateWithFlags(&hstream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_h_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_cast_, hipEventDisableTiming));
-    HIP_OK(hipStreamCreateWithFlags(&h2_, hipStreamNonBlocking));
+
     HIP_OK(hipEventCreateWithFlags(&ev2_h_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev2_dy_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_l2_, hipEventDisableTiming));
@@ -356,18 +356,27 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
         HIP_OK(hipEventCreateWithFlags(&ev_dy_, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&ev_w_, hipEventDisableTiming));
     }
-    // FOUR streams, not five: the hardware runs four queues side by side (ROCm's default GPU_MAX_HW_QUEUES); a fifth
+    // FEW streams: the hardware runs four queues side by side (ROCm's default GPU_MAX_HW_QUEUES); a fifth
     // active stream is time-multiplexed onto one of them, and which two streams then share a queue depends on creation
     // order.  Measured (gpurun r02_v / r02_w, bf16 step): every stream on its own queue (8 queues) 3075 images/s, the
     // default four queues 4016 (and 3850 for a net created after others in the same process), four STREAMS 4080-4120
     // whatever the queue count.  The second forward lane and the weight gradients are never busy at the same time
     // (forward / backward), so they are ONE stream.  (SSD_LANE_STREAM=own restores the fifth stream for the A/B.)
-    static const bool own_lane_stream = [] { const char* v = getenv("SSD_LANE_STREAM"); return v && v[0] == 'o'; }();
-    if (training_ && !own_lane_stream) {
+    // SSD_LANE_STREAM: "own" = five streams (A/B), "heads" = four (the second lane keeps a side stream for its heads),
+    // default = THREE: the second lane runs its heads on its own main stream as well, which measures the same as four
+    // (bf16 4142 vs 4081 images/s, r02_w) and leaves the fourth queue to a data-parallel caller's collective stream.
+    static const char lane_mode = [] { const char* v = getenv("SSD_LANE_STREAM"); return v ? v[0] : 'd'; }();
+    if (training_ && lane_mode != 'o') {
         s2_ = wstream_;
         s2_is_w_ = true;
     } else {
         HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+    }
+    if (lane_mode == 'o' || lane_mode == 'h') {
+        HIP_OK(hipStreamCreateWithFlags(&h2_, hipStreamNonBlocking));
+    } else {
+        h2_ = s2_;
+        h2_is_s2_ = true;
     }
 }
 
@@ -387,7 +396,7 @@ Net::~Net() {
         (void)hipEventDestroy(ev_h_);
         (void)hipEventDestroy(ev_cast_);
         if (!s2_is_w_) (void)hipStreamDestroy(s2_);
-        (void)hipStreamDestroy(h2_);
+        if (!h2_is_s2_) (void)hipStreamDestroy(h2_);
         (void)hipEventDestroy(ev2_h_);
         (void)hipEventDestroy(ev2_dy_);
         (void)hipEventDestroy(ev_l2_);
@@ -744,6 +753,7 @@ void Net::set_wgrad_stream(hipStream_t s) {
     wstream_ = s;
     own_wstream_ = false;
     if (s2_is_w_) s2_ = s;      // the second forward lane lives on the weight-gradient stream
+    if (h2_is_s2_) h2_ = s2_;
 }
 
 void Net::backward(int b, const float* y) {
