@@ -1406,15 +1406,19 @@ __global__ __launch_bounds__(256) void cast_filters_kernel(CastTable t, const fl
     const int tap = b / g.cit;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const size_t base = g.off + (size_t)tap * g.ci * g.co;
+    float v[4];
+    bool ok[4];
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-        const int ci = cit * 32 + r, co = cot * 32 + tx;
-        float v = 0.f;
-        if (ci < g.ci && co < g.co) {
-            v = w[base + (size_t)ci * g.co + co];
-            io[base + (size_t)ci * g.co + co].v = f2bf(v);
-        }
-        tile[r][tx] = v;
+    for (int q = 0; q < 4; ++q) {                      // the four loads first (clamped), then their uses
+        const int ci = cit * 32 + ty + 8 * q, co = cot * 32 + tx;
+        ok[q] = ci < g.ci && co < g.co;
+        v[q] = w[base + (size_t)(ok[q] ? ci : 0) * g.co + (ok[q] ? co : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ci = cit * 32 + ty + 8 * q, co = cot * 32 + tx;
+        if (ok[q]) io[base + (size_t)ci * g.co + co].v = f2bf(v[q]);
+        tile[ty + 8 * q][tx] = ok[q] ? v[q] : 0.f;
     }
     __syncthreads();
 #pragma unroll

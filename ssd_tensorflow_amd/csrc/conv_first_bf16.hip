@@ -57,12 +57,17 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            // (all 8 loads first, from a clamped row: `k < K ? w[..] : 0` made each of the 32 loads of this prologue wait for
+            // the one before -- 25 us per workgroup before its first tile)
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = ks * 16 + 8 * lh + j;
-                v[j] = k < K ? p.w[(size_t)k * p.Co + nt * 32 + li] : 0.f;
+                v[j] = p.w[(size_t)(k < K ? k : K - 1) * p.Co + nt * 32 + li];
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (ks * 16 + 8 * lh + j >= K) v[j] = 0.f;
             wa[nt][ks] = __builtin_bit_cast(bf16x8, pack8(v));
         }
 #pragma unroll
