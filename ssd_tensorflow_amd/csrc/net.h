@@ -151,7 +151,7 @@ private:
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
     hipEvent_t ev_h_ = nullptr, ev_cast_ = nullptr, ev_fmap_[MAX_MAPS] = {};
-    hipStream_t s2_ = nullptr, h2_ = nullptr;   // second forward lane: its main and head streams (net.hip Net::forward)
+    hipStream_t s2_ = nullptr, h2_ = nullptr;   // second forward lane: its main and head streams (by default both = wstream_: net.hip constructor)
     hipEvent_t ev2_h_ = nullptr, ev2_dy_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
     struct BwLane {                             // a lane of the data-gradient chain (net.hip Net::backward_begin)
         hipStream_t s, h;

@@ -417,8 +417,9 @@ Net::~Net() {
 // ---------------------------------------------------------------------------------
 // steps
 // ---------------------------------------------------------------------------------
-// Forward runs the op list on up to two LANES: the batch is cut in two halves that walk the network on two sets of
-// streams, so that the tail of one half's kernel (its last, partial round of workgroups) is filled by the other half's
+// Forward runs the op list on up to two LANES: the batch is cut in two halves that walk the network side by side (lane 0
+// on the caller's stream + the side stream for its heads, lane 1 on s2_ / h2_, which by default are both the
+// weight-gradient stream: see the constructor), so that the tail of one half's kernel (its last, partial round of workgroups) is filled by the other half's
 // kernel instead of idle CUs.  Measured on one box (SSD_FWD_LANES=1 / 2, gpurun r02): training step +0.5 % fp32 and
 // +2.7 % bf16, inference at batch 128 +1.6 %.  Nothing in forward couples the samples except the loss's final
 // reduction, which the last per-sample workgroup of either lane performs (ops.hip).
