@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 // Wave w owns pixel rows 32 w .. 32 w + 31 of the tile x all 64 channels (2 accumulator tiles); the results leave
 // straight from the accumulators (4 consecutive channels of one pixel per register quad = one 8-byte store).
 // =================================================================================
-template <int MODE>
+template <int MODE, bool EPI>
 __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks) {
     constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
     constexpr int ZROW = (AROWS - 1) * 128;
@@ -633,6 +633,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
         // data gradient: the relu mask / the values to accumulate onto are fetched while the last kernel row multiplies
         // (one workgroup per CU: nothing else would hide that round trip)
         u32x2 pre_mask[2][4], pre_old[2][4];
+        u32x4 row_mask[4];
 #pragma unroll
         for (int kr = 0; kr < 3; ++kr, ++gunit) {
             wait_tiles_and_sync<1>(0);                    // this unit's tile (and, the first time, the filter) has landed
@@ -642,9 +643,17 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const size_t o = (size_t)m * 64 + ni * 32 + 8 * g + 4 * lh;
-                        if (p.mask) pre_mask[ni][g] = *reinterpret_cast<const u32x2*>(p.mask + o);
+                        if (!EPI && p.mask) pre_mask[ni][g] = *reinterpret_cast<const u32x2*>(p.mask + o);
                         if (p.accum) pre_old[ni][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
                     }
+            }
+            if (EPI && MODE == MODE_DGRAD && kr == 2 && p.mask) {      // the mask in the write-out layout: whole 128-byte rows
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r2 = wave * 32 + i * 8 + (lane >> 3), m2 = m0 + r2;
+                    const size_t o2 = (size_t)((r2 < BMV && m2 < p.M) ? m2 : 0) * 64 + (lane & 7) * 8;
+                    row_mask[i] = *reinterpret_cast<const u32x4*>(p.mask + o2);
+                }
             }
             if (kr < 2) issue(tile, kr + 1, (gunit + 1) & 1);
             else if (tile + tstep < tend) issue(tile + tstep, 0, (gunit + 1) & 1);
@@ -671,6 +680,48 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             }
         }
         // ---- results: pixel m, channels 32 ni + 8 g + 4 lh + (0..3)
+        if constexpr (EPI) {
+            // Through LDS, so that rows leave (and the mask arrives) as whole 128-byte lines: written straight from the
+            // accumulators every 128-byte line is touched by 8 different 16-byte requests (and as many for the mask).  The
+            // staging area is this wave's 32 rows of the activation buffer the last unit has just consumed; 16-byte chunk c
+            // of row r lives at chunk c ^ sw(r).
+            __syncthreads();                              // the neighbours have read their halo rows of that buffer
+            unsigned char* S = smem + A_BASE + ((gunit - 1) & 1) * A_BYTES + wave * (32 * 128);
+            const int swl = (li ^ (li >> 3)) & 7;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
+                    if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += bv[ni][g][e];
+                            if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                    } else if (p.accum && rr < BMV && m < p.M) {
+                        const u32x2 old = pre_old[ni][g];
+                        v[0] += lo2f(old[0]); v[1] += hi2f(old[0]); v[2] += lo2f(old[1]); v[3] += hi2f(old[1]);
+                    }
+                    *reinterpret_cast<u32x2*>(S + li * 128 + (((4 * ni + g) ^ swl) * 16) + lh * 8) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                }
+            // (wave-private rows: no barrier between this wave's writes and its reads)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3), ch = lane & 7;
+                const int r2 = wave * 32 + row, m2 = m0 + r2;
+                u32x4 v = *reinterpret_cast<const u32x4*>(S + row * 128 + ((ch ^ ((row ^ (row >> 3)) & 7)) * 16));
+                if (MODE == MODE_DGRAD && p.mask) {
+                    const u32x4 y = row_mask[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned lo = lo2f(y[e]) > 0.f ? 0x0000FFFFu : 0u, hi = hi2f(y[e]) > 0.f ? 0xFFFF0000u : 0u;
+                        v[e] &= (lo | hi);
+                    }
+                }
+                if (r2 < BMV && m2 < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m2 * 64 + ch * 8) = v;
+            }
+        } else
         if (rr < BMV && m < p.M) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -1548,12 +1599,20 @@ static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, d
     // the DATA: 0.33 ms on random operands, 0.25 ms on the step's post-relu activations, i.e. with power and clock.)
     static const int xcd_on = env_int("SSD_C64_XCD", 1);      // A/B switch: XCD-contiguous tile chunks (forward +2..7 %, step +0.3 %)
     constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128;
-    auto kern = conv_gather_bf16_c64_kernel<MODE>;
-    static bool once = (set_lds(kern, lds), true);
-    (void)once;
+    static const int epi = env_int("SSD_C64_EPI", 1);         // A/B switch: results leave through LDS as whole 128-byte rows
     const int ntiles = cdiv(a.M, 253);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
+    if (epi) {
+        auto kern = conv_gather_bf16_c64_kernel<MODE, true>;
+        static bool once = (set_lds(kern, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
+    } else {
+        auto kern = conv_gather_bf16_c64_kernel<MODE, false>;
+        static bool once = (set_lds(kern, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
+    }
     HIP_OK(hipGetLastError());
 }
 
