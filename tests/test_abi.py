@@ -66,3 +66,17 @@ def test_mirror_module_surface():
     assert lr.values == [0.1, 0.01] and lr.boundaries == [10]
     with pytest.raises(ValueError):
         ssdvgg.LearningRate([0.1], [10])
+
+
+def test_bench_keeps_stdout_to_one_json_line():
+    """bench.py's contract is ONE JSON line on stdout; libraries print there as well (RCCL's version banner).  While the
+    benchmark runs file descriptor 1 points at stderr, the line itself goes to the real stdout."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; q = bench._QuietStdout(); "
+            "os.write(1, b'library banner\\n'); print('python noise'); q.emit(json.dumps({'value': 1})); os.write(1, b'late noise\\n')") % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'value': 1}, r.stdout
+    assert 'library banner' in r.stderr and 'python noise' in r.stderr and 'late noise' in r.stderr
