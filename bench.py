@@ -138,9 +138,11 @@ def cpu_baseline(preset, seconds_hint=20):
 
 
 def bench_augment(args, rank, world, local):
-    """the train augmentation recipe for one batch, decisions on the host (untimed, they are
-    microseconds per image), pixels on the GPU (timed: the two launches of ssd_augment_batch_dev on plans and
-    source images already resident).  CPU figure beside it: the numpy restatement (oracle/augment.py), one core."""
+    """the GPU half of the train augmentation recipe for one batch: the two launches of
+    ssd_augment_batch_dev on plans and source images already resident.  The host half (the transforms' decisions: a few
+    milliseconds per image in Python, dominated by the sample-picker's trials) is NOT in this number: it is timed where it
+    matters, in the end-to-end block (run_train_e2e), where worker processes run it beside the step.  CPU figure beside
+    it: the numpy restatement (oracle/augment.py), one core."""
     import random
     import ctypes as C2
     import torch
@@ -498,6 +500,68 @@ def run_config(a, rank, world, local):
     return out
 
 
+def run_train_e2e(a, rank, world, local):
+    """The training driver's own loop (ssd_tensorflow_amd/train.py StepLoop = the reference's train.py:254-281) timed end
+    to end on one GPU: the feeder (synthetic uint8 "files" -> the reference's augmentation recipe decided by `workers`
+    forked processes -> upload -> augmentation + label kernels into the device slot ring), the training step, the loss
+    fetch one step late, decode + NMS of every batch and the collection of its detections for the AP bookkeeping.
+    Nothing is resident before the timed region except the dataset's source bytes in host RAM (a real source reads
+    files).  One untimed epoch first (workers fork, anchors / caches warm), then `epochs` timed ones."""
+    import torch
+    from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+    from ssd_tensorflow_amd.training_data import TrainingData
+    from ssd_tensorflow_amd.train import StepLoop
+    from ssd_tensorflow_amd.average_precision import APCalculator
+    from ssd_tensorflow_amd.summaries import LossSummary
+    b = a.batch
+    n_samples = b * a.e2e_steps
+    t0 = time.perf_counter()
+    td = TrainingData(None, a.preset, num_train=n_samples, num_valid=b, augment=True, device=local, seed=1234 + rank)
+    t_data = time.perf_counter() - t0
+    sess = Session(local)
+    net = SSDVGG(sess, a.preset)
+    net.build_from_vgg(None, 20, max_batch=b, training=True, seed=42, dtype=a.dtype)
+    net.build_optimizer(learning_rate=0.00075, weight_decay=0.0005, momentum=0.9)
+    net.set_stream(torch.cuda.current_stream().cuda_stream)
+    res = {}
+    try:
+        for label, workers, epochs in (('prefetched', a.e2e_workers, a.e2e_epochs), ('serial', 0, 1)):
+            if label == 'serial' and a.e2e_serial_steps <= 0:
+                continue
+            loop = StepLoop(net, sess, td, b, workers)
+            calc = APCalculator(); summ = LossSummary(None, 'training', n_samples)
+            td.epoch = 0
+            if label == 'prefetched':
+                loop.run_epoch(td.train_generator, True, summ, calc, True)          # untimed: forks the workers, warms everything
+            else:
+                td.num_train = b * a.e2e_serial_steps                                 # the serial feeder is slow: fewer steps
+                td._recipes['train'].total = td.num_train
+            calc.clear()
+            torch.cuda.synchronize()
+            steps0 = loop.steps
+            t0 = time.perf_counter()
+            for e in range(epochs):
+                td.epoch = 1 + e
+                loop.run_epoch(td.train_generator, True, summ, calc, True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            steps = loop.steps - steps0
+            res[label] = dict(value=round(steps * b / dt, 2), ms_per_step=round(dt / steps * 1e3, 4), steps=steps, epochs=epochs, workers=workers,
+                              losses_last_epoch=summ.push(0), detections_collected=len(calc.det_confidence))
+    finally:
+        td.close(); sess.close()
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    r = res['prefetched']
+    return {'metric': 'images/sec end to end (feeder + augmentation + fwd+bwd + loss fetch + decode/NMS collection) %s batch%d' % (a.preset, b),
+            'value': r['value'], 'unit': 'images/s', 'ms_per_step': r['ms_per_step'], 'steps': r['steps'], 'epochs': r['epochs'], 'dtype': a.dtype,
+            'feeder_workers': r['workers'], 'host_cores': os.cpu_count(), 'dataset_build_s': round(t_data, 2),
+            'serial_feeder': res.get('serial'), 'losses_last_epoch': r['losses_last_epoch'], 'detections_collected': r['detections_collected'],
+            'config': {'workload': f"{a.preset} train.py StepLoop, {b} images/step, {n_samples} synthetic uint8 images of 200..640 px through the reference's "
+                                   'train recipe (process_dataset.py:66-140), --num-workers %d' % r['workers']}}
+
+
 # configurations BASELINE.json names beside the headline; timed by the default invocation with a few steps each so
 # that they are driver-run numbers (the headline `value` stays configs[1])
 SECONDARY = [
@@ -536,7 +600,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--preset', default='vgg300')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment', 'train_e2e'])
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -551,6 +615,11 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
+    ap.add_argument('--e2e-workers', type=int, default=0, help='train_e2e: feeder worker processes (0 = min(24, host cores / 4))')
+    ap.add_argument('--e2e-steps', type=int, default=0, help='train_e2e: steps per epoch (0 = 20 fp32 / 60 bf16)')
+    ap.add_argument('--e2e-epochs', type=int, default=1, help='train_e2e: timed epochs')
+    ap.add_argument('--e2e-serial-steps', type=int, default=3, help='train_e2e: steps of the serial-feeder comparison (0 = skip)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end blocks of the default invocation')
     args = ap.parse_args()
 
     import torch
@@ -580,6 +649,19 @@ def main():
 
     if args.mode == 'augment':
         return bench_augment(args, rank, world, local)
+
+    def e2e(dtype):
+        sub = argparse.Namespace(**vars(args))
+        sub.dtype = dtype
+        sub.e2e_workers = args.e2e_workers or min(24, max(2, (os.cpu_count() or 8) // 4))
+        sub.e2e_steps = args.e2e_steps or (60 if dtype == 'bf16' else 20)
+        return run_train_e2e(sub, rank, world, local)
+
+    if args.mode == 'train_e2e':
+        r = e2e(args.dtype)
+        if rank == 0:
+            _OUT.emit(json.dumps(r))
+        return
     out = run_config(args, rank, world, local)
     headline = (args.mode, args.preset, args.batch, args.dtype) == ('train', 'vgg300', 32, 'f32')
     if headline and world == 1 and not args.no_secondary and not args.zero_input and not args.per_layer:
@@ -592,6 +674,17 @@ def main():
                              if k in r}
             except (Exception, SystemExit) as e:      # noqa: BLE001 -- a secondary block never costs the headline line
                 out[name] = {'error': f'{type(e).__name__}: {e}'}
+        if not args.no_e2e:
+            # the driver loop end to end, beside the resident-input numbers above (same process, same box)
+            for name, dtype, resident in (('train_e2e', 'f32', out), ('train_e2e_bf16', 'bf16', out.get('bf16'))):
+                try:
+                    r = e2e(dtype)
+                    if resident and 'value' in resident:
+                        r['resident_input_value'] = resident['value']
+                        r['vs_resident_input'] = round(r['value'] / resident['value'], 4)
+                    out[name] = r
+                except (Exception, SystemExit) as e:      # noqa: BLE001
+                    out[name] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
         _OUT.emit(json.dumps(out))
     if world > 1 or args.force_collectives:

@@ -80,6 +80,7 @@ SIGNATURES = {
     'ssd_forward_dev': (i32, [handle, vp, vp, i32]),
     'ssd_backward_begin_dev': (i32, [handle, vp, i32]),
     'ssd_backward_next_dev': (i32, [handle, sz, i32, C.POINTER(sz), C.POINTER(sz), p_i32]),
+    'ssd_backward_ranges': (i32, [handle, sz, C.POINTER(sz), C.POINTER(sz), i32, p_i32]),
     'ssd_set_wgrad_stream': (i32, [handle, vp]),
     'ssd_set_loss_normalizer': (i32, [handle, f32]),
     'ssd_null_gradients_dev': (i32, [handle]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     'ssd_result_dev': (i32, [handle, C.POINTER(vp)]),
     'ssd_get_result': (i32, [handle, i32, vp]),
     'ssd_get_losses': (i32, [handle, vp]),
+    'ssd_get_losses_step': (i32, [handle, i32, vp]),
     'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -63,6 +63,20 @@ class APCalculator:
                                         np_ptr(gk), np_ptr(gs), ncls, float(self.minoverlap), np_ptr(ap), np_ptr(present)))
         return {label: float(ap[k]) for label, k in label_id.items() if present[k]}
 
+    def state(self):
+        """Everything add_detections has collected, as plain lists (picklable: one rank's share of a data-parallel run)."""
+        return dict(det_params=self.det_params, det_confidence=self.det_confidence, det_labels=self.det_labels,
+                    det_sample_ids=self.det_sample_ids, gt_boxes=self.gt_boxes)
+
+    def merge(self, state):
+        """Append another calculator's state(); its sample ids are shifted behind the samples already held."""
+        base = len(self.gt_boxes)
+        self.gt_boxes.extend(state['gt_boxes'])
+        self.det_params.extend(state['det_params'])
+        self.det_confidence.extend(state['det_confidence'])
+        self.det_labels.extend(state['det_labels'])
+        self.det_sample_ids.extend(i + base for i in state['det_sample_ids'])
+
     def clear(self):
         self.det_params = []
         self.det_confidence = []

@@ -483,6 +483,17 @@ int ssd_backward_next_dev(ssd_handle h, size_t min_floats, int sync_main, size_t
     *more = n.backward_step(min_floats, offset, count, sync_main != 0) ? 1 : 0;
     API_END
 }
+int ssd_backward_ranges(ssd_handle h, size_t min_floats, size_t* offsets, size_t* counts, int cap, int* n_out) {
+    API_BEGIN_NET(h)
+    SSD_REQUIRE(n_out != nullptr, "null argument");
+    const auto r = n.backward_ranges(min_floats);
+    *n_out = (int)r.size();
+    for (int i = 0; i < (int)r.size() && i < cap; ++i) {
+        if (offsets) offsets[i] = r[i].first;
+        if (counts) counts[i] = r[i].second;
+    }
+    API_END
+}
 int ssd_set_wgrad_stream(ssd_handle h, void* stream) {
     API_BEGIN_NET(h)
     n.set_wgrad_stream((hipStream_t)stream);
@@ -540,6 +551,12 @@ int ssd_get_result(ssd_handle h, int b, float* result_out) {
 int ssd_get_losses(ssd_handle h, float losses_out[4]) {
     API_BEGIN_NET(h)
     n.get_losses(losses_out);
+    API_END
+}
+int ssd_get_losses_step(ssd_handle h, int steps_back, float losses_out[4]) {
+    API_BEGIN_NET(h)
+    SSD_REQUIRE(losses_out != nullptr, "null argument");
+    n.get_losses_step(steps_back, losses_out);
     API_END
 }
 int ssd_arenas(ssd_handle h, float** params_dev, float** grads_dev, float** momentum_dev, size_t* floats,

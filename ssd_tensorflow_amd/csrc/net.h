@@ -85,6 +85,9 @@ public:
     void backward_begin(int b, const float* y);
     // runs reverse ops until >= min_floats of filter gradients are newly final; [off, off+count) is that range
     bool backward_step(size_t min_floats, size_t* off, size_t* count, bool sync_main);
+    // the (offset, count) ranges backward_step(min_floats, ...) reports, in order, without running anything: a rank whose
+    // shard is empty issues the collectives of the ranks that do run backward (parallel.train_step_dp)
+    std::vector<std::pair<size_t, size_t>> backward_ranges(size_t min_floats) const;
     void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
     void backward_apply(int b, const float* y, float grad_scale);      // backward + update, the optimizer overlapped with backward's tail
@@ -97,7 +100,10 @@ public:
     const float* x_stage() const { return x_stage_; }
     const float* y_stage() const { return y_stage_; }
 
-    void get_losses(float out[4]);
+    void get_losses(float out[4]);                       // the last step's; waits for everything on the stream
+    // the losses of the last step (steps_back = 0) or of one of the LOSS_RING - 1 steps before it: waits for THAT step's
+    // forward only, so a caller can book step k - 1 while step k runs (train.py)
+    void get_losses_step(int steps_back, float out[4]);
     void copy_result(float* out, int b);
     void set_result(const float* pred_dev, int b);
 
@@ -185,7 +191,12 @@ private:
     void* pool_ws_ = nullptr;
     void* loss_ws_ = nullptr;
     LossWork lw_{};
-    float* losses_host_ = nullptr;        // pinned
+    static constexpr int LOSS_RING = 4;
+    float* losses_host_ = nullptr;        // pinned, device-mapped: LOSS_RING slots of 4 floats, slot = loss_seq_ % LOSS_RING
+    float* losses_dev_ = nullptr;         // the device's view of the same memory
+    hipEvent_t ev_loss_[LOSS_RING] = {};  // recorded behind the forward pass that wrote the slot
+    long long loss_seq_ = -1;             // forward passes with a loss so far - 1
+    float* begin_loss_slot();             // next slot: waits until its previous use (LOSS_RING passes ago) has finished
     double* anchors_dev_ = nullptr;
     int* anchors_abs_dev_ = nullptr;
     void* detect_ws_ = nullptr;

@@ -289,13 +289,16 @@ void Net::alloc() {
     // The four losses are written by the loss kernel's final block straight into pinned, device-mapped host memory: a
     // 16-byte device-to-host copy would be a blit kernel of its own on the critical path between the loss and its
     // gradient (12 us of launch gap + the kernel in the rocprofv3 trace, tools/trace_gaps.py).
-    HIP_OK(hipHostMalloc((void**)&losses_host_, 4 * sizeof(float), hipHostMallocMapped));
-    for (int i = 0; i < 4; ++i) losses_host_[i] = 0.f;
+    // A ring of LOSS_RING such slots (one per forward pass) lets the host read step k - 1's losses while step k runs.
+    HIP_OK(hipHostMalloc((void**)&losses_host_, LOSS_RING * 4 * sizeof(float), hipHostMallocMapped));
+    for (int i = 0; i < LOSS_RING * 4; ++i) losses_host_[i] = 0.f;
     {
         void* dp = nullptr;
         HIP_OK(hipHostGetDevicePointer(&dp, losses_host_, 0));
-        lw_.losses = static_cast<float*>(dp);
+        losses_dev_ = static_cast<float*>(dp);
+        lw_.losses = losses_dev_;
     }
+    for (int i = 0; i < LOSS_RING; ++i) HIP_OK(hipEventCreateWithFlags(&ev_loss_[i], hipEventDisableTiming));
     anchors_dev_ = (double*)dalloc((size_t)A * 4 * sizeof(double));
     anchors_abs_dev_ = (int*)dalloc((size_t)A * 4 * sizeof(int));
     anchors_device(*preset_, anchors_dev_, anchors_abs_dev_, nullptr);
@@ -411,6 +414,8 @@ Net::~Net() {
     }
     for (void* p : allocs_) (void)hipFree(p);
     if (losses_host_) (void)hipHostFree(losses_host_);
+    for (int i = 0; i < LOSS_RING; ++i)
+        if (ev_loss_[i]) (void)hipEventDestroy(ev_loss_[i]);
     if (prev_dev != device_) (void)hipSetDevice(prev_dev);
 }
 
@@ -460,6 +465,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         }
     }
     if (train_mode) {
+        begin_loss_slot();
         // the l2 term reads every filter once (105 MB): on the side stream beside the first (matrix-bound) layers
         prof_.layer = "loss";
         l2_partials(params_, nfilters_, lw_, side ? hstream_ : stream_);
@@ -521,6 +527,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
     prof_.layer = "loss";
     const int A = preset_->num_anchors, nv = C_ + 5;
+    // The lanes' loss launches share a self-resetting completion ticket (ops.hip): if a launch fails after another
+    // lane's has been enqueued, the count never reaches the step's total and the ticket would stay non-zero for the life
+    // of the handle -- drain the device and clear it before the error leaves.
+    try {
     for (int li = 0; li < nl; ++li) {
         Lane& ln = lane[li];
         if (ln.heads_on_side) {
@@ -537,10 +547,18 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             heads_result(hl, ln.nb, res, ln.s);
         }
     }
+    } catch (...) {
+        if (train_mode && lw_.ticket) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(lw_.ticket, 0, sizeof(unsigned));
+        }
+        throw;
+    }
     if (nl == 2) {
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
+    if (train_mode) HIP_OK(hipEventRecord(ev_loss_[loss_seq_ % LOSS_RING], stream_));
 }
 
 // Backward runs the op list in reverse.  It can be driven in stages so a data-parallel caller can
@@ -748,6 +766,22 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     return bw_next_ >= 0;
 }
 
+std::vector<std::pair<size_t, size_t>> Net::backward_ranges(size_t min_floats) const {
+    std::vector<std::pair<size_t, size_t>> out;
+    size_t hi = nfilters_;
+    int next = (int)ops_.size() - 1;
+    while (next >= 0) {
+        size_t lo = hi;
+        while (next >= 0 && hi - lo < min_floats) {
+            const Op& op = ops_[next--];
+            if (op.kind == OP_CONV) lo = op.w_off;      // conv ops own descending, adjacent filter ranges (backward_step)
+        }
+        if (hi > lo) out.emplace_back(lo, hi - lo);
+        hi = lo;
+    }
+    return out;
+}
+
 void Net::set_wgrad_stream(hipStream_t s) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     if (own_wstream_ && wstream_) (void)hipStreamDestroy(wstream_);
@@ -815,7 +849,11 @@ void Net::backward_apply(int b, const float* y, float grad_scale) {
 void Net::null_gradients_step() {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     null_gradients(params_, grads_, nfilters_, nparams_, wd_, stream_);
-    for (int i = 0; i < 4; ++i) losses_host_[i] = 0.f;
+    // a step without samples has no loss kernel: its slot of the ring is written here, after the slot's previous user
+    // (LOSS_RING passes ago) has finished -- no kernel in flight writes to it
+    float* slot = begin_loss_slot();
+    for (int i = 0; i < 4; ++i) slot[i] = 0.f;
+    HIP_OK(hipEventRecord(ev_loss_[loss_seq_ % LOSS_RING], stream_));
 }
 
 void Net::set_optimizer(const float* lr_values, const long long* bounds, int n, float momentum, float wd) {
@@ -836,9 +874,26 @@ void Net::upload_xy(const float* x, const float* y, int b) {
     }
 }
 
+float* Net::begin_loss_slot() {
+    ++loss_seq_;
+    const int slot = (int)(loss_seq_ % LOSS_RING);
+    if (loss_seq_ >= LOSS_RING) HIP_OK(hipEventSynchronize(ev_loss_[slot]));      // its previous pass (long finished)
+    lw_.losses = losses_dev_ + 4 * slot;
+    return losses_host_ + 4 * slot;
+}
+
 void Net::get_losses(float out[4]) {
     HIP_OK(hipStreamSynchronize(stream_));
-    for (int i = 0; i < 4; ++i) out[i] = losses_host_[i];
+    const int slot = loss_seq_ < 0 ? 0 : (int)(loss_seq_ % LOSS_RING);
+    for (int i = 0; i < 4; ++i) out[i] = losses_host_[4 * slot + i];
+}
+
+void Net::get_losses_step(int steps_back, float out[4]) {
+    SSD_REQUIRE(steps_back >= 0 && steps_back < LOSS_RING - 1, "steps_back must be in 0..%d", LOSS_RING - 2);
+    SSD_REQUIRE(loss_seq_ - steps_back >= 0, "no step with a loss has run %d step(s) back", steps_back);
+    const int slot = (int)((loss_seq_ - steps_back) % LOSS_RING);
+    HIP_OK(hipEventSynchronize(ev_loss_[slot]));
+    for (int i = 0; i < 4; ++i) out[i] = losses_host_[4 * slot + i];
 }
 
 void Net::set_result(const float* pred_dev, int b) {

@@ -112,26 +112,32 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
         return
     if global_count is not None:
         net.set_loss_normalizer(global_count / world)
-    # every rank must issue the same collectives: a global batch with fewer samples than ranks leaves some
-    # shards empty, and those ranks have no staged backward -- that step uses ONE all-reduce everywhere
-    some_empty = global_count is not None and global_count < world
-    if b == 0 and not some_empty:
-        raise ValueError('empty shard, but global_count does not say that shards may be empty')
+    # Every rank must issue the same collectives whatever its shard holds.  The sequence is a function of
+    # bucket_floats alone: the ranges backward reports in stages are fixed by the layer sizes (ssd_backward_ranges), so
+    # a rank with an empty shard (a short last batch with fewer samples than ranks -- or a feeder that disagrees with
+    # the other ranks', which then shows up as wrong losses instead of a hang) reduces the same ranges of its
+    # weight-decay-only gradient arena.
     try:
-        if b == 0:
-            net.null_gradients_dev()
-            dist.all_reduce(net.grads_flat)
-        elif bucket_floats <= 0 or some_empty:
-            net.forward_backward_dev(x_dev, y_dev)
+        if bucket_floats <= 0:
+            if b == 0:
+                net.null_gradients_dev()
+            else:
+                net.forward_backward_dev(x_dev, y_dev)
             dist.all_reduce(net.grads_flat)
         else:
             # Collectives are enqueued behind the weight-gradient stream only: the data gradients on the
             # current stream keep running ahead of them.  The last stage joins the two streams, after which
             # the bias / scale tail is reduced and the current stream waits for everything.
             side = net.use_torch_wgrad_stream()
-            net.forward_dev(x_dev, y_dev)
+            if b == 0:
+                net.null_gradients_dev()
+                side.wait_stream(torch.cuda.current_stream(side.device))
+                ranges = net.backward_ranges(bucket_floats)
+            else:
+                net.forward_dev(x_dev, y_dev)
+                ranges = net.backward_staged(y_dev, b, bucket_floats, sync_main=False)
             works = []
-            for off, cnt in net.backward_staged(y_dev, b, bucket_floats, sync_main=False):
+            for off, cnt in ranges:
                 with torch.cuda.stream(side):
                     works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True))
             works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True))

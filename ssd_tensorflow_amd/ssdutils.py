@@ -243,18 +243,27 @@ def non_maximum_suppression(boxes, overlap_threshold):
 _ANCHORS_ABS = {}
 
 
+def prime_anchor_table(preset, table=None):
+    """The integer anchor table (xmin, xmax, ymin, ymax on the 1000-pixel grid, ssdutils.py:120-130) of the redraw
+    test, computed once per process by the anchor kernel.  The feeder calls this before it forks its workers: they
+    inherit the table and never call the GPU.  `table` installs a given [A, 4] array instead (CPU tests)."""
+    key = preset.name
+    if table is not None:
+        _ANCHORS_ABS[key] = np.ascontiguousarray(table, np.float64).reshape(preset.num_anchors, 4)
+    if key not in _ANCHORS_ABS:
+        out = np.empty((preset.num_anchors, 4), np.int32)
+        check(lib.ssd_anchors_abs(_pname(preset), _lib.device(), np_ptr(out)))
+        _ANCHORS_ABS[key] = out.astype(np.float64)
+    return _ANCHORS_ABS[key]
+
+
 def has_positive_anchor(preset, boxes):
     """Would LabelCreatorTransform mark at least one anchor positive for these Box records?  That is the only
     thing the reference's redraw loop looks at (training_data.py:92-95: num_bg < rows), and an anchor turns
     positive iff its IoU (+1 pixel, 1000-pixel grid) with some box exceeds 0.5 (transforms.py:76-107,
     ssdutils.py:152-169).  A handful of boxes against the cached integer anchor table, on the host."""
     from .utils import prop2abs, Size
-    key = preset.name
-    if key not in _ANCHORS_ABS:
-        out = np.empty((preset.num_anchors, 4), np.int32)
-        check(lib.ssd_anchors_abs(_pname(preset), _lib.device(), np_ptr(out)))
-        _ANCHORS_ABS[key] = out.astype(np.float64)
-    an = _ANCHORS_ABS[key]
+    an = prime_anchor_table(preset)
     area_a = (an[:, 1] - an[:, 0] + 1) * (an[:, 3] - an[:, 2] + 1)
     grid = Size(1000, 1000)
     for b in boxes:

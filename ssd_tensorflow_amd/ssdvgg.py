@@ -166,6 +166,7 @@ class SSDVGG:
         self.labels = None
         self.losses = None
         self.optimizer = None
+        self.eval_op = None
 
     def _tok(self, name):
         t = _Token(name)
@@ -196,6 +197,7 @@ class SSDVGG:
             check(lib.ssd_set_global_step(self._h, int(global_step)))
         self.labels = self._tok('labels:0')
         self.optimizer = self._tok('optimizer/optimizer')
+        self.eval_op = self._tok('total_loss/loss:0 (deferred)')      # forward + loss without the update; read with get_losses_step
         self.losses = {k: self._tok(n) for k, n in zip(
             LOSS_NAMES, ('total_loss/loss:0', 'localization_loss/localization_loss:0',
                          'confidence_loss/confidence_loss:0', 'total_loss/l2_loss:0'))}
@@ -318,22 +320,23 @@ class SSDVGG:
         check(lib.ssd_get_result(self._h, b, np_ptr(res)))
         return res
 
-    def train_step(self, x, y, want_result=True):
+    def train_step(self, x, y, want_result=True, want_losses=True):
         if self._is_cuda(x):
             x, y = self._dev_xy(x, y)
             self.train_step_dev(x, y)
-            return self._dev_result(x.shape[0], want_result), self.get_losses()
+            # neither fetch: nothing waits for the step (the driver reads the losses one step late, get_losses_step)
+            return self._dev_result(x.shape[0], want_result), (self.get_losses() if want_losses else None)
         x = self._check_x(x); y = self._check_y(y, x.shape[0])
         res = np.empty(y.shape, np.float32) if want_result else None
         L = np.zeros(4, np.float32)
         check(lib.ssd_train_step(self._h, np_ptr(x), np_ptr(y), x.shape[0], np_ptr(res), np_ptr(L)))
         return res, dict(zip(LOSS_NAMES, (float(v) for v in L)))
 
-    def eval_step(self, x, y, want_result=True):
+    def eval_step(self, x, y, want_result=True, want_losses=True):
         if self._is_cuda(x):
             x, y = self._dev_xy(x, y)
             self.eval_step_dev(x, y)
-            return self._dev_result(x.shape[0], want_result), self.get_losses()
+            return self._dev_result(x.shape[0], want_result), (self.get_losses() if want_losses else None)
         x = self._check_x(x); y = self._check_y(y, x.shape[0])
         res = np.empty(y.shape, np.float32) if want_result else None
         L = np.zeros(4, np.float32)
@@ -382,6 +385,13 @@ class SSDVGG:
             if cnt.value:
                 yield off.value, cnt.value
 
+    def backward_ranges(self, min_floats):
+        """[(offset, count)] exactly as backward_staged(..., min_floats) yields them, without running backward."""
+        cap = 128
+        offs = (C.c_size_t * cap)(); cnts = (C.c_size_t * cap)(); n = C.c_int()
+        check(lib.ssd_backward_ranges(self._h, int(min_floats), offs, cnts, cap, C.byref(n)))
+        return [(offs[i], cnts[i]) for i in range(min(n.value, cap))]
+
     def set_loss_normalizer(self, batch):
         """reduce_mean over `batch` samples instead of the step's own b (<= 0 restores the default): data
         parallel shards of unequal size pass global_samples / world (parallel.train_step_dp)."""
@@ -406,6 +416,13 @@ class SSDVGG:
     def get_losses(self):
         L = np.zeros(4, np.float32)
         check(lib.ssd_get_losses(self._h, np_ptr(L)))
+        return dict(zip(LOSS_NAMES, (float(v) for v in L)))
+
+    def get_losses_step(self, steps_back=0):
+        """The losses of the last step (0) or of the step 1 / 2 before it, waiting only for THAT step's forward pass
+        (ssd_get_losses_step): a driver books step k - 1 after launching step k instead of stalling on every step."""
+        L = np.zeros(4, np.float32)
+        check(lib.ssd_get_losses_step(self._h, int(steps_back), np_ptr(L)))
         return dict(zip(LOSS_NAMES, (float(v) for v in L)))
 
     def set_stream(self, stream_ptr):
@@ -442,14 +459,15 @@ class SSDVGG:
         want_opt = any(f is self.optimizer for f in fetches if self.optimizer is not None)
         want_loss = any(isinstance(f, dict) or (self.losses and f in self.losses.values()) for f in fetches)
         want_res = any(f is self.result for f in fetches)      # the [b, A, C+5] copy to the host only when fetched
+        want_eval = any(f is self.eval_op for f in fetches if getattr(self, 'eval_op', None) is not None)
         if want_opt:
             if y is None:
                 raise ValueError('feed_dict must hold net.labels')
-            res, L = self.train_step(x, y, want_res)
-        elif want_loss:
+            res, L = self.train_step(x, y, want_res, want_loss)
+        elif want_loss or want_eval:
             if y is None:
                 raise ValueError('feed_dict must hold net.labels')
-            res, L = self.eval_step(x, y, want_res)
+            res, L = self.eval_step(x, y, want_res, want_loss)
         else:
             res, L = self.infer(x), None
         out = []
@@ -459,6 +477,8 @@ class SSDVGG:
             elif isinstance(f, dict):
                 out.append({k: L[k] for k in f})
             elif self.optimizer is not None and f is self.optimizer:
+                out.append(None)
+            elif getattr(self, 'eval_op', None) is not None and f is self.eval_op:
                 out.append(None)
             elif self.losses and f in self.losses.values():
                 out.append(L[[k for k, v in self.losses.items() if v is f][0]])

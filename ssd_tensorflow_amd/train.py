@@ -32,6 +32,80 @@ def compute_lr(lr_values, lr_boundaries):
     return LearningRate(lr_values, lr_boundaries)
 
 
+class StepLoop:
+    """The body of the reference's epoch loops (train.py:254-281 training, 286-306 validation) over the HIP library,
+    shared by main() below and by bench.py's end-to-end block.  The host never waits for the step it has just launched:
+    the losses of step k are read after step k + 1 is in flight (ssd_get_losses_step), the detections of step k are
+    collected after step k + 1's decode has been launched, and with num_workers > 0 batch k + 1 is already in HBM
+    (training_data.py)."""
+
+    def __init__(self, net, sess, td, batch_size, num_workers=0, world=1, rank=0, bucket=0):
+        self.net, self.sess, self.td = net, sess, td
+        self.batch_size, self.num_workers = batch_size, num_workers
+        self.world, self.rank, self.bucket = world, rank, bucket
+        self.steps = 0
+
+    def booked(self, loss_batch, count):
+        """(values, weight) for LossSummary.add.  One GPU: the batch's losses, weighted by its samples
+        (train.py:271).  Data parallel: a rank's data terms are normalised by count / world, so summed over ranks
+        with weight count / world they are count x the global-batch value; the l2 term is the same number on every
+        rank that ran a step and absent on a rank whose shard was empty, so rank 0 (never empty) books it, once."""
+        world = self.world
+        if world <= 1:
+            return loss_batch, count
+        data = loss_batch['localization'] + loss_batch['confidence']
+        l2 = loss_batch['l2'] * world if self.rank == 0 else 0.0
+        return dict(total=data + l2, localization=loss_batch['localization'], confidence=loss_batch['confidence'], l2=l2), count / world
+
+    def book(self, loss_batch, count, loss_summary):
+        if math.isnan(loss_batch['confidence']):
+            print('[!] Confidence loss is NaN.')                                     # train.py:268-269
+        if loss_summary is not None:
+            loss_summary.add(*self.booked(loss_batch, count))
+
+    def collect(self, dets, gt_boxes, calc):
+        if dets is None:
+            return
+        for gt, det in zip(gt_boxes, dets.get()):
+            calc.add_detections(gt, boxes_from_detection(det, self.td.lid2name))
+
+    def run_epoch(self, generator, train, loss_summary, ap_calc, with_ap):
+        net, sess, td, world = self.net, self.sess, self.td, self.world
+        pending_det = None
+        pending_loss = None                     # sample count of the launched step whose losses are not booked yet
+        for x, y, gt_boxes in generator(self.batch_size, self.num_workers):
+            n = len(gt_boxes)
+            count = td.global_count if world > 1 else n
+            ran = True
+            if train and world > 1:
+                parallel.train_step_dp(net, x, y, world, self.bucket, td.global_count)       # an empty shard still steps
+            elif n == 0:
+                ran = False
+            elif train:
+                sess.run(net.optimizer, feed_dict={net.image_input: x, net.labels: y})
+            else:
+                if world > 1:
+                    net.set_loss_normalizer(td.global_count / world)
+                sess.run(net.eval_op, feed_dict={net.image_input: x, net.labels: y})
+                if world > 1:
+                    net.set_loss_normalizer(0.0)
+            self.steps += int(ran)
+            if pending_loss is not None:
+                self.book(net.get_losses_step(1 if ran else 0), pending_loss, loss_summary)
+            pending_loss = count if ran else None
+            if not with_ap or n == 0:
+                continue
+            # decode + NMS of the batch just computed, on the GPU (train.py:275-277)
+            launched = net.detect_last_launch(n, 0.5, 200, None)
+            if pending_det:
+                self.collect(pending_det[0], pending_det[1], ap_calc)
+            pending_det = (launched, gt_boxes)
+        if pending_loss is not None:
+            self.book(net.get_losses_step(0), pending_loss, loss_summary)
+        if pending_det:
+            self.collect(pending_det[0], pending_det[1], ap_calc)
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser(description='Train the SSD')
     parser.add_argument('--name', default='test', help='project name')
@@ -142,58 +216,27 @@ def main(argv=None):
         training_loss = LossSummary(writer, 'training', td.num_train)
         validation_loss = LossSummary(writer, 'validation', td.num_valid)
 
-        def collect(dets, gt_boxes, calc):
-            if dets is None:
-                return
-            for gt, det in zip(gt_boxes, dets.get()):
-                calc.add_detections(gt, boxes_from_detection(det, td.lid2name))
+        loop = StepLoop(net, sess, td, args.batch_size, args.num_workers, world, rank, bucket)
+
+        def gathered_aps(calc):
+            """{label: AP} over the WHOLE sample (train.py:317-323): data parallel, every rank's detections and ground
+            truth are gathered to rank 0, which computes; the other ranks get {}."""
+            if world <= 1:
+                return calc.compute_aps()
+            states = [None] * world if rank == 0 else None
+            torch.distributed.gather_object(calc.state(), states, dst=0)
+            if rank != 0:
+                return {}
+            merged = APCalculator(calc.minoverlap)
+            for st in states:
+                merged.merge(st)
+            return merged.compute_aps()
 
         say('[i] Training...')
         for e in range(start_epoch, args.epochs):
             td.epoch = e
-            # ---- train (train.py:254-281) --------------------------------------------------------
-            pending = None
-            for x, y, gt_boxes in td.train_generator(args.batch_size, args.num_workers):
-                n = len(gt_boxes)
-                if world > 1:
-                    parallel.train_step_dp(net, x, y, world, bucket, td.global_count)
-                    # this rank's losses are normalised by global_count / world: their sum over ranks is world x the
-                    # global-batch loss, so each rank books its share of the batch's samples
-                    loss_batch, weight = net.get_losses(), td.global_count / world
-                else:
-                    loss_batch, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
-                    weight = n
-                if math.isnan(loss_batch['confidence']):
-                    print('[!] Confidence loss is NaN.')
-                training_loss.add(loss_batch, weight)
-                if e == 0 or n == 0:
-                    continue
-                # decode + NMS of the batch just computed, on the GPU (train.py:275-277); the detections of batch k
-                # are collected after batch k+1 has been launched
-                launched = net.detect_last_launch(n, 0.5, 200, None)
-                collect(pending[0], pending[1], training_ap_calc) if pending else None
-                pending = (launched, gt_boxes)
-            if pending:
-                collect(pending[0], pending[1], training_ap_calc)
-            # ---- validate (train.py:286-306) ---------------------------------------------------
-            pending = None
-            for x, y, gt_boxes in td.valid_generator(args.batch_size, args.num_workers):
-                n = len(gt_boxes)
-                if n == 0:
-                    continue
-                if world > 1:
-                    net.set_loss_normalizer(td.global_count / world)
-                loss_batch = sess.run(net.losses, feed_dict={net.image_input: x, net.labels: y})
-                if world > 1:
-                    net.set_loss_normalizer(0.0)
-                validation_loss.add(loss_batch, td.global_count / world if world > 1 else n)
-                if e == 0:
-                    continue
-                launched = net.detect_last_launch(n, 0.5, 200, None)
-                collect(pending[0], pending[1], validation_ap_calc) if pending else None
-                pending = (launched, gt_boxes)
-            if pending:
-                collect(pending[0], pending[1], validation_ap_calc)
+            loop.run_epoch(td.train_generator, True, training_loss, training_ap_calc, e > 0)
+            loop.run_epoch(td.valid_generator, False, validation_loss, validation_ap_calc, e > 0)
             # ---- summaries (train.py:311-331) -----------------------------------------------------
             tl = training_loss.push(e + 1, rank_sum)
             vl = validation_loss.push(e + 1, rank_sum)
@@ -201,10 +244,10 @@ def main(argv=None):
                 e + 1, args.epochs, tl['total'], tl['localization'], tl['confidence'], tl['l2']))
             say('[i] Valid {:>2}/{}  total {:.4f}  localization {:.4f}  confidence {:.4f}  l2 {:.4f}'.format(
                 e + 1, args.epochs, vl['total'], vl['localization'], vl['confidence'], vl['l2']))
-            # mAP of this rank's shard (VOC07 11-point, on the GPU); rank 0's is reported
-            APs = training_ap_calc.compute_aps(); mAP = APs2mAP(APs)
+            # VOC07 11-point AP on the GPU, over all ranks' samples
+            APs = gathered_aps(training_ap_calc); mAP = APs2mAP(APs)
             training_ap.push(e + 1, mAP, APs)
-            vAPs = validation_ap_calc.compute_aps(); vmAP = APs2mAP(vAPs)
+            vAPs = gathered_aps(validation_ap_calc); vmAP = APs2mAP(vAPs)
             validation_ap.push(e + 1, vmAP, vAPs)
             if e > 0:
                 say('[i] mAP  {:>2}/{}  training {:.4f}  validation {:.4f}'.format(e + 1, args.epochs, mAP, vmAP))
@@ -222,6 +265,7 @@ def main(argv=None):
             print('[i] Checkpoint saved:', path)
         if writer is not None:
             writer.close()
+        td.close()
         if os.environ.get('SSD_PRINT_CHECKSUM'):      # replica agreement check of the multi-rank tests
             print('[checksum] rank %d step %d params %.12e' % (rank, net.global_step, float(net.params_flat.double().sum())), flush=True)
     if world > 1:

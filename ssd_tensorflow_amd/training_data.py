@@ -1,13 +1,30 @@
 """Batch feeder for the step loop: the counterpart of the reference's TrainingData /
 DataQueue (training_data.py:35-206, data_queue.py:26-112) for the path this build covers.
 
-The reference forks N workers that run cv2 transforms and copy batches through shared-memory
-slots to ONE device.  Here every rank feeds only its own shard (parallel.ShardSampler) and a batch is
-born in HBM: the images come out of the batch augmentation kernels (transforms.augment_batch: the
-reference's transform recipe, decisions on the host, pixels on the GPU), the label vectors out of the
+The reference forks N workers that run cv2 transforms and copy finished float32 batches through
+shared-memory slots to ONE device.  Here every rank feeds only its own shard (parallel.ShardSampler) and
+a batch is born in HBM: the images come out of the batch augmentation kernels (transforms.augment_batch:
+the reference's transform recipe, decisions on the host, pixels on the GPU), the label vectors out of the
 HIP label encoder (ssd_encode_labels_dev) -- only the images' source bytes and a handful of boxes go up,
 nothing of a batch ever comes down.  A generator yields `(images, labels, gt_boxes)` like the
 reference's, with `images` / `labels` float32 CUDA tensors (device_tensors=False: numpy arrays).
+
+`gen_batch(batch_size, num_workers)` means what the reference's means (training_data.py:137-195):
+
+  * num_workers == 0: the serial generator -- batch k+1 is prepared when the caller asks for it;
+  * num_workers  > 0: that many forked worker processes run the host half of the recipe (file decode, the
+    transforms' decisions incl. the <= 50 redraws, packing) into the slots of a data_queue.DataQueue,
+    while a feeder thread of the training process uploads finished slots IN ORDER and launches the
+    augmentation + label kernels on its own stream into a ring of three device slots.  Batch k+1 is
+    therefore ready in HBM while step k runs; the consumer's stream waits for the slot's event, and a
+    slot is rewritten only after the kernels the consumer enqueued on it have run.  A yielded batch is
+    valid until the next one is requested.
+
+The two are bit-identical: every sample's decisions are drawn from Python's `random` seeded with
+(seed, data set, epoch, sample index), so a batch does not depend on which process prepared it or on what
+was drawn before (tests/test_feeder_cpu.py, tests/test_gpu_feeder.py).  The reference's workers all start
+from the parent's `random` state and its batches arrive in completion order: an epoch there is not
+reproducible; that is not mirrored.
 
 Sources:
   * data_dir None / '' / 'synthetic'  -- SURVEY.md 8d: float32 preset-sized images (augment=False) or a
@@ -20,14 +37,160 @@ Sources:
     (transforms.build_train_transforms / build_valid_transforms) are built in process.  Images are
     decoded by transforms.load_image_bgr (.npy arrays or Pillow; decoder parity with OpenCV unpinned).
 """
+import multiprocessing as mp
+import os
+import queue
+import random
+import threading
+import traceback
+
 import numpy as np
 
+from .data_queue import DataQueue, WorkerError
 from .parallel import ShardSampler
-from .ssdutils import encode_labels_batch, encode_labels_batch_dev, get_preset_by_name, has_positive_anchor
+from .ssdutils import (encode_labels_batch, encode_labels_batch_dev, get_preset_by_name, has_positive_anchor,
+                       prime_anchor_table)
 from .utils import Box, Point, Size, Sample, load_data_source
 
 VOC_NAMES = ['aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow', 'diningtable', 'dog',
              'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train', 'tvmonitor']
+
+DEVICE_SLOTS = 3            # one under the step, one ready, one being filled
+CACHE_SYNTHETIC_UP_TO = 4096  # synthetic "files" kept in RAM (a real source reads its files instead)
+
+
+def _gt_arrays(gts):
+    bxs = [np.array([[b.center.x, b.center.y, b.size.w, b.size.h] for b in g], np.float64).reshape(-1, 4) for g in gts]
+    cls = [np.array([b.labelid for b in g], np.int32) for g in gts]
+    return bxs, cls
+
+
+class _Recipe:
+    """One data set of a TrainingData (train or valid): where its samples come from and how a list of sample
+    indices becomes the host half of a batch.  Lives in the parent and, by fork, in the workers."""
+
+    def __init__(self, td, which, total, salt, sample_at=None, transforms=None):
+        self.td, self.which, self.total, self.salt = td, which, total, salt
+        self.sample_at, self.transforms = sample_at, transforms
+        self.pool = None
+        self.active = False
+
+    # ---- host half of a batch: runs in a worker process or, for num_workers == 0, in the caller --------------------
+    def plan(self, epoch, idx):
+        td = self.td
+        if self.transforms is None:                              # preset-sized float32 synthetic images
+            imgs, gts = [], []
+            for i in idx:
+                # redrawn (<= 50 times) until at least one anchor is positive (training_data.py:92-98)
+                for tries in range(50):
+                    img, gt = td._sample(int(i) + 7919 * tries, self.salt)
+                    if has_positive_anchor(td.preset, gt):
+                        break
+                imgs.append(img); gts.append(gt)
+            return {'images': np.stack(imgs)}, gts
+        from . import transforms as T
+        host_tfs = [t for t in self.transforms if not isinstance(t, T.LabelCreatorTransform)]
+        loader = host_tfs[0]
+        preset_images = getattr(loader, 'images', None)
+        plans, gts = [], []
+        try:
+            for i in idx:
+                s = self.sample_at(int(i))
+                if not isinstance(s, Sample):                    # synthetic: the pixels travel with the record
+                    loader.images, sample = s
+                else:
+                    loader.images, sample = preset_images, s
+                random.seed(td._sample_seed(self.salt, epoch, int(i)))
+                # run_transforms until at least one anchor is positive, at most 50 times (training_data.py:88-98);
+                # the label of a try is only LOOKED at there (num_bg < rows), so the test runs on the host and the
+                # label vectors of the whole batch are encoded once, on the GPU
+                for _ in range(50):
+                    args = (None, None, sample)
+                    for t in host_tfs:
+                        args = t(*args)
+                    if has_positive_anchor(td.preset, args[2].boxes):
+                        break
+                plans.append(args[0]); gts.append(args[2].boxes)
+        finally:
+            loader.images = preset_images
+        arr, packed = T.plan_params(plans, td.preset.image_size.w, td.preset.image_size.h)
+        return {'params': np.frombuffer(arr, np.uint8).copy(), 'packed': packed}, gts
+
+    def slot_bytes(self, batch_size):
+        td = self.td
+        W, H = td.preset.image_size.w, td.preset.image_size.h
+        if self.transforms is None:
+            return batch_size * H * W * 3 * 4 + 4096
+        return batch_size * (td._max_image_bytes + 16 + 256) + 4096
+
+
+def _worker_main(recipe, tasks, results):
+    """batch_producer of the reference (training_data.py:109-134).  The workers never touch the GPU: the HIP
+    runtime they inherited by fork is not called (the anchor table of the redraw test is primed before the fork)."""
+    try:
+        import signal
+        signal.signal(signal.SIGINT, signal.SIG_IGN)
+    except Exception:
+        pass
+    while True:
+        task = tasks.get()
+        if task is None:
+            break
+        gen, seq, slot, epoch, idx = task
+        try:
+            arrays, gts = recipe.plan(epoch, idx)
+            results.put((gen, seq), slot, arrays, gts)
+        except BaseException:
+            results.put_error((gen, seq), slot, traceback.format_exc())
+
+
+class _WorkerPool:
+    def __init__(self, recipe, num_workers, slot_bytes):
+        ctx = mp.get_context('fork')
+        self.num_workers, self.slot_bytes = num_workers, slot_bytes
+        self.nslots = num_workers + 2
+        self.tasks = ctx.Queue()
+        self.results = DataQueue(slot_bytes, self.nslots, ctx)
+        self.free_slots = list(range(self.nslots))
+        self.outstanding = {}                 # (gen, seq) -> slot of tasks whose result has not been seen
+        self.generation = 0
+        self.pinned = []
+        self.workers = []
+        for _ in range(num_workers):
+            w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results), daemon=True)
+            w.start()
+            self.workers.append(w)
+
+    def pin(self, device):
+        """Page-lock the slots so the uploads are asynchronous DMA transfers (a refusal is harmless: the copies are
+        then staged by the runtime)."""
+        import torch
+        if self.pinned or not torch.cuda.is_available():
+            return
+        rt = torch.cuda.cudart()
+        for a in self.results.array_pool:
+            try:
+                rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+                self.pinned.append(int(rc) == 0)
+            except Exception:
+                self.pinned.append(False)
+
+    def check_alive(self):
+        for w in self.workers:
+            if not w.is_alive():
+                raise RuntimeError('a feeder worker process died (exit code %s)' % (w.exitcode,))
+
+    def close(self):
+        for _ in self.workers:
+            try:
+                self.tasks.put(None)
+            except Exception:
+                pass
+        for w in self.workers:
+            w.join(timeout=2)
+            if w.is_alive():
+                w.terminate()
+        self.workers = []
 
 
 class TrainingData:
@@ -44,6 +207,9 @@ class TrainingData:
         self.epoch = 0
         self.device, self.device_tensors = device, bool(device_tensors)
         self.global_count = 0
+        self._dev = None                       # device-side slot ring, feeder stream (created on first use)
+        self._upload_hook = None               # tests: replaces the GPU half of a batch
+        self._synthetic_cache = {}
         from . import transforms as T
         if data_dir not in (None, '', 'synthetic'):
             # ---- a real dataset directory (training_data.py:41-69 + process_dataset.py:199-252) ----
@@ -60,42 +226,67 @@ class TrainingData:
             self.augment = True
             self.train_transforms = T.build_train_transforms(self.preset, self.num_classes, sampler_trials, expand_prob, images)
             self.valid_transforms = T.build_valid_transforms(self.preset, self.num_classes, images)
-            self.train_generator = self._augmented_generator(lambda i: self.train_samples[i], self.num_train, 0, self.train_transforms)
-            self.valid_generator = self._augmented_generator(lambda i: self.valid_samples[i], self.num_valid, 1 << 20, self.valid_transforms)
-            return
-        self.num_classes = 20
-        self.label_colors = {}
-        self.lid2name = dict(enumerate(VOC_NAMES))
-        self.lname2id = {n: i for i, n in self.lid2name.items()}
-        self.num_train, self.num_valid = num_train, num_valid
-        self.augment = bool(augment)
-        if self.augment:
-            self.train_transforms = T.build_train_transforms(self.preset, self.num_classes, sampler_trials, expand_prob)
-            self.valid_transforms = T.build_valid_transforms(self.preset, self.num_classes)
-            self.train_generator = self._augmented_generator(lambda i: self._dataset_sample(i, 0), num_train, 0, self.train_transforms)
-            self.valid_generator = self._augmented_generator(lambda i: self._dataset_sample(i, 1 << 20), num_valid, 1 << 20,
-                                                             self.valid_transforms)
-            self.train_samples = [self._dataset_sample(i, 0)[1] for i in range(num_train)]
-            self.valid_samples = [self._dataset_sample(i, 1 << 20)[1] for i in range(num_valid)]
-            return
-        self.train_generator = self._generator(num_train, 0)
-        self.valid_generator = self._generator(num_valid, 1 << 20)
-        self.train_samples = self.valid_samples = None
+            self._max_image_bytes = max([s.imgsize.w * s.imgsize.h * 3 for s in self.train_samples + self.valid_samples] + [1])
+            self._recipes = {
+                'train': _Recipe(self, 'train', self.num_train, 0, lambda i: self.train_samples[i], self.train_transforms),
+                'valid': _Recipe(self, 'valid', self.num_valid, 1 << 20, lambda i: self.valid_samples[i], self.valid_transforms)}
+        else:
+            self.num_classes = 20
+            self.label_colors = {}
+            self.lid2name = dict(enumerate(VOC_NAMES))
+            self.lname2id = {n: i for i, n in self.lid2name.items()}
+            self.num_train, self.num_valid = num_train, num_valid
+            self.augment = bool(augment)
+            if self.augment:
+                self.train_transforms = T.build_train_transforms(self.preset, self.num_classes, sampler_trials, expand_prob)
+                self.valid_transforms = T.build_valid_transforms(self.preset, self.num_classes)
+                self.train_samples = [self._dataset_sample(i, 0)[1] for i in range(num_train)]
+                self.valid_samples = [self._dataset_sample(i, 1 << 20)[1] for i in range(num_valid)]
+                self._max_image_bytes = 640 * 640 * 3
+                self._recipes = {
+                    'train': _Recipe(self, 'train', num_train, 0, lambda i: self._dataset_sample(i, 0), self.train_transforms),
+                    'valid': _Recipe(self, 'valid', num_valid, 1 << 20, lambda i: self._dataset_sample(i, 1 << 20), self.valid_transforms)}
+            else:
+                self.train_samples = self.valid_samples = None
+                self._recipes = {'train': _Recipe(self, 'train', num_train, 0), 'valid': _Recipe(self, 'valid', num_valid, 1 << 20)}
+        self.train_generator = self._make_generator(self._recipes['train'])
+        self.valid_generator = self._make_generator(self._recipes['valid'])
+
+    # ---- lifetime of the worker processes ----------------------------------------------------------------------
+    def close(self):
+        for r in self._recipes.values():
+            if r.pool is not None:
+                r.pool.close()
+                r.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _sample_seed(self, salt, epoch, index):
+        """The seed of sample #index's decisions in `epoch` of data set `salt`: one integer whose 32-bit words all
+        enter random.seed's init_by_array."""
+        return ((int(self.seed) & 0xffffffff) << 96) | (int(salt) << 64) | (int(epoch) << 32) | int(index)
 
     # ---- labels: encoded once per batch on the GPU, left there ---------------------------------------------------
-    def _labels(self, gts):
-        bxs = [np.array([[b.center.x, b.center.y, b.size.w, b.size.h] for b in g], np.float64).reshape(-1, 4) for g in gts]
-        cls = [np.array([b.labelid for b in g], np.int32) for g in gts]
+    def _labels(self, gts, out=None):
+        bxs, cls = _gt_arrays(gts)
         if self.device_tensors:
-            return encode_labels_batch_dev(self.preset, self.num_classes, bxs, cls, self.device)
+            return encode_labels_batch_dev(self.preset, self.num_classes, bxs, cls, self.device, out=out)
         return encode_labels_batch(self.preset, self.num_classes, bxs, cls)
 
     # ---- a dataset of variously sized uint8 images through the reference's transform recipe ---------------------
     def _dataset_sample(self, index, salt):
         """Deterministic synthetic "file" #index: ({name: uint8 BGR image}, Sample record with 1..5 boxes)."""
+        key = (salt, index)
+        hit = self._synthetic_cache.get(key)
+        if hit is not None:
+            return hit
         rng = np.random.default_rng([self.seed, salt, index, 77])
         W, H = int(rng.integers(200, 640)), int(rng.integers(200, 640))
-        img = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         n = int(rng.integers(1, 6))
         w = rng.uniform(0.1, 0.6, n); h = rng.uniform(0.1, 0.6, n)
         cx = rng.uniform(w / 2, 1 - w / 2); cy = rng.uniform(h / 2, 1 - h / 2)
@@ -103,46 +294,10 @@ class TrainingData:
         boxes = [Box(self.lid2name[int(c)], int(c), Point(float(x), float(y)), Size(float(ww), float(hh)))
                  for x, y, ww, hh, c in zip(cx, cy, w, h, cls)]
         name = 'synthetic/%d/%d' % (salt, index)
-        return {name: img}, Sample(name, boxes, Size(W, H))
-
-    def _augmented_generator(self, sample_at, total, salt, transforms):
-        from . import transforms as T
-        host_tfs = [t for t in transforms if not isinstance(t, T.LabelCreatorTransform)]
-        loader = host_tfs[0]
-        preset_images = getattr(loader, 'images', None)
-
-        def gen_batch(batch_size, num_workers=0):
-            sampler = ShardSampler(total, batch_size, self.rank, self.world, self.seed + salt)
-            W, H = self.preset.image_size.w, self.preset.image_size.h
-            for idx, count in sampler.batches_with_count(self.epoch):
-                self.global_count = count
-                if len(idx) == 0:              # an empty shard of a short last batch: the rank still takes the step
-                    yield None, None, []
-                    continue
-                plans, gts = [], []
-                for i in idx:
-                    s = sample_at(int(i))
-                    if not isinstance(s, Sample):                # synthetic: the pixels travel with the record
-                        loader.images, sample = s
-                    else:
-                        loader.images, sample = preset_images, s
-                    # run_transforms until at least one anchor is positive, at most 50 times (training_data.py:88-98);
-                    # the label of a try is only LOOKED at there (num_bg < rows), so the test runs on the host and the
-                    # label vectors of the whole batch are encoded once, on the GPU, below
-                    for _ in range(50):
-                        args = (None, None, sample)
-                        for t in host_tfs:
-                            args = t(*args)
-                        if has_positive_anchor(self.preset, args[2].boxes):
-                            break
-                    plans.append(args[0]); gts.append(args[2].boxes)
-                loader.images = preset_images
-                images = T.augment_batch(plans, W, H, device=self.device)
-                labels = self._labels(gts)
-                if not self.device_tensors:
-                    images = images.cpu().numpy()
-                yield images, labels, gts
-        return gen_batch
+        out = ({name: img}, Sample(name, boxes, Size(W, H)))
+        if len(self._synthetic_cache) < CACHE_SYNTHETIC_UP_TO:
+            self._synthetic_cache[key] = out
+        return out
 
     # ---- preset-sized float32 synthetic images (no transform recipe) ------------------------------------------------
     def _sample(self, index, salt):
@@ -157,26 +312,221 @@ class TrainingData:
         gt = [Box(self.lid2name[int(ci)], int(ci), Point(*map(float, bi[:2])), Size(*map(float, bi[2:]))) for bi, ci in zip(boxes, cls)]
         return img, gt
 
-    def _generator(self, total, salt):
+    # ---- GPU half of a batch ------------------------------------------------------------------------------------------
+    def _device_ring(self, batch_size):
+        """Three device slots (images, labels, staging for the source bytes, tap-table workspace) + the feeder stream."""
+        import torch
+        from ._lib import lib
+        d = self._dev
+        if d is not None and d['batch'] >= batch_size:
+            return d
+        dev = torch.device('cuda', self.device)
+        W, H = self.preset.image_size.w, self.preset.image_size.h
+        A, nv = self.preset.num_anchors, self.num_classes + 5
+        d = {'batch': batch_size, 'stream': torch.cuda.Stream(device=dev),
+             'images': [torch.empty((batch_size, H, W, 3), dtype=torch.float32, device=dev) for _ in range(DEVICE_SLOTS)],
+             'labels': [torch.empty((batch_size, A, nv), dtype=torch.float32, device=dev) for _ in range(DEVICE_SLOTS)],
+             'packed': [None] * DEVICE_SLOTS,
+             'ws': [torch.empty((lib.ssd_augment_ws_bytes(batch_size, W, H),), dtype=torch.uint8, device=dev) for _ in range(DEVICE_SLOTS)]}
+        self._dev = d
+        return d
+
+    def _upload(self, arrays, gts, slot=None):
+        """Source bytes up, augmentation + label kernels on torch's current stream -> (images, labels) of this batch.
+        slot None: fresh tensors (the serial generator); else the device slot to fill."""
+        if self._upload_hook is not None:
+            return self._upload_hook(arrays, gts, slot)
+        import ctypes as C
+        import torch
+        from ._lib import lib, check
+        b = len(gts)
+        dev = torch.device('cuda', self.device)
+        W, H = self.preset.image_size.w, self.preset.image_size.h
+        ring = self._dev if slot is not None else None
+        if 'images' in arrays:
+            src = torch.from_numpy(arrays['images'])
+            if ring is not None:
+                images = ring['images'][slot][:b]
+                images.copy_(src, non_blocking=True)
+            else:
+                images = src.to(dev, non_blocking=True) if self.device_tensors else arrays['images']
+        else:
+            packed, params = arrays['packed'], arrays['params']
+            if ring is not None:
+                if ring['packed'][slot] is None or ring['packed'][slot].numel() < packed.size:
+                    ring['packed'][slot] = torch.empty((max(packed.size, ring['batch'] * (self._max_image_bytes + 16)),), dtype=torch.uint8, device=dev)
+                staged = ring['packed'][slot][:packed.size]
+                staged.copy_(torch.from_numpy(packed), non_blocking=True)
+                images, ws = ring['images'][slot][:b], ring['ws'][slot]
+            else:
+                staged = torch.from_numpy(packed).to(dev)
+                images = torch.empty((b, H, W, 3), dtype=torch.float32, device=dev)
+                ws = torch.empty((lib.ssd_augment_ws_bytes(b, W, H),), dtype=torch.uint8, device=dev)
+            check(lib.ssd_augment_batch_dev(staged.data_ptr(), C.c_void_p(params.ctypes.data), b, W, H, images.data_ptr(), ws.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+            if not self.device_tensors:
+                images = images.cpu().numpy()
+        labels = self._labels(gts, out=ring['labels'][slot][:b] if ring is not None else None)
+        return images, labels
+
+    # ---- the generators ----------------------------------------------------------------------------------------------
+    def _make_generator(self, recipe):
         def gen_batch(batch_size, num_workers=0):
-            import torch
-            sampler = ShardSampler(total, batch_size, self.rank, self.world, self.seed + salt)
-            for idx, count in sampler.batches_with_count(self.epoch):
-                self.global_count = count
-                if len(idx) == 0:
+            sampler = ShardSampler(recipe.total, batch_size, self.rank, self.world, self.seed + recipe.salt)
+            batches = list(sampler.batches_with_count(self.epoch))
+            if num_workers and num_workers > 0 and (self.device_tensors or self._upload_hook is not None):
+                yield from self._prefetched(recipe, batches, self.epoch, batch_size, int(num_workers))
+                return
+            for idx, count in batches:
+                if len(idx) == 0:              # an empty shard of a short last batch: the rank still takes the step
+                    self.global_count = count
                     yield None, None, []
                     continue
-                imgs, gts = [], []
-                for i in idx:
-                    # redrawn (<= 50 times) until at least one anchor is positive (training_data.py:92-98)
-                    for tries in range(50):
-                        img, gt = self._sample(int(i) + 7919 * tries, salt)
-                        if has_positive_anchor(self.preset, gt):
-                            break
-                    imgs.append(img); gts.append(gt)
-                images = np.stack(imgs)
-                labels = self._labels(gts)
-                if self.device_tensors:
-                    images = torch.from_numpy(images).to(torch.device('cuda', self.device), non_blocking=True)
+                arrays, gts = recipe.plan(self.epoch, idx)
+                images, labels = self._upload(arrays, gts)
+                self.global_count = count
                 yield images, labels, gts
         return gen_batch
+
+    def _prefetched(self, recipe, batches, epoch, batch_size, num_workers):
+        import torch
+        if recipe.active:
+            raise RuntimeError('one %s generator at a time: finish or close the previous one first' % recipe.which)
+        slot_bytes = recipe.slot_bytes(batch_size)
+        pool = recipe.pool
+        if pool is not None and (pool.num_workers != num_workers or pool.slot_bytes < slot_bytes):
+            pool.close()
+            pool = None
+        if pool is None:
+            prime_anchor_table(self.preset)              # the workers must find it: they never call the GPU
+            pool = recipe.pool = _WorkerPool(recipe, num_workers, slot_bytes)
+        use_gpu = self._upload_hook is None
+        if use_gpu:
+            pool.pin(self.device)
+            ring = self._device_ring(batch_size)
+            fstream = ring['stream']
+            dev = torch.device('cuda', self.device)
+        pool.generation += 1
+        gen = pool.generation
+        nb = len(batches)
+        ready = queue.Queue()
+        dev_free = queue.Queue()
+        for s in range(DEVICE_SLOTS):
+            dev_free.put((s, None))
+        cancel = threading.Event()
+
+        def feeder():
+            try:
+                next_submit = next_upload = 0
+                done = {}
+                while next_upload < nb and not cancel.is_set():
+                    while next_submit < nb and (len(batches[next_submit][0]) == 0 or pool.free_slots):
+                        idx = batches[next_submit][0]
+                        if len(idx) == 0:
+                            done[next_submit] = None
+                        else:
+                            slot = pool.free_slots.pop()
+                            pool.outstanding[(gen, next_submit)] = slot
+                            pool.tasks.put((gen, next_submit, slot, epoch, np.asarray(idx)))
+                        next_submit += 1
+                    if next_upload in done:
+                        item = done.pop(next_upload)
+                        count = batches[next_upload][1]
+                        if item is None:
+                            ready.put((next_upload, None, 0, [], count, None))
+                            next_upload += 1
+                            continue
+                        hslot, arrays, gts = item
+                        while True:
+                            try:
+                                dslot, released = dev_free.get(timeout=0.2)
+                                break
+                            except queue.Empty:
+                                if cancel.is_set():
+                                    return
+                        if use_gpu:
+                            with torch.cuda.stream(fstream):
+                                if released is not None:
+                                    fstream.wait_event(released)
+                                images, labels = self._upload(arrays, gts, dslot)
+                                ev = torch.cuda.Event()
+                                ev.record(fstream)
+                                ev.synchronize()          # the slot's bytes have left the host
+                        else:
+                            images, labels = self._upload(arrays, gts, dslot)
+                            ev = None
+                        pool.free_slots.append(hslot)
+                        ready.put((next_upload, dslot, len(gts), (images, labels, gts), count, ev))
+                        next_upload += 1
+                        continue
+                    try:
+                        tag, hslot, arrays, gts = pool.results.get(timeout=0.5)
+                    except queue.Empty:
+                        pool.check_alive()
+                        continue
+                    except WorkerError as e:
+                        pool.outstanding.pop(e.tag, None)
+                        if e.tag[0] != gen:
+                            continue
+                        raise
+                    pool.outstanding.pop(tag, None)
+                    if tag[0] != gen:                      # a batch of an abandoned epoch
+                        pool.free_slots.append(hslot)
+                        continue
+                    done[tag[1]] = (hslot, arrays, gts)
+            except BaseException as e:
+                ready.put(e)
+
+        recipe.active = True
+        th = threading.Thread(target=feeder, name='ssd-feeder-' + recipe.which, daemon=True)
+        th.start()
+        try:
+            for k in range(nb):
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                seq, dslot, n, payload, count, ev = item
+                assert seq == k
+                if dslot is None:
+                    self.global_count = count
+                    yield None, None, []
+                    continue
+                images, labels, gts = payload
+                if ev is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                self.global_count = count
+                yield images, labels, gts
+                # the caller is back for the next batch: what it enqueued on its stream reads this slot
+                released = None
+                if use_gpu:
+                    released = torch.cuda.Event()
+                    released.record(torch.cuda.current_stream(dev))
+                dev_free.put((dslot, released))
+        finally:
+            cancel.set()
+            th.join()
+            recipe.active = False
+            # slots of results that were received but never uploaded go back; tasks still in flight are
+            # recognised by their generation when they arrive
+            while True:
+                try:
+                    item = ready.get_nowait()
+                except queue.Empty:
+                    break
+            self._reclaim(pool, gen)
+
+    @staticmethod
+    def _reclaim(pool, gen):
+        """After a generator ended (exhausted or abandoned): wait for the tasks of generation `gen` that are still with
+        the workers and take their slots back."""
+        while pool.outstanding:
+            try:
+                tag, hslot, _, _ = pool.results.get(timeout=5.0)
+            except queue.Empty:
+                pool.check_alive()
+                continue
+            except WorkerError as e:
+                tag = e.tag
+            pool.outstanding.pop(tag, None)
+        pool.outstanding.clear()
+        pool.free_slots = list(range(pool.nslots))

@@ -1,0 +1,141 @@
+"""CPU half of the feeder (reference training_data.py:137-195, data_queue.py:26-112):
+the worker processes, the shared-memory slot ring and the ordering / reproducibility contract, with the
+GPU half of a batch (upload + augmentation + label kernels) replaced by a host stand-in.  The real thing is
+tests/test_gpu_feeder.py."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import boxes as ob
+from ssd_tensorflow_amd import ssdutils
+from ssd_tensorflow_amd.data_queue import DataQueue, WorkerError
+from ssd_tensorflow_amd.training_data import TrainingData
+
+
+def _prime(preset_name='vgg300'):
+    preset = ssdutils.get_preset_by_name(preset_name)
+    ssdutils.prime_anchor_table(preset, ob.anchors_abs(ob.anchors(ob.PRESETS[preset_name])))
+    return preset
+
+
+def _host_upload(arrays, gts, slot):
+    """stand-in for TrainingData._upload: keeps a COPY of what would have gone to the GPU"""
+    return {k: np.array(v) for k, v in arrays.items()}, [[tuple(b) for b in g] for g in gts]
+
+
+def _collect(td, gen, batch, workers):
+    out = []
+    for x, y, gt in gen(batch, workers):
+        out.append((x, y, gt, td.global_count))
+    return out
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for (xa, ya, ga, ca), (xb, yb, gb, cb) in zip(a, b):
+        assert ca == cb
+        if xa is None:
+            assert xb is None and ga == gb == []
+            continue
+        assert xa.keys() == xb.keys()
+        for k in xa:
+            assert np.array_equal(xa[k], xb[k]), k
+        assert ya == yb and ga == gb
+
+
+def test_data_queue_slots_and_overflow():
+    dq = DataQueue(1000, 2)
+    a = np.arange(100, dtype=np.float32); b = np.arange(7, dtype=np.uint8)
+    dq.put(('g', 0), 1, {'a': a, 'b': b}, ['boxes'])
+    tag, slot, arrays, boxes = dq.get(timeout=5)
+    assert tag == ('g', 0) and slot == 1 and boxes == ['boxes']
+    assert np.array_equal(arrays['a'], a) and np.array_equal(arrays['b'], b)
+    assert arrays['a'].base is not None                                  # a view of the slot, not a copy
+    big = np.arange(2000, dtype=np.uint8)
+    dq.put(('g', 1), 0, {'big': big}, [])                                # does not fit: travels through the pipe
+    tag, slot, arrays, _ = dq.get(timeout=5)
+    assert tag == ('g', 1) and np.array_equal(arrays['big'], big)
+    with pytest.raises(ValueError):
+        dq.put(('g', 2), 0, {'x': [1, 2, 3]}, [])                        # data_queue.py:64-65
+    with pytest.raises(ValueError):
+        dq.put(('g', 2), 0, {'x': np.zeros((4, 4))[:, ::2]}, [])
+    dq.put_error(('g', 3), 1, 'boom')
+    with pytest.raises(WorkerError) as e:
+        dq.get(timeout=5)
+    assert e.value.tag == ('g', 3) and e.value.arr_id == 1
+
+
+@pytest.mark.parametrize('augment', [True, False])
+def test_workers_produce_the_serial_generators_batches(augment):
+    """num_workers = 0, 1 and 3: the same batches in the same order, twice (two epochs differ, a repeated epoch does
+    not), whatever was drawn from `random` in between."""
+    _prime()
+    td = TrainingData(None, 'vgg300', num_train=22, num_valid=5, augment=augment, device_tensors=False)
+    td._upload_hook = _host_upload
+    try:
+        td.epoch = 0
+        random.seed(1)
+        serial = _collect(td, td.train_generator, 4, 0)
+        assert [len(g) for _, _, g, _ in serial] == [4, 4, 4, 4, 4, 2]
+        random.seed(2); random.random()
+        one = _collect(td, td.train_generator, 4, 1)
+        three = _collect(td, td.train_generator, 4, 3)
+        _same(serial, one); _same(serial, three)
+        valid0 = _collect(td, td.valid_generator, 4, 0)
+        valid2 = _collect(td, td.valid_generator, 4, 2)
+        _same(valid0, valid2)
+        td.epoch = 1
+        other = _collect(td, td.train_generator, 4, 3)
+        assert any(not np.array_equal(a[0][k], b[0][k]) if a[0][k].shape == b[0][k].shape else True
+                   for a, b in zip(serial, other) for k in a[0])
+        _same(other, _collect(td, td.train_generator, 4, 0))
+    finally:
+        td.close()
+
+
+def test_rank_shards_with_workers_keep_lock_step():
+    """Two ranks, a short last global batch that leaves rank 1 empty: same number of yields on both ranks, the
+    global batch size travels with the batch it belongs to (not with the one being prefetched)."""
+    _prime()
+    tds = [TrainingData(None, 'vgg300', num_train=9, num_valid=2, augment=True, device_tensors=False, rank=r, world=2)
+           for r in range(2)]
+    try:
+        outs = []
+        for td in tds:
+            td._upload_hook = _host_upload
+            outs.append(_collect(td, td.train_generator, 2, 2))
+        assert len(outs[0]) == len(outs[1]) == 3
+        assert [c for *_, c in outs[0]] == [c for *_, c in outs[1]] == [4, 4, 1]
+        assert len(outs[0][2][2]) == 1 and outs[1][2][0] is None and outs[1][2][2] == []
+        for td, want in zip(tds, outs):
+            _same(want, _collect(td, td.train_generator, 2, 0))
+    finally:
+        for td in tds:
+            td.close()
+
+
+def test_abandoned_epoch_and_failing_worker():
+    _prime()
+    td = TrainingData(None, 'vgg300', num_train=40, num_valid=4, augment=True, device_tensors=False)
+    td._upload_hook = _host_upload
+    try:
+        want = _collect(td, td.train_generator, 4, 0)
+        g = td.train_generator(4, 2)
+        first = next(g)
+        g.close()                                              # the consumer walks away mid-epoch
+        again = _collect(td, td.train_generator, 4, 2)         # the pool is reused, no stale batch leaks in
+        _same(want, again)
+        assert np.array_equal(first[0]['packed'], want[0][0]['packed'])
+        # a worker that raises: the consumer sees the error, the next epoch still works
+        recipe = td._recipes['train']
+        recipe.pool.close(); recipe.pool = None
+        orig = recipe.sample_at
+        recipe.sample_at = lambda i: (_ for _ in ()).throw(OSError('unreadable file %d' % i)) if i == 7 else orig(i)
+        with pytest.raises(RuntimeError, match='unreadable file 7'):
+            _collect(td, td.train_generator, 4, 2)
+        recipe.pool.close(); recipe.pool = None
+        recipe.sample_at = orig
+        _same(want, _collect(td, td.train_generator, 4, 2))
+    finally:
+        td.close()
