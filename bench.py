@@ -537,6 +537,7 @@ def run_train_e2e(a, rank, world, local):
                 td.num_train = b * a.e2e_serial_steps                                 # the serial feeder is slow: fewer steps
                 td._recipes['train'].total = td.num_train
             calc.clear()
+            summ = LossSummary(None, 'training', td.num_train * epochs)
             torch.cuda.synchronize()
             steps0 = loop.steps
             t0 = time.perf_counter()
@@ -547,7 +548,10 @@ def run_train_e2e(a, rank, world, local):
             dt = time.perf_counter() - t0
             steps = loop.steps - steps0
             res[label] = dict(value=round(steps * b / dt, 2), ms_per_step=round(dt / steps * 1e3, 4), steps=steps, epochs=epochs, workers=workers,
-                              losses_last_epoch=summ.push(0), detections_collected=len(calc.det_confidence))
+                              mean_losses=summ.push(0), detections_collected=len(calc.det_confidence))
+            if workers:      # last epoch's account of the feeder: who waited for whom (ms per step)
+                st = td.feeder_stats
+                res[label]['feeder_ms_per_step'] = {k: round(v / max(st['batches'], 1) * 1e3, 3) for k, v in st.items() if k != 'batches'}
     finally:
         td.close(); sess.close()
     torch.cuda.empty_cache()
@@ -557,7 +561,8 @@ def run_train_e2e(a, rank, world, local):
     return {'metric': 'images/sec end to end (feeder + augmentation + fwd+bwd + loss fetch + decode/NMS collection) %s batch%d' % (a.preset, b),
             'value': r['value'], 'unit': 'images/s', 'ms_per_step': r['ms_per_step'], 'steps': r['steps'], 'epochs': r['epochs'], 'dtype': a.dtype,
             'feeder_workers': r['workers'], 'host_cores': os.cpu_count(), 'dataset_build_s': round(t_data, 2),
-            'serial_feeder': res.get('serial'), 'losses_last_epoch': r['losses_last_epoch'], 'detections_collected': r['detections_collected'],
+            'serial_feeder': res.get('serial'), 'mean_losses': r['mean_losses'], 'detections_collected': r['detections_collected'],
+            'feeder_ms_per_step': r.get('feeder_ms_per_step'),
             'config': {'workload': f"{a.preset} train.py StepLoop, {b} images/step, {n_samples} synthetic uint8 images of 200..640 px through the reference's "
                                    'train recipe (process_dataset.py:66-140), --num-workers %d' % r['workers']}}
 

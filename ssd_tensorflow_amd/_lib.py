@@ -57,6 +57,7 @@ SIGNATURES = {
     'ssd_arena_floats': (sz, [cstr, i32]),
     'ssd_augment_ws_bytes': (sz, [i32, i32, i32]),
     'ssd_augment_batch_dev': (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    'ssd_sampler_trials': (i32, [vp, i32, vp, vp, i32, i32, vp, i32, vp, vp]),
     'ssd_create': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, C.POINTER(handle)]),
     'ssd_create_dtype': (i32, [cstr, i32, i32, i32, i32, C.c_ulonglong, vp, vp, vp, i32, C.POINTER(handle)]),
     'ssd_get_dtype': (i32, [handle, p_i32]),

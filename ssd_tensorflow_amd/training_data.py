@@ -42,6 +42,7 @@ import os
 import queue
 import random
 import threading
+import time
 import traceback
 
 import numpy as np
@@ -210,6 +211,9 @@ class TrainingData:
         self._dev = None                       # device-side slot ring, feeder stream (created on first use)
         self._upload_hook = None               # tests: replaces the GPU half of a batch
         self._synthetic_cache = {}
+        # where a prefetched epoch's time went (seconds, reset by every gen_batch call with workers): the consumer waiting
+        # for a batch, the feeder thread waiting for the workers / for a free device slot / uploading
+        self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, batches=0)
         from . import transforms as T
         if data_dir not in (None, '', 'synthetic'):
             # ---- a real dataset directory (training_data.py:41-69 + process_dataset.py:199-252) ----
@@ -414,6 +418,8 @@ class TrainingData:
         for s in range(DEVICE_SLOTS):
             dev_free.put((s, None))
         cancel = threading.Event()
+        stats = self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, batches=0)
+        clock = time.perf_counter
 
         def feeder():
             try:
@@ -437,6 +443,7 @@ class TrainingData:
                             next_upload += 1
                             continue
                         hslot, arrays, gts = item
+                        t0 = clock()
                         while True:
                             try:
                                 dslot, released = dev_free.get(timeout=0.2)
@@ -444,6 +451,8 @@ class TrainingData:
                             except queue.Empty:
                                 if cancel.is_set():
                                     return
+                        t1 = clock()
+                        stats['slot_wait'] += t1 - t0
                         if use_gpu:
                             with torch.cuda.stream(fstream):
                                 if released is not None:
@@ -455,13 +464,17 @@ class TrainingData:
                         else:
                             images, labels = self._upload(arrays, gts, dslot)
                             ev = None
+                        stats['upload'] += clock() - t1
+                        stats['batches'] += 1
                         pool.free_slots.append(hslot)
                         ready.put((next_upload, dslot, len(gts), (images, labels, gts), count, ev))
                         next_upload += 1
                         continue
+                    t0 = clock()
                     try:
                         tag, hslot, arrays, gts = pool.results.get(timeout=0.5)
                     except queue.Empty:
+                        stats['worker_wait'] += clock() - t0
                         pool.check_alive()
                         continue
                     except WorkerError as e:
@@ -469,6 +482,7 @@ class TrainingData:
                         if e.tag[0] != gen:
                             continue
                         raise
+                    stats['worker_wait'] += clock() - t0
                     pool.outstanding.pop(tag, None)
                     if tag[0] != gen:                      # a batch of an abandoned epoch
                         pool.free_slots.append(hslot)
@@ -482,7 +496,9 @@ class TrainingData:
         th.start()
         try:
             for k in range(nb):
+                t0 = clock()
                 item = ready.get()
+                stats['consumer_wait'] += clock() - t0
                 if isinstance(item, BaseException):
                     raise item
                 seq, dslot, n, payload, count, ev = item

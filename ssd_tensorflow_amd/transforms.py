@@ -274,6 +274,10 @@ class SamplerTransform(Transform):
                 break
         else:
             return None
+        return self.crop(data, label, gt, window)
+
+    def crop(self, data, label, gt, window):
+        """The accepted window (xmin, xmax, ymin, ymax in pixels of gt.imgsize) applied to the plan and the boxes."""
         left, top = int(window[0]), int(window[2])
         new_size = Size(int(window[1] - window[0]), int(window[3] - window[2]))
         out = _copy_plan(data)
@@ -293,15 +297,54 @@ def _copy_plan(p):
     return q
 
 
+NATIVE_SAMPLER = os.environ.get('SSD_NATIVE_SAMPLER', '1') != '0'      # A/B switch: '0' runs the trial loops in Python
+
+
 class SamplePickerTransform(Transform):
-    """Parameters: samplers (transforms.py:362-376)"""
+    """Parameters: samplers (transforms.py:362-376).
+
+    The samplers' trial loops (<= 50 draws of a window each, ~210 per image: the whole cost of planning an image in
+    Python) run in ONE native call, ssd_sampler_trials, on the state of Python's `random`: the same draws in the same
+    order, the generator left where the Python loops leave it (tests/test_augment.py pins that against the loops)."""
+
     def __call__(self, data, label, gt):
+        if NATIVE_SAMPLER and all(type(s) is SamplerTransform for s in self.samplers):
+            return self._native(data, label, gt)
         samples = []
         for sampler in self.samplers:
             sample = sampler(data, label, gt)
             if sample is not None:
                 samples.append(sample)
         return random.choice(samples)
+
+    def _native(self, data, label, gt):
+        active = [s for s in self.samplers if s.sample]
+        n = len(active)
+        found = (C.c_int * max(n, 1))()
+        windows = (C.c_longlong * (4 * max(n, 1)))()
+        if n:
+            if not gt.boxes:
+                raise ValueError('zero-size array to reduction operation maximum which has no identity')      # what the loop's .max() raises
+            st = random.getstate()
+            mt = (C.c_uint32 * 625)(*st[1])
+            params = (C.c_double * (5 * n))(*[v for s in active for v in (s.min_scale, s.max_scale, s.min_aspect_ratio, s.max_aspect_ratio,
+                                                                         s.min_jaccard_overlap)])
+            trials = (C.c_int * n)(*[int(s.max_trials) for s in active])
+            gt_px = np.array([prop2abs(b.center, b.size, gt.imgsize) for b in gt.boxes], dtype=np.float64).reshape(-1, 4)
+            check(lib.ssd_sampler_trials(mt, n, params, trials, int(gt.imgsize.w), int(gt.imgsize.h), gt_px.ctypes.data, len(gt.boxes),
+                                         windows, found))
+            random.setstate((st[0], tuple(mt), st[2]))
+        # the candidates in the samplers' order; only the chosen one is materialised (building a candidate draws nothing)
+        cands, k = [], 0
+        for s in self.samplers:
+            if not s.sample:
+                cands.append((s, None))
+            else:
+                if found[k]:
+                    cands.append((s, [windows[4 * k + i] for i in range(4)]))
+                k += 1
+        s, window = random.choice(cands)
+        return (data, label, gt) if window is None else s.crop(data, label, gt, window)
 
 
 class HorizontalFlipTransform(Transform):
@@ -334,14 +377,18 @@ class _Params(C.Structure):
 def plan_params(plans, width, height):
     """(ctypes array of ssd_augment_params, packed uint8 image bytes) for a list of ImagePlans"""
     arr = (_Params * len(plans))()
-    chunks, off = [], 0
+    offs, off = [], 0
+    for p in plans:
+        offs.append(off)
+        off += (p.image.size + 15) // 16 * 16
+    packed = np.empty(off, np.uint8)
     for i, p in enumerate(plans):
         if p.resize is None:
             raise ValueError('plan %d was not resized: the batch needs one output size (ResizeTransform last)' % i)
         if (p.resize[0], p.resize[1]) != (width, height):
             raise ValueError('plan %d resizes to %s, the batch is %s' % (i, p.resize[:2], (width, height)))
         q = arr[i]
-        q.src_off = off; q.src_w = p.src.w; q.src_h = p.src.h
+        q.src_off = offs[i]; q.src_w = p.src.w; q.src_h = p.src.h
         q.brightness_on = int(p.brightness is not None); q.brightness_delta = p.brightness or 0
         q.n_distort = len(p.distort)
         for k, (kind, val) in enumerate(p.distort):
@@ -355,12 +402,9 @@ def plan_params(plans, width, height):
         q.crop_x0 = x0; q.crop_y0 = y0; q.crop_w = cw; q.crop_h = ch
         q.flip = int(p.flip); q.resize_alg = p.resize[2]
         n = p.image.size
-        padded = (n + 15) // 16 * 16
-        chunk = np.zeros(padded, np.uint8)
-        chunk[:n] = p.image.reshape(-1)
-        chunks.append(chunk)
-        off += padded
-    return arr, np.concatenate(chunks)
+        packed[offs[i]:offs[i] + n] = p.image.reshape(-1)
+        packed[offs[i] + n:offs[i] + (n + 15) // 16 * 16] = 0
+    return arr, packed
 
 
 def augment_batch(plans, width, height, device=0, out=None):

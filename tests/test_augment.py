@@ -7,6 +7,7 @@
 import random
 
 import numpy as np
+import pytest
 
 from golden_util import load
 from oracle import augment as oa
@@ -120,3 +121,43 @@ def test_plan_order_is_enforced():
         T.BrightnessTransform(delta=3)(p, None, gt)
     with pytest.raises(ValueError):
         T.ImagePlan(np.zeros((8, 8, 3), np.float32))
+
+
+def test_native_sampler_trials_are_the_python_loops():
+    """ssd_sampler_trials (csrc/planner.hip: all samplers of a SamplePickerTransform in one native call on the state of
+    Python's Mersenne Twister) against the Python trial loops: the same plans, the same transformed boxes and the same
+    generator state afterwards on the whole train recipe -- so the golden-vector cases above, which run the native path,
+    pin it to the reference as well."""
+    from ssd_tensorflow_amd import transforms as T
+    from ssd_tensorflow_amd.ssdutils import get_preset_by_name
+    from ssd_tensorflow_amd.utils import Box, Point, Sample, Size
+    preset = get_preset_by_name('vgg300')
+    host = [t for t in T.build_train_transforms(preset, 20, 50, 0.5) if not isinstance(t, T.LabelCreatorTransform)]
+    rng = np.random.default_rng(0)
+    samples = []
+    for i in range(120):
+        W, H = int(rng.integers(120, 700)), int(rng.integers(120, 700))
+        n = int(rng.integers(1, 6)); w = rng.uniform(0.02, 0.7, n); h = rng.uniform(0.02, 0.7, n)
+        cx = rng.uniform(w / 2, 1 - w / 2); cy = rng.uniform(h / 2, 1 - h / 2)
+        boxes = [Box('x', 0, Point(float(a), float(b)), Size(float(c), float(d))) for a, b, c, d in zip(cx, cy, w, h)]
+        samples.append(({'f%d' % i: np.zeros((H, W, 3), np.uint8)}, Sample('f%d' % i, boxes, Size(W, H))))
+
+    def run(native):
+        saved, T.NATIVE_SAMPLER = T.NATIVE_SAMPLER, native
+        try:
+            out = []
+            for k, (imgs, s) in enumerate(samples):
+                random.seed(1000 + k)
+                host[0].images = imgs
+                a = (None, None, s)
+                for t in host:
+                    a = t(*a)
+                out.append((a[0].crop, a[0].flip, a[0].expand, a[0].resize, a[2].boxes, random.getstate()))
+            return out
+        finally:
+            T.NATIVE_SAMPLER = saved
+    assert run(False) == run(True)
+    # no ground-truth box left (all dropped by an expand): the loops' numpy reduction raises, so does the native path
+    picker = [t for t in host if isinstance(t, T.SamplePickerTransform)][0]
+    with pytest.raises(ValueError):
+        picker(T.ImagePlan(np.zeros((50, 50, 3), np.uint8)), None, Sample('e', [], Size(50, 50)))

@@ -118,7 +118,7 @@ def test_train_driver_with_workers_matches_without(tmp_path, capsys):
     out3 = capsys.readouterr().out
     assert '[i] Number of workers:     3' in out3
     pick = lambda o: [l for l in o.splitlines() if l.startswith(('[i] Train', '[i] Valid', '[i] mAP'))]
-    assert pick(out0) == pick(out3) and len(pick(out0)) == 5
+    assert pick(out0) == pick(out3) and len(pick(out0)) == 6          # '[i] Training...' + 2 x (Train, Valid) + mAP
     ca, cb = np.load(a + '/final.npz'), np.load(b + '/final.npz')
     for k in ca.files:
         assert np.array_equal(ca[k], cb[k]), k
