@@ -222,13 +222,14 @@ EXPECT_PATH = os.path.join(ROOT, 'tests', 'golden', 'bench_expect.json')
 def expected_losses(preset, batch, dtype):
     """Step-0 losses of the benchmark's own inputs (rank 0: images / boxes from default_rng(1234), library weights
     from seed 42) computed by the CPU oracle in the build container (tools/make_bench_expect.py); None if that
-    configuration was not generated.  bf16 runs are checked against the fp32 values with a bf16-sized tolerance."""
+    configuration was not generated.  bf16 runs are checked against the fp32 values at 2e-3 (measured distance ~1e-4; the
+    bf16 kernels themselves are checked layer by layer at these sizes by tests/test_gpu_bench_config.py)."""
     try:
         table = json.load(open(EXPECT_PATH))
     except OSError:
         return None, None
     e = table.get(f'{preset}_b{batch}')
-    return (e, 1e-3 if dtype == 'f32' else 3e-2) if e else (None, None)
+    return (e, 1e-3 if dtype == 'f32' else 2e-3) if e else (None, None)
 
 
 def run_config(a, rank, world, local):
@@ -620,7 +621,7 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
-    ap.add_argument('--e2e-workers', type=int, default=0, help='train_e2e: feeder worker processes (0 = min(24, host cores / 4))')
+    ap.add_argument('--e2e-workers', type=int, default=0, help='train_e2e: feeder worker processes (0 = 4)')
     ap.add_argument('--e2e-steps', type=int, default=0, help='train_e2e: steps per epoch (0 = 20 fp32 / 60 bf16)')
     ap.add_argument('--e2e-epochs', type=int, default=1, help='train_e2e: timed epochs')
     ap.add_argument('--e2e-serial-steps', type=int, default=3, help='train_e2e: steps of the serial-feeder comparison (0 = skip)')
@@ -658,7 +659,7 @@ def main():
     def e2e(dtype):
         sub = argparse.Namespace(**vars(args))
         sub.dtype = dtype
-        sub.e2e_workers = args.e2e_workers or min(24, max(2, (os.cpu_count() or 8) // 4))
+        sub.e2e_workers = args.e2e_workers or 4
         sub.e2e_steps = args.e2e_steps or (60 if dtype == 'bf16' else 20)
         return run_train_e2e(sub, rank, world, local)
 

@@ -80,6 +80,49 @@ def test_benchmarked_batch_forward_loss_and_layer_local_backward(pname, b):
     sess.close()
 
 
+@pytest.mark.parametrize('pname,b', [('vgg300', 32), ('vgg512', 16)])
+def test_benchmarked_batch_bf16_layer_local(pname, b):
+    """BASELINE.json configs[2] / [3] per GPU in bf16: the M-dependent choices of the real step -- the 8-wave kernel-row
+    weight gradient's split count (256 / (3 CT NT) workgroups), the 256-row gather tiles, the persistent 64 -> 64 kernel, the
+    4-wave kernel-row weight gradient of the 64-channel layers, conv1_1's dedicated kernels, two forward lanes of 16 + 16 --
+    only exist at these sizes.  Every checked layer's forward, data gradient and weight gradient is recomputed by the
+    oracle from the GPU's own input activation / output gradient with the SAME roundings (tests/test_gpu_bf16.py):
+    1e-3 where the result is stored in fp32, one bf16 rounding where it is stored in bf16."""
+    from test_gpu_bf16 import layer_local_forward_check, qt, TOL_BF, TOL_BF2
+    from test_gpu_model import head_out_from_buffers
+    layers = BENCH_LAYERS[pname] + ['conv1_1', 'conv2_1', 'conv3_1', 'l2_norm_conv4_3']
+    preset, x, y = bench_inputs(pname, b)
+    w = ref.init_params(preset, 20, seed=42, alive=True)
+    m = ref.RefModel(pname, params=w)
+    m.set_optimizer([0.00075], [], 0.9, WD)
+    sess = Session(0)
+    net = SSDVGG(sess, pname)
+    net.build_from_vgg(None, 20, max_batch=b, weights=w, dtype='bf16')
+    net.build_optimizer(learning_rate=0.00075, weight_decay=WD, momentum=0.9)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    net.forward_dev(xt, yt)
+    L = net.get_losses()
+    r = net._dev_result(b, True)
+    worst = layer_local_forward_check(net, m, preset, b, x, only=layers)
+    print('    worst layer-local forward error', worst)
+    assert worst < TOL_BF
+    # the loss and the softmax result from the GPU's own fp32 head outputs
+    out_gpu = head_out_from_buffers(net, preset, b)
+    conf, loc, _, _ = ref.loss_numpy(out_gpu, y)
+    assert abs(L['confidence'] - conf) < TOL * abs(conf) and abs(L['localization'] - loc) < TOL * abs(loc)
+    sm = torch.softmax(torch.from_numpy(out_gpu[..., :21]), -1).numpy()
+    assert max_rel(r[..., :21], sm) < TOL and np.array_equal(r[..., 21:], out_gpu[..., 21:])
+    # distance to the fp32 oracle at this batch (what bench.py's step-0 guard looks at), reported
+    _, L_ref = oracle_forward_chunked(m, x, y)
+    print('    bf16 vs fp32 oracle losses', {k: (round(L[k], 5), round(float(L_ref[k]), 5)) for k in L})
+    net.forward_backward_dev(xt, yt)
+    torch.cuda.synchronize()
+    worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y, wq=qt, tol_dout=TOL_BF, only=layers)
+    print('    worst layer-local weight-gradient error', worst_w, ' data-gradient error', worst_x)
+    assert worst_w < TOL and worst_x < TOL_BF2
+    sess.close()
+
+
 def test_bench_step0_losses_equal_stored_oracle_values():
     """The stored step-0 losses bench.py checks itself against (tests/golden/bench_expect.json, made on the CPU by
     tools/make_bench_expect.py from oracle.init_params_lib weights): (1) the library's own initial weights ARE that
