@@ -97,6 +97,7 @@ SIGNATURES = {
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'ssd_detect_last_dev': (i32, [handle, i32, f32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     'ssd_detect_fetch': (i32, [handle, i32, vp, vp, vp, vp, vp]),
+    'ssd_detect_host': (i32, [handle, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), p_i32, p_i32]),
     'ssd_nms_boxes': (i32, [i32, i32, vp, vp, vp, C.c_double, vp, p_i32]),
     'ssd_set_overlap': (i32, [handle, i32]),
     'ssd_profile_enable': (i32, [handle, i32]),

@@ -624,6 +624,19 @@ int ssd_detect_fetch(ssd_handle h, int which, int* count, float* conf, int* cls,
     API_END
 }
 
+int ssd_detect_host(ssd_handle h, int which, const int** count, const float** conf, const int** cls, const int** idx,
+                    const int** box, int* b, int* out_cap) {
+    API_BEGIN_NET(h)
+    DetectOut d;
+    n.detect_host(which, &d, b, out_cap);
+    if (count) *count = d.count;
+    if (conf) *conf = d.conf;
+    if (cls) *cls = d.cls;
+    if (idx) *idx = d.idx;
+    if (box) *box = d.box;
+    API_END
+}
+
 int ssd_set_overlap(ssd_handle h, int on) {
     API_BEGIN_NET(h)
     n.set_overlap(on != 0);

@@ -255,92 +255,6 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // the survivors stored from the first row of the segment on, their number in `bcount`.  A workgroup's rows
 // belong to at most two images (A >= 256): two segments, the second one starting at the image boundary.
 // No atomics (a per-image counter serialises in L2: 137 waves hit each address), no memset, deterministic.
-constexpr int SCAN_ROWS = 256;
-constexpr int SCAN_MAXV = 32;                       // nv <= 32
-constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
-
-__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          u64* __restrict__ dense, int* __restrict__ bcount) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];
-    __shared__ int s_cnt[2][4];
-    const int total_rows = B * A;
-    const int r0 = blockIdx.x * SCAN_ROWS;
-    const int nrows = min(SCAN_ROWS, total_rows - r0);
-    const int nfl = nrows * nv;
-    const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
-    const int n4 = nfl >> 2;
-    // all of this thread's loads are issued before the first one is consumed
-    float4 v[SCAN_LOADS];
-#pragma unroll
-    for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
-    }
-    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int img_first = r0 / A;
-    const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
-    u64 key = 0ull;
-    int half = 0;
-    if ((int)threadIdx.x < nrows) {
-        const float* r = rows + (size_t)threadIdx.x * nv;
-        const int nfg = nv - 5;                  // argmax excludes the background class
-        int best = 0;
-        float conf = r[0];
-        for (int c = 1; c < nfg; ++c)
-            if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-        const int row = r0 + threadIdx.x;
-        half = row >= boundary ? 1 : 0;
-        const int a = row - (img_first + half) * A;
-        if (!(conf < thr))                        // the reference breaks at the first conf < thr
-            key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
-    }
-    const u64 bal0 = __ballot(key != 0ull && half == 0), bal1 = __ballot(key != 0ull && half == 1);
-    if (lane == 0) { s_cnt[0][wv] = __popcll(bal0); s_cnt[1][wv] = __popcll(bal1); }
-    __syncthreads();
-    int base = 0, tot0 = 0, tot1 = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wv) base += s_cnt[half][w];
-        tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
-    }
-    if (key != 0ull) {
-        const u64 bal = half ? bal1 : bal0;
-        dense[(size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-    }
-    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
-}
-
-// descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
-__device__ void bitonic_desc(u64* keys, int n2) {
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if (up ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int n) {
-    int p = 1;
-    while (p < n) p <<= 1;
-    return p;
-}
-
 // decode_location under numpy>=2 promotion (x, y float32; w, h float64) followed by
 // normalize_box's integer box (utils.py:118-135; centre*1000 in f32, half extent cast to f32).
 __device__ __forceinline__ void decode_box(const float* loc, const double* an, int* o) {
@@ -372,6 +286,105 @@ __device__ __forceinline__ void decode_box(const float* loc, const double* an, i
     const long long lo = -(1LL << 30);
     o[0] = (int)(xmin > lo ? xmin : lo); o[1] = (int)(xmax > lo ? xmax : lo);
     o[2] = (int)(ymin > lo ? ymin : lo); o[3] = (int)(ymax > lo ? ymax : lo);
+}
+
+constexpr int SCAN_ROWS = 256;
+constexpr int SCAN_MAXV = 32;                       // nv <= 32
+constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
+
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          const double* __restrict__ anchors, u64* __restrict__ dense,
+                                                          int4* __restrict__ dense_box, int* __restrict__ bcount) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    __shared__ int s_cnt[2][4];
+    const int total_rows = B * A;
+    const int r0 = blockIdx.x * SCAN_ROWS;
+    const int nrows = min(SCAN_ROWS, total_rows - r0);
+    const int nfl = nrows * nv;
+    const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
+    const int n4 = nfl >> 2;
+    // all of this thread's loads are issued before the first one is consumed
+    float4 v[SCAN_LOADS];
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int img_first = r0 / A;
+    const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
+    u64 key = 0ull;
+    int half = 0;
+    int4 cbox = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x < nrows) {
+        const float* r = rows + (size_t)threadIdx.x * nv;
+        const int nfg = nv - 5;                  // argmax excludes the background class
+        int best = 0;
+        float conf = r[0];
+        for (int c = 1; c < nfg; ++c)
+            if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
+        const int row = r0 + threadIdx.x;
+        half = row >= boundary ? 1 : 0;
+        const int a = row - (img_first + half) * A;
+        if (!(conf < thr)) {                      // the reference breaks at the first conf < thr
+            key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
+            // The candidate's box is decoded HERE, where its row already sits in LDS: the per-image kernel then reads
+            // (key, box) pairs from one contiguous run instead of chasing the key's anchor into the prediction tensor
+            // and the anchor table (a dependent, scattered load per candidate on that latency-bound kernel's critical
+            // path, plus two f64 exponentials).  ~3 % of the rows are candidates: the arithmetic hides under this
+            // kernel's HBM stream.
+            int bx[4];
+            decode_box(r + (nv - 4), anchors + (size_t)a * 4, bx);
+            cbox = make_int4(bx[0], bx[1], bx[2], bx[3]);
+        }
+    }
+    const u64 bal0 = __ballot(key != 0ull && half == 0), bal1 = __ballot(key != 0ull && half == 1);
+    if (lane == 0) { s_cnt[0][wv] = __popcll(bal0); s_cnt[1][wv] = __popcll(bal1); }
+    __syncthreads();
+    int base = 0, tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) base += s_cnt[half][w];
+        tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
+    }
+    if (key != 0ull) {
+        const u64 bal = half ? bal1 : bal0;
+        const size_t at = (size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull));
+        dense[at] = key;
+        dense_box[at] = cbox;
+    }
+    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
+}
+
+// descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
+__device__ void bitonic_desc(u64* keys, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if (up ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
 }
 
 // prop2abs(abs2prop(ints)) as non_maximum_suppression recomputes it (not the identity)
@@ -438,6 +451,7 @@ struct DetectArgs {
     int cap, max_out, out_cap, do_nms;
     const int* bcount;  // [scan workgroups][2] candidates per (workgroup, image) segment
     const u64* dense;   // [B*A] the segments' keys, compacted at each segment's first row
+    const int4* dense_box;   // [B*A] their decoded boxes (detect_scan_kernel), same positions
     u64* keys1;         // [B][A2] general path: the image's candidates gathered for the sort
     u64* keys2;
     int* box;       // [B][A][4]
@@ -519,14 +533,15 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     }
     __syncthreads();
     const int n = seg_off[nseg];
-    auto candidate = [&](int f) {            // f-th candidate of the image (any order: the keys are unique and get sorted)
+    auto candidate_at = [&](int f) -> size_t {      // where the f-th candidate of the image lies in dense / dense_box
         int lo = 0, hi = nseg - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (seg_off[mid] <= f) lo = mid; else hi = mid - 1;
         }
-        return p.dense[(size_t)seg_base[lo] + (f - seg_off[lo])];
+        return (size_t)seg_base[lo] + (f - seg_off[lo]);
     };
+    auto candidate = [&](int f) { return p.dense[candidate_at(f)]; };      // (any order: the keys are unique and get sorted)
 
     if (n <= DET_FAST) {
         // ================= everything in LDS: rank sort, decode, NMS, emit =================
@@ -540,19 +555,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         // predicated: a select on a loaded value would make each load wait in turn.
         constexpr int PER = DET_FAST / DET_THREADS;
         u64 mykey[PER];
-        float loc[PER][4];
-        double anc[PER][4];
+        int4 mybox[PER];
         int pos[PER], cpos[PER];
         if (n > 0) {
 #pragma unroll
-            for (int r = 0; r < PER; ++r) mykey[r] = candidate(min(tid + DET_THREADS * r, n - 1));
-#pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const int a = 32767 - (int)((mykey[r] >> 8) & 0xFFFFull);
-                const float* lp = p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4);
-                const double* ap = p.anchors + (size_t)a * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { loc[r][e] = lp[e]; anc[r][e] = ap[e]; }
+                const size_t at = candidate_at(min(tid + DET_THREADS * r, n - 1));
+                mykey[r] = p.dense[at];
+                mybox[r] = p.dense_box[at];
             }
         }
 #pragma unroll
@@ -634,9 +644,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             if (i < n && pos[r] < m) {
                 const u64 key = mykey[r];
                 const int q = p.do_nms ? segstart[crank[(int)(key & 31ull)]] + cpos[r] : pos[r];
-                const int a = 32767 - (int)((key >> 8) & 0xFFFFull);
-                int bx[4], nb[4];
-                decode_box(loc[r], anc[r], bx);
+                int bx[4] = {mybox[r].x, mybox[r].y, mybox[r].z, mybox[r].w}, nb[4];
                 nms_roundtrip(bx, nb);
                 okey[q] = key;
                 box[q] = make_int4(bx[0], bx[1], bx[2], bx[3]);
@@ -748,7 +756,7 @@ static size_t det_head_bytes(int B, int A) {      // bcount [scan workgroups][2]
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
-    return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
+    return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 3 * (size_t)B * A * 16;
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
@@ -766,17 +774,18 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
     int* box = (int*)base; base += (size_t)B * A * 16;
-    int* nbox = (int*)base;
+    int* nbox = (int*)base; base += (size_t)B * A * 16;
+    int4* dense_box = (int4*)base;
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                           conf_thr, dense, bcount);
+                           conf_thr, anchors, dense, dense_box, bcount);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
-    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense; a.dense_box = dense_box;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
     ProfScope prof("detect_image", 0.0, 0.0, s);
     hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);

@@ -1550,6 +1550,18 @@ static int pick_tile_h(long long M, int N, int mode) {
         const double cost = (double)((wgs + slots - 1) / slots) * bm[c] * bn[c] * per_cu[c] / eff[c];
         if (cost < bc * 0.999) { bc = cost; best = c; }
     }
+    // A/B switch (default off until measured): a launch of at most one workgroup per CU is latency-bound by its serial k
+    // loop with ONE tile in flight (the tail conv8_1 ... conv11_2 and the small maps' heads: matrix-pipe duty 0.17); the
+    // same tile with 3 / 4 pipeline stages keeps two or three tiles in flight -- LDS is no constraint when a CU holds
+    // a single workgroup.
+    static const int small_deep = env_int("SSD_SMALL_DEEP", 0);
+    if (small_deep) {
+        const long long wgs = (long long)cdiv(M, bm[best]) * cdiv(N, bn[best]);
+        if (wgs <= 256 * small_deep) {
+            if (best == 0) best = 4;           // 128x128 x4
+            else if (best == 1) best = 5;      // 128x64 x3
+        }
+    }
     return best;
 }
 

@@ -118,6 +118,8 @@ public:
     const DetectSlot& detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out);
     // host copy of the latest (which = 0) or the previous (which = 1) pass; waits for that slot's copy only
     void detect_fetch(int which, int* count, float* conf, int* cls, int* idx, int* box);
+    // the pinned host mirror of that slot itself (valid until the second-next pass); waits for the slot's copy only
+    void detect_host(int which, DetectOut* host, int* b, int* out_cap);
 
     const Preset& preset() const { return *preset_; }
     int num_classes() const { return C_; }

@@ -1040,6 +1040,17 @@ void Net::detect_fetch(int which, int* count, float* conf, int* cls, int* idx, i
     if (box) memcpy(box, h.box, n * 16);
 }
 
+void Net::detect_host(int which, DetectOut* host, int* b, int* out_cap) {
+    SSD_REQUIRE(which == 0 || which == 1, "which must be 0 (latest) or 1 (the one before)");
+    SSD_REQUIRE(host != nullptr, "null argument");
+    DetectSlot& sl = det_slot_[det_cur_ ^ which];
+    SSD_REQUIRE(sl.ready != nullptr && sl.b > 0, "no detection pass in that slot");
+    HIP_OK(hipEventSynchronize(sl.ready));
+    detect_slot_carve(sl, *host, sl.host);
+    if (b) *b = sl.b;
+    if (out_cap) *out_cap = sl.out_cap;
+}
+
 void Net::detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls,
                       int* idx, int* box) {
     detect_last_dev(b, thr, cap, max_out, out_cap, nms, nullptr);

@@ -33,6 +33,32 @@ class _Token:
         return f'<ssd token {self.name}>'
 
 
+class _DetectionList:
+    """The detections of one pass as a sequence of per-image dicts {conf, cls, idx, box} (what detect_last returned as
+    a list).  The arrays are VIEWS of the handle's pinned host mirror of that pass: an image's dict is built when it
+    is indexed, so collecting a batch costs the host one event wait and no per-image work it does not ask for.  Valid
+    until the second-next pass is launched (two slots alternate); copy what must live longer."""
+
+    def __init__(self, count, conf, cls, idx, box, out_cap):
+        self.count, self.conf, self.cls, self.idx, self.box, self.out_cap = count, conf, cls, idx, box, out_cap
+
+    def __len__(self):
+        return len(self.count)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        n = min(int(self.count[i]), self.out_cap)
+        return dict(conf=self.conf[i, :n], cls=self.cls[i, :n], idx=self.idx[i, :n], box=self.box[i, :n])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class _Detections:
     """Ticket of SSDVGG.detect_last_launch."""
     def __init__(self, net, serial, b, out_cap):
@@ -42,13 +68,17 @@ class _Detections:
         which = self.net._det_serial - self.serial
         if which not in (0, 1):
             raise RuntimeError('these detections were overwritten: only the two most recent passes are kept')
-        b, out_cap = self.b, self.out_cap
-        count = np.zeros(b, np.int32); conf = np.zeros((b, out_cap), np.float32)
-        cls = np.zeros((b, out_cap), np.int32); idx = np.zeros((b, out_cap), np.int32)
-        box = np.zeros((b, out_cap, 4), np.int32)
-        check(lib.ssd_detect_fetch(self.net._h, which, np_ptr(count), np_ptr(conf), np_ptr(cls), np_ptr(idx), np_ptr(box)))
-        return [dict(conf=conf[i, :min(count[i], out_cap)], cls=cls[i, :min(count[i], out_cap)],
-                     idx=idx[i, :min(count[i], out_cap)], box=box[i, :min(count[i], out_cap)]) for i in range(b)]
+        ptrs = [C.c_void_p() for _ in range(5)]
+        b = C.c_int(); out_cap = C.c_int()
+        check(lib.ssd_detect_host(self.net._h, which, *[C.byref(p) for p in ptrs], C.byref(b), C.byref(out_cap)))
+        b, oc = b.value, out_cap.value
+
+        def view(p, ctype, dtype, shape):
+            n = int(np.prod(shape))
+            return np.frombuffer((ctype * n).from_address(p.value), dtype=dtype).reshape(shape)
+        return _DetectionList(view(ptrs[0], C.c_int, np.int32, (b,)), view(ptrs[1], C.c_float, np.float32, (b, oc)),
+                              view(ptrs[2], C.c_int, np.int32, (b, oc)), view(ptrs[3], C.c_int, np.int32, (b, oc)),
+                              view(ptrs[4], C.c_int, np.int32, (b, oc, 4)), oc)
 
 
 class LearningRate:
@@ -448,7 +478,8 @@ class SSDVGG:
 
     def detect_last(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):
         """decode + NMS of the last step's result without leaving the GPU (train.py:275-277)."""
-        return self.detect_last_launch(b, confidence_threshold, detections_cap, max_out, nms).get()
+        # (copies: a caller of this synchronous form may keep the result across any number of later passes)
+        return [{k: v.copy() for k, v in d.items()} for d in self.detect_last_launch(b, confidence_threshold, detections_cap, max_out, nms).get()]
 
     # ------------------------------------------------------------------ Session.run routing
     def _run(self, fetches, feed):
