@@ -650,9 +650,9 @@ def main():
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
-    ap.add_argument('--force-collectives', action='store_true',
+    ap.add_argument('--force-collectives', action='store_true', default=os.environ.get('SSD_BENCH_FORCE_COLLECTIVES', '0') == '1',
                     help='one GPU: run the data-parallel step (staged backward + bucketed all-reduce on a single-rank RCCL group) to price its plumbing')
-    ap.add_argument('--bucket-mb', type=float, default=16, help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    ap.add_argument('--bucket-mb', type=float, default=float(os.environ.get('SSD_BENCH_BUCKET_MB', 16)), help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     ap.add_argument('--allow-fallback', action='store_true', help='N > 1: downgrade a failing bucketed all-reduce to a single one / report diverged replicas instead of aborting')
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')

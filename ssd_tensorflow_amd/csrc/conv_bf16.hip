@@ -1550,11 +1550,12 @@ static int pick_tile_h(long long M, int N, int mode) {
         const double cost = (double)((wgs + slots - 1) / slots) * bm[c] * bn[c] * per_cu[c] / eff[c];
         if (cost < bc * 0.999) { bc = cost; best = c; }
     }
-    // A/B switch (default off until measured): a launch of at most one workgroup per CU is latency-bound by its serial k
-    // loop with ONE tile in flight (the tail conv8_1 ... conv11_2 and the small maps' heads: matrix-pipe duty 0.17); the
-    // same tile with 3 / 4 pipeline stages keeps two or three tiles in flight -- LDS is no constraint when a CU holds
-    // a single workgroup.
-    static const int small_deep = env_int("SSD_SMALL_DEEP", 0);
+    // A launch of at most one workgroup per CU is latency-bound by its serial k loop with ONE tile in flight (the tail
+    // conv8_1 ... conv11_2 and the small maps' heads: matrix-pipe duty 0.17); the same tile with 3 / 4 pipeline stages
+    // keeps two or three tiles in flight -- LDS is no constraint when a CU holds a single workgroup.  Measured on one
+    // box, two interleaved repetitions (profiles/r03_a_ab_small_deep_bf16.txt): step 7.591 / 7.561 -> 7.499 / 7.512 ms
+    // (+0.9 %); up to two workgroups per CU (value 2): 7.580 / 7.600, no gain.  SSD_SMALL_DEEP=0 switches it off.
+    static const int small_deep = env_int("SSD_SMALL_DEEP", 1);
     if (small_deep) {
         const long long wgs = (long long)cdiv(M, bm[best]) * cdiv(N, bn[best]);
         if (wgs <= 256 * small_deep) {

@@ -63,7 +63,8 @@ struct DetectSlot {
     char* host = nullptr;
     size_t bytes = 0, used = 0;
     int b = 0, out_cap = 0;
-    hipEvent_t ready = nullptr;     // recorded behind the device-to-host copy
+    bool mapped = false;            // dev IS the device's view of the pinned host buffer (no HBM copy, no transfer)
+    hipEvent_t ready = nullptr;     // recorded behind the pass (behind the device-to-host copy when !mapped)
 };
 
 class Net {
@@ -90,6 +91,10 @@ public:
     std::vector<std::pair<size_t, size_t>> backward_ranges(size_t min_floats) const;
     void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
+    // the update of ONE range of the arena on a caller's stream (a data-parallel caller updates every bucket behind its
+    // all-reduce while backward still runs); finish_step() then counts the step once every range has been applied
+    void apply_gradients_range(size_t off, size_t count, float grad_scale, hipStream_t s);
+    void finish_step() { ++global_step; }
     void backward_apply(int b, const float* y, float grad_scale);      // backward + update, the optimizer overlapped with backward's tail
     void set_loss_normalizer(float bnorm) { loss_bnorm_ = bnorm; }      // <= 0: every step's own batch size
     void null_gradients_step();                                         // gradient arena of a step without samples

@@ -390,7 +390,7 @@ Net::~Net() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (DetectSlot& sl : det_slot_) {
-        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.dev && !sl.mapped) (void)hipFree(sl.dev);
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.ready) (void)hipEventDestroy(sl.ready);
     }
@@ -811,6 +811,15 @@ void Net::apply_gradients(float grad_scale) {
     ++global_step;
 }
 
+void Net::apply_gradients_range(size_t off, size_t count, float grad_scale, hipStream_t s) {
+    SSD_REQUIRE(training_, "handle was created with training = 0");
+    SSD_REQUIRE(off % 4 == 0 && count % 4 == 0 && off + count <= nparams_, "range [%zu, +%zu) outside the arena or not a multiple of 4", off, count);
+    if (count == 0) return;
+    g_prof = &prof_;
+    prof_.layer = "optimizer";
+    momentum_update(params_ + off, mom_ + off, grads_ + off, count, current_lr(), momentum_, grad_scale, s);
+}
+
 // backward + update of a single-GPU step with the optimizer overlapped: the filter region of the arena completes from its
 // end (heads, conv11 ... conv1), so once the bulk of it is final its momentum update runs on the weight-gradient stream
 // beside the data gradients of the first layers; only the small remainder (conv1_x / conv2_x filters, biases, scale) is
@@ -1002,15 +1011,29 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     } else {
         HIP_OK(hipEventSynchronize(sl.ready));      // the slot's previous copy must have landed before it is reused
     }
+    // The survivors (a few hundred KB per batch, only count-many entries per image are written) go STRAIGHT into pinned,
+    // device-mapped host memory from the per-image kernel's ordered emit -- like the four losses (alloc()): a
+    // device-to-host copy of the whole [b][out_cap] arrays is a blit KERNEL of its own behind the pass (13 us per batch of
+    // 128 in the rocprofv3 trace, a third of the pass) plus one more launch for the host to issue.  SSD_DETECT_MAPPED=0
+    // keeps the HBM arrays + copy (A/B switch).
+    static const bool mapped = [] { const char* v = getenv("SSD_DETECT_MAPPED"); return !(v && v[0] == '0'); }();
     const size_t need = det_count_bytes(b) + (size_t)b * out_cap * 28;
     if (need > sl.bytes) {
-        if (sl.dev) HIP_OK(hipFree(sl.dev));
+        if (sl.dev && !sl.mapped) HIP_OK(hipFree(sl.dev));
         if (sl.host) HIP_OK(hipHostFree(sl.host));
         sl.dev = sl.host = nullptr;
         sl.bytes = 0;
         const size_t grow = std::max(need, det_count_bytes(Bmax_) + (size_t)Bmax_ * std::min(out_cap, 200) * 28);
-        HIP_OK(hipMalloc((void**)&sl.dev, grow));
-        HIP_OK(hipHostMalloc((void**)&sl.host, grow));
+        sl.mapped = mapped;
+        if (mapped) {
+            HIP_OK(hipHostMalloc((void**)&sl.host, grow, hipHostMallocMapped));
+            void* dp = nullptr;
+            HIP_OK(hipHostGetDevicePointer(&dp, sl.host, 0));
+            sl.dev = static_cast<char*>(dp);
+        } else {
+            HIP_OK(hipMalloc((void**)&sl.dev, grow));
+            HIP_OK(hipHostMalloc((void**)&sl.host, grow));
+        }
         sl.bytes = grow;
     }
     sl.b = b; sl.out_cap = out_cap; sl.used = need;
@@ -1019,7 +1042,7 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     DetectOut d;
     detect_slot_carve(sl, d, sl.dev);
     detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
-    HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
+    if (!sl.mapped) HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipEventRecord(sl.ready, stream_));
     if (dev_out) *dev_out = d;
     return sl;

@@ -72,13 +72,20 @@ class _Detections:
         b = C.c_int(); out_cap = C.c_int()
         check(lib.ssd_detect_host(self.net._h, which, *[C.byref(p) for p in ptrs], C.byref(b), C.byref(out_cap)))
         b, oc = b.value, out_cap.value
+        key = (ptrs[0].value, ptrs[4].value, b, oc)
+        views = self.net._det_views.get(key)
+        if views is None:      # the slots' host arrays move only when a slot grows: the numpy views are built once per layout
 
-        def view(p, ctype, dtype, shape):
-            n = int(np.prod(shape))
-            return np.frombuffer((ctype * n).from_address(p.value), dtype=dtype).reshape(shape)
-        return _DetectionList(view(ptrs[0], C.c_int, np.int32, (b,)), view(ptrs[1], C.c_float, np.float32, (b, oc)),
-                              view(ptrs[2], C.c_int, np.int32, (b, oc)), view(ptrs[3], C.c_int, np.int32, (b, oc)),
-                              view(ptrs[4], C.c_int, np.int32, (b, oc, 4)), oc)
+            def view(p, ctype, dtype, shape):
+                n = int(np.prod(shape))
+                return np.frombuffer((ctype * n).from_address(p.value), dtype=dtype).reshape(shape)
+            views = (view(ptrs[0], C.c_int, np.int32, (b,)), view(ptrs[1], C.c_float, np.float32, (b, oc)),
+                     view(ptrs[2], C.c_int, np.int32, (b, oc)), view(ptrs[3], C.c_int, np.int32, (b, oc)),
+                     view(ptrs[4], C.c_int, np.int32, (b, oc, 4)))
+            if len(self.net._det_views) > 8:
+                self.net._det_views.clear()
+            self.net._det_views[key] = views
+        return _DetectionList(*views, oc)
 
 
 class LearningRate:
@@ -434,6 +441,19 @@ class SSDVGG:
     def apply_gradients_dev(self, grad_scale=1.0):
         check(lib.ssd_apply_gradients_dev(self._h, float(grad_scale)))
 
+    def apply_gradients_range_dev(self, off, count, grad_scale, stream_ptr):
+        check(lib.ssd_apply_gradients_range_dev(self._h, int(off), int(count), float(grad_scale), stream_ptr))
+
+    def finish_step_dev(self):
+        check(lib.ssd_finish_step_dev(self._h))
+
+    def use_torch_comm_stream(self):
+        """A torch-owned stream for a data-parallel caller's collectives and per-bucket updates (parallel.train_step_dp)."""
+        import torch
+        if getattr(self, 'comm_stream', None) is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        return self.comm_stream
+
     def train_step_dev(self, x_t, y_t):
         check(lib.ssd_train_step_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))
 
@@ -474,6 +494,8 @@ class SSDVGG:
         check(lib.ssd_detect_last_dev(self._h, b, float(confidence_threshold), cap, mo, out_cap, 1 if nms else 0,
                                       None, None, None, None, None))
         self._det_serial = getattr(self, '_det_serial', 0) + 1
+        if not hasattr(self, '_det_views'):
+            self._det_views = {}
         return _Detections(self, self._det_serial, b, out_cap)
 
     def detect_last(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):

@@ -181,7 +181,24 @@ class _WorkerPool:
             if not w.is_alive():
                 raise RuntimeError('a feeder worker process died (exit code %s)' % (w.exitcode,))
 
+    def unpin(self):
+        """Before the slots' memory goes away: a registration that outlives its pages poisons whatever the allocator
+        maps at that address next (a later hipMemcpy from an ordinary buffer there fails with "invalid argument")."""
+        if not any(self.pinned):
+            self.pinned = []
+            return
+        import torch
+        rt = torch.cuda.cudart()
+        for a, ok in zip(self.results.array_pool, self.pinned):
+            if ok:
+                try:
+                    rt.cudaHostUnregister(a.ctypes.data)
+                except Exception:
+                    pass
+        self.pinned = []
+
     def close(self):
+        self.unpin()
         for _ in self.workers:
             try:
                 self.tasks.put(None)

@@ -39,8 +39,11 @@ def _net(b, w, dtype='f32'):
     return sess, net
 
 
-@pytest.mark.parametrize('overlap', [True, False])
-def test_bucketed_allreduce_over_rccl_equals_plain_step(nccl_group, overlap):
+@pytest.mark.parametrize('overlap,bucket_update', [(True, False), (False, False), (True, True), (False, True)])
+def test_bucketed_allreduce_over_rccl_equals_plain_step(nccl_group, overlap, bucket_update, monkeypatch):
+    """bucket_update: every bucket all-reduced and APPLIED on the communication stream while backward still runs
+    (SSD_DP_BUCKET_UPDATE), instead of one update after the last collective."""
+    monkeypatch.setattr(parallel, 'BUCKET_UPDATE', bucket_update)
     b = 2
     preset = ob.get_preset('vgg300')
     w = ref.init_params(preset, 20, seed=3, alive=True)
@@ -93,4 +96,16 @@ def test_loss_normalizer_and_null_gradients(nccl_group):
     net.null_gradients_dev()
     torch.cuda.synchronize()
     assert torch.equal(net.grads_flat, wd_term)
+    # an empty shard issues the collectives of the ranks that run backward: the same ranges, in the same order
+    staged = list(net.backward_ranges(4_000_000))
+    net.forward_dev(xt, yt)
+    assert staged == list(net.backward_staged(yt, b, 4_000_000)) and len(staged) >= 4
+    assert staged[0][0] + staged[0][1] == nf and staged[-1][0] == 0 and all(a[0] == c[0] + c[1] for a, c in zip(staged, staged[1:]))
+    for bucket in (0, 4_000_000):
+        p0 = net.params_flat.clone(); m0 = net.momentum_flat.clone(); step0 = net.global_step
+        parallel.train_step_dp(net, None, None, 1, bucket_floats=bucket, force_collectives=True, global_count=0)
+        torch.cuda.synchronize()
+        assert net.global_step == step0 + 1 and net.get_losses_step(0) == dict(total=0.0, localization=0.0, confidence=0.0, l2=0.0)
+        wd = 0.0005 * p0; wd[nf:] = 0
+        assert torch.allclose(net.momentum_flat, 0.9 * m0 + wd, rtol=1e-6, atol=1e-12)
     sess.close()

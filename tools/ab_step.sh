@@ -4,7 +4,7 @@
 TAG=${1:-ab}; DT=${2:-bf16}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-run() { env "$@" python bench.py --dtype $DT --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-events 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f img/s %7.3f ms' % (d['value'], d['ms_per_step']))"; }
+run() { env "$@" python bench.py --dtype $DT --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-events ${AB_FLAGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f img/s %7.3f ms' % (d['value'], d['ms_per_step']))"; }
 DEFAULT="SSD_NOP=1;SSD_EARLY_UPDATE=0;SSD_BW_SIDE=0;SSD_REDUCE_GROUPED=0;SSD_POOL_RECORD=0;SSD_EARLY_UPDATE=0 SSD_BW_SIDE=0 SSD_REDUCE_GROUPED=0 SSD_POOL_RECORD=0"
 IFS=';' read -ra CFGS <<< "${AB_CONFIGS:-$DEFAULT}"
 for rep in 1 2; do
