@@ -661,6 +661,7 @@ def main():
     ap.add_argument('--e2e-steps', type=int, default=0, help='train_e2e: steps per epoch (0 = 20 fp32 / 60 bf16)')
     ap.add_argument('--e2e-epochs', type=int, default=1, help='train_e2e: timed epochs')
     ap.add_argument('--e2e-serial-steps', type=int, default=3, help='train_e2e: steps of the serial-feeder comparison (0 = skip)')
+    ap.add_argument('--e2e-both', action='store_true', help='train_e2e: run both dtypes in this process')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end blocks of the default invocation')
     args = ap.parse_args()
 
@@ -701,6 +702,10 @@ def main():
 
     if args.mode == 'train_e2e':
         r = e2e(args.dtype)
+        if args.e2e_both:      # both dtypes in one process, as the default invocation runs them
+            r = {'f32' if args.dtype == 'f32' else 'bf16': r}
+            other = 'bf16' if args.dtype == 'f32' else 'f32'
+            r[other] = e2e(other)
         if rank == 0:
             _OUT.emit(json.dumps(r))
         return

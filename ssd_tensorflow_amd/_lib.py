@@ -78,8 +78,6 @@ SIGNATURES = {
     'ssd_infer': (i32, [handle, vp, i32, vp]),
     'ssd_forward_backward_dev': (i32, [handle, vp, vp, i32]),
     'ssd_apply_gradients_dev': (i32, [handle, f32]),
-    'ssd_apply_gradients_range_dev': (i32, [handle, sz, sz, f32, vp]),
-    'ssd_finish_step_dev': (i32, [handle]),
     'ssd_forward_dev': (i32, [handle, vp, vp, i32]),
     'ssd_backward_begin_dev': (i32, [handle, vp, i32]),
     'ssd_backward_next_dev': (i32, [handle, sz, i32, C.POINTER(sz), C.POINTER(sz), p_i32]),

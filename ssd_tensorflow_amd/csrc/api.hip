@@ -504,16 +504,6 @@ int ssd_apply_gradients_dev(ssd_handle h, float grad_scale) {
     n.apply_gradients(grad_scale);
     API_END
 }
-int ssd_apply_gradients_range_dev(ssd_handle h, size_t offset, size_t count, float grad_scale, void* stream) {
-    API_BEGIN_NET(h)
-    n.apply_gradients_range(offset, count, grad_scale, (hipStream_t)stream);
-    API_END
-}
-int ssd_finish_step_dev(ssd_handle h) {
-    API_BEGIN_NET(h)
-    n.finish_step();
-    API_END
-}
 int ssd_set_loss_normalizer(ssd_handle h, float batch) {
     API_BEGIN_NET(h)
     n.set_loss_normalizer(batch);

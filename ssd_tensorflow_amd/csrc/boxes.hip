@@ -255,6 +255,92 @@ void encode_labels(const Preset& p, int num_classes, const double* anchors, cons
 // the survivors stored from the first row of the segment on, their number in `bcount`.  A workgroup's rows
 // belong to at most two images (A >= 256): two segments, the second one starting at the image boundary.
 // No atomics (a per-image counter serialises in L2: 137 waves hit each address), no memset, deterministic.
+constexpr int SCAN_ROWS = 256;
+constexpr int SCAN_MAXV = 32;                       // nv <= 32
+constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
+
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          u64* __restrict__ dense, int* __restrict__ bcount) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    __shared__ int s_cnt[2][4];
+    const int total_rows = B * A;
+    const int r0 = blockIdx.x * SCAN_ROWS;
+    const int nrows = min(SCAN_ROWS, total_rows - r0);
+    const int nfl = nrows * nv;
+    const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
+    const int n4 = nfl >> 2;
+    // all of this thread's loads are issued before the first one is consumed
+    float4 v[SCAN_LOADS];
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_LOADS; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int img_first = r0 / A;
+    const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
+    u64 key = 0ull;
+    int half = 0;
+    if ((int)threadIdx.x < nrows) {
+        const float* r = rows + (size_t)threadIdx.x * nv;
+        const int nfg = nv - 5;                  // argmax excludes the background class
+        int best = 0;
+        float conf = r[0];
+        for (int c = 1; c < nfg; ++c)
+            if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
+        const int row = r0 + threadIdx.x;
+        half = row >= boundary ? 1 : 0;
+        const int a = row - (img_first + half) * A;
+        if (!(conf < thr))                        // the reference breaks at the first conf < thr
+            key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
+    }
+    const u64 bal0 = __ballot(key != 0ull && half == 0), bal1 = __ballot(key != 0ull && half == 1);
+    if (lane == 0) { s_cnt[0][wv] = __popcll(bal0); s_cnt[1][wv] = __popcll(bal1); }
+    __syncthreads();
+    int base = 0, tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) base += s_cnt[half][w];
+        tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
+    }
+    if (key != 0ull) {
+        const u64 bal = half ? bal1 : bal0;
+        dense[(size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    }
+    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
+}
+
+// descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
+__device__ void bitonic_desc(u64* keys, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if (up ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
 // decode_location under numpy>=2 promotion (x, y float32; w, h float64) followed by
 // normalize_box's integer box (utils.py:118-135; centre*1000 in f32, half extent cast to f32).
 __device__ __forceinline__ void decode_box(const float* loc, const double* an, int* o) {
@@ -288,105 +374,6 @@ __device__ __forceinline__ void decode_box(const float* loc, const double* an, i
     o[2] = (int)(ymin > lo ? ymin : lo); o[3] = (int)(ymax > lo ? ymax : lo);
 }
 
-constexpr int SCAN_ROWS = 256;
-constexpr int SCAN_MAXV = 32;                       // nv <= 32
-constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
-
-__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          const double* __restrict__ anchors, u64* __restrict__ dense,
-                                                          int4* __restrict__ dense_box, int* __restrict__ bcount) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];
-    __shared__ int s_cnt[2][4];
-    const int total_rows = B * A;
-    const int r0 = blockIdx.x * SCAN_ROWS;
-    const int nrows = min(SCAN_ROWS, total_rows - r0);
-    const int nfl = nrows * nv;
-    const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
-    const int n4 = nfl >> 2;
-    // all of this thread's loads are issued before the first one is consumed
-    float4 v[SCAN_LOADS];
-#pragma unroll
-    for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
-    }
-    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int img_first = r0 / A;
-    const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
-    u64 key = 0ull;
-    int half = 0;
-    int4 cbox = make_int4(0, 0, 0, 0);
-    if ((int)threadIdx.x < nrows) {
-        const float* r = rows + (size_t)threadIdx.x * nv;
-        const int nfg = nv - 5;                  // argmax excludes the background class
-        int best = 0;
-        float conf = r[0];
-        for (int c = 1; c < nfg; ++c)
-            if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-        const int row = r0 + threadIdx.x;
-        half = row >= boundary ? 1 : 0;
-        const int a = row - (img_first + half) * A;
-        if (!(conf < thr)) {                      // the reference breaks at the first conf < thr
-            key = ((u64)__float_as_uint(conf) << 32) | ((u64)(32767 - a) << 8) | (u64)best | (1ull << 7);
-            // The candidate's box is decoded HERE, where its row already sits in LDS: the per-image kernel then reads
-            // (key, box) pairs from one contiguous run instead of chasing the key's anchor into the prediction tensor
-            // and the anchor table (a dependent, scattered load per candidate on that latency-bound kernel's critical
-            // path, plus two f64 exponentials).  ~3 % of the rows are candidates: the arithmetic hides under this
-            // kernel's HBM stream.
-            int bx[4];
-            decode_box(r + (nv - 4), anchors + (size_t)a * 4, bx);
-            cbox = make_int4(bx[0], bx[1], bx[2], bx[3]);
-        }
-    }
-    const u64 bal0 = __ballot(key != 0ull && half == 0), bal1 = __ballot(key != 0ull && half == 1);
-    if (lane == 0) { s_cnt[0][wv] = __popcll(bal0); s_cnt[1][wv] = __popcll(bal1); }
-    __syncthreads();
-    int base = 0, tot0 = 0, tot1 = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wv) base += s_cnt[half][w];
-        tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
-    }
-    if (key != 0ull) {
-        const u64 bal = half ? bal1 : bal0;
-        const size_t at = (size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull));
-        dense[at] = key;
-        dense_box[at] = cbox;
-    }
-    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
-}
-
-// descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
-__device__ void bitonic_desc(u64* keys, int n2) {
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if (up ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int n) {
-    int p = 1;
-    while (p < n) p <<= 1;
-    return p;
-}
-
 // prop2abs(abs2prop(ints)) as non_maximum_suppression recomputes it (not the identity)
 __device__ __forceinline__ void nms_roundtrip(const int* b, int* o) {
     const double width = (double)(b[1] - b[0]), height = (double)(b[3] - b[2]);
@@ -407,22 +394,51 @@ __device__ __forceinline__ bool overlaps45(int x0, int x1, int y0, int y1, int a
 // Greedy NMS of one class segment (boxes in descending confidence) by one wave.  Segments of up to 64 boxes
 // live in registers: lane j holds box j, the pivot is broadcast with v_readlane, the survivors are a 64-bit
 // mask; no memory traffic in the loop.  Longer segments walk the boxes in LDS / global.
-__device__ __forceinline__ void nms_segment(const int4* nbox, volatile unsigned char* al, int s0, int len, int lane) {
+// `al` is a plain LDS pointer on purpose: a `volatile` one degrades to a generic pointer whose byte stores compile to
+// `flat_store_byte ... sc0 sc1` + `s_waitcnt vmcnt(0)` -- a system-scope store that took ~2 us EACH (three per wave here:
+// 6.3 of this kernel's 13.7 us at batch 128, SSD_DETECT_STAMPS=1); only the long-segment walk below, where lanes read flags
+// other lanes have just cleared, goes through a volatile alias.
+__device__ __forceinline__ void nms_segment(const int4* nbox, unsigned char* al_plain, int s0, int len, int lane) {
+    // The segment bounds come out of LDS, i.e. in vector registers: left there, the compiler treats the pivot loop as
+    // divergent (exec-mask bookkeeping, 64-bit vector shifts for the survivor mask, a v_readfirstlane per v_readlane) --
+    // ~420 cycles per pivot, 7.8 us of the 23 us this kernel took at batch 128 (SSD_DETECT_STAMPS=1).  They are wave
+    // uniform, so say so: the loop counter, the survivor mask and the pivot's coordinates then live in scalar registers.
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    len = __builtin_amdgcn_readfirstlane(len);
     if (len <= 64) {
         int4 me = make_int4(0, 0, 0, 0);
         if (lane < len) me = nbox[s0 + lane];
-        u64 alive = len == 64 ? ~0ull : ((1ull << len) - 1ull);
-        for (int i = 0; i < len; ++i) {
-            if (!((alive >> i) & 1ull)) continue;
+        // Phase A, no dependence between iterations, no branch: lane j collects the set of EARLIER boxes that overlap it
+        // (bit i of lo / hi).  The greedy walk "pivot i suppresses what it overlaps, if it is still alive itself" spent
+        // ~340 cycles per pivot on its serial chain (survivor mask -> branch -> 4 v_readlane -> compare -> ballot -> mask).
+        unsigned lo = 0u, hi = 0u;
+        const int n_lo = len < 32 ? len : 32;
+        for (int i = 0; i < n_lo; ++i) {
             const int x0 = __builtin_amdgcn_readlane(me.x, i), x1 = __builtin_amdgcn_readlane(me.y, i);
             const int y0 = __builtin_amdgcn_readlane(me.z, i), y1 = __builtin_amdgcn_readlane(me.w, i);
-            const int area_i = (x1 - x0 + 1) * (y1 - y0 + 1);
-            const bool kill = lane > i && lane < len && overlaps45(x0, x1, y0, y1, area_i, me);
-            alive &= ~__ballot(kill);
+            const bool ov = overlaps45(x0, x1, y0, y1, (x1 - x0 + 1) * (y1 - y0 + 1), me) & (lane > i);
+            lo |= ov ? (1u << i) : 0u;
         }
-        if (lane < len) al[s0 + lane] = (alive >> lane) & 1ull ? 1 : 0;
+        for (int i = 32; i < len; ++i) {
+            const int x0 = __builtin_amdgcn_readlane(me.x, i), x1 = __builtin_amdgcn_readlane(me.y, i);
+            const int y0 = __builtin_amdgcn_readlane(me.z, i), y1 = __builtin_amdgcn_readlane(me.w, i);
+            const bool ov = overlaps45(x0, x1, y0, y1, (x1 - x0 + 1) * (y1 - y0 + 1), me) & (lane > i);
+            hi |= ov ? (1u << (i - 32)) : 0u;
+        }
+        // Phase B: only boxes that overlap an earlier one can die.  In ascending order (the survivor bits below j are final
+        // when j's turn comes): j dies iff one of its earlier overlappers is alive.
+        u64 alive = len == 64 ? ~0ull : ((1ull << len) - 1ull);
+        u64 cand = __ballot(((lo | hi) != 0u) & (lane < len));
+        while (cand) {
+            const int j = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const u64 killers = ((u64)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)lo, j);
+            if (killers & alive) alive &= ~(1ull << j);
+        }
+        if (lane < len) al_plain[s0 + lane] = (alive >> lane) & 1ull ? 1 : 0;
         return;
     }
+    volatile unsigned char* al = al_plain;
     for (int i = 0; i < len; ++i) {
         if (!al[s0 + i]) continue;
         const int4 bi = nbox[s0 + i];
@@ -451,17 +467,24 @@ struct DetectArgs {
     int cap, max_out, out_cap, do_nms;
     const int* bcount;  // [scan workgroups][2] candidates per (workgroup, image) segment
     const u64* dense;   // [B*A] the segments' keys, compacted at each segment's first row
-    const int4* dense_box;   // [B*A] their decoded boxes (detect_scan_kernel), same positions
     u64* keys1;         // [B][A2] general path: the image's candidates gathered for the sort
     u64* keys2;
     int* box;       // [B][A][4]
     int* nbox;      // [B][A][4]
     DetectOut out;
+    unsigned long long* stamps;   // measurement aid (SSD_DETECT_STAMPS=1): workgroup 0's clock at each phase boundary
 };
+#define DET_STAMP(k)                                                                  \
+    do {                                                                              \
+        if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                        \
+            p.stamps[2 * (k)] = __builtin_readcyclecounter();                         \
+            p.stamps[2 * (k) + 1] = wall_clock64();                                   \
+        }                                                                             \
+    } while (0)
 
 // survivors in order -> the caller's arrays, clipped to [:max_out] / out_cap
 template <typename KeyAt, typename BoxAt>
-__device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, const volatile unsigned char* alive, KeyAt key_at,
+__device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, const unsigned char* alive, KeyAt key_at,
                                             BoxAt box_at, int* s_wtot) {
     const int tid = threadIdx.x;
     int limit = p.out_cap;
@@ -500,9 +523,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     __shared__ __attribute__((aligned(16))) unsigned char smem[DET_SMEM];
     __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
     __shared__ int s_npresent, s_wtot[DET_WAVES];
+    __shared__ u64 cmax[32];
+    __shared__ int bstart[32];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     u64* g1 = p.keys1 + (size_t)b * p.A2;
+    DET_STAMP(0);
     // ---- the image's candidate segments (one per scan workgroup that touched the image) ----------------
     __shared__ int seg_off[DET_MAX_SEGS + 1], seg_base[DET_MAX_SEGS];
     __shared__ int s_pos[DET_FAST], s_cpos[DET_FAST];
@@ -533,15 +559,15 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     }
     __syncthreads();
     const int n = seg_off[nseg];
-    auto candidate_at = [&](int f) -> size_t {      // where the f-th candidate of the image lies in dense / dense_box
+    DET_STAMP(1);
+    auto candidate = [&](int f) {            // f-th candidate of the image (any order: the keys are unique and get sorted)
         int lo = 0, hi = nseg - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (seg_off[mid] <= f) lo = mid; else hi = mid - 1;
         }
-        return (size_t)seg_base[lo] + (f - seg_off[lo]);
+        return p.dense[(size_t)seg_base[lo] + (f - seg_off[lo])];
     };
-    auto candidate = [&](int f) { return p.dense[candidate_at(f)]; };      // (any order: the keys are unique and get sorted)
 
     if (n <= DET_FAST) {
         // ================= everything in LDS: rank sort, decode, NMS, emit =================
@@ -549,20 +575,25 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         u64* okey = skey + DET_FAST;                                    // candidates in output order
         int4* box = reinterpret_cast<int4*>(okey + DET_FAST);
         int4* nbox = box + DET_FAST;
-        volatile unsigned char* alive = reinterpret_cast<unsigned char*>(nbox + DET_FAST);
+        unsigned char* alive = reinterpret_cast<unsigned char*>(nbox + DET_FAST);      // (not volatile: see nms_segment)
         // every candidate's key, then (addressed by the key's anchor) its offsets and anchor: all global loads of the
         // workgroup are in flight together and land while the ranking sweep below runs.  Indices are clamped instead of
         // predicated: a select on a loaded value would make each load wait in turn.
         constexpr int PER = DET_FAST / DET_THREADS;
         u64 mykey[PER];
-        int4 mybox[PER];
+        float loc[PER][4];
+        double anc[PER][4];
         int pos[PER], cpos[PER];
         if (n > 0) {
 #pragma unroll
+            for (int r = 0; r < PER; ++r) mykey[r] = candidate(min(tid + DET_THREADS * r, n - 1));
+#pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const size_t at = candidate_at(min(tid + DET_THREADS * r, n - 1));
-                mykey[r] = p.dense[at];
-                mybox[r] = p.dense_box[at];
+                const int a = 32767 - (int)((mykey[r] >> 8) & 0xFFFFull);
+                const float* lp = p.pred + ((size_t)b * p.A + a) * p.nv + (p.nv - 4);
+                const double* ap = p.anchors + (size_t)a * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { loc[r][e] = lp[e]; anc[r][e] = ap[e]; }
             }
         }
 #pragma unroll
@@ -574,8 +605,75 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         }
         if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
         __syncthreads();
+        DET_STAMP(2);      // candidates, offsets and anchors loaded
+        const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
+        // The output order is: class groups in first-appearance order of the confidence-sorted list (defaultdict,
+        // ssdutils.py:311-314) = classes by their best key, and inside a group by key.  When no cap bites (m == n, the
+        // inference setting infer.py:233-234; training's cap of 200 only above 200 candidates) the GLOBAL rank of a
+        // candidate is never needed: a counting sort by class and a rank inside the class' bucket (~n / 20 comparisons per
+        // candidate instead of n) replace the n x n sweep, which was 9.6 of this kernel's 23 us at batch 128.
+        const bool by_class = p.do_nms && m == n;
+        if (by_class) {
+            int myslot[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + DET_THREADS * r;
+                myslot[r] = i < n ? atomicAdd(&ccount[(int)(mykey[r] & 31ull)], 1) : 0;      // any order inside the bucket
+                pos[r] = 0;
+            }
+            __syncthreads();
+            if (tid < 64) {         // exclusive prefix of the class counts (raw class ids): where each bucket starts
+                const int v = tid < 32 ? ccount[tid] : 0;
+                int inc = v;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
+                }
+                if (tid < 32) bstart[tid] = inc - v;
+            }
+            __syncthreads();
+            u64* bkey = reinterpret_cast<u64*>(nbox);       // (nbox is written by the placement phase, two barriers on)
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + DET_THREADS * r;
+                if (i < n) bkey[bstart[(int)(mykey[r] & 31ull)] + myslot[r]] = mykey[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + DET_THREADS * r;
+                cpos[r] = 0;
+                if (i < n) {
+                    const u64 key = mykey[r];
+                    const int c = (int)(key & 31ull);
+                    const u64* bk = bkey + bstart[c];
+                    const int cnt = ccount[c];
+                    int cp = 0;
+                    for (int j = 0; j < cnt; ++j) cp += bk[j] > key ? 1 : 0;
+                    cpos[r] = cp;
+                    if (cp == 0) cmax[c] = key;      // the class' best key: one writer per class
+                }
+            }
+            __syncthreads();
+            DET_STAMP(3);      // ranking
+            if (tid < 64) {         // one lane per class: its rank among the present classes and where its segment starts
+                const bool present = tid < 32 && ccount[tid & 31] > 0;
+                const u64 mine = present ? cmax[tid & 31] : 0ull;
+                int r = 0, start = 0;
+                for (int c = 0; c < 32; ++c) {
+                    const bool before = ccount[c] > 0 && cmax[c] > mine;
+                    r += before ? 1 : 0;
+                    start += before ? ccount[c] : 0;
+                }
+                const int np = __popcll(__ballot(present));
+                if (tid < 32) crank[tid] = r;
+                if (present) segstart[r] = start;
+                if (tid == 0) { s_npresent = np; segstart[np] = m; }
+            }
+        } else {
         // Rank of every candidate among all (confidence descending, anchor ascending: keys are unique) and among those of
-        // its own class: the n x n comparison is the bulk of this kernel's arithmetic, so it is spread over ALL thread
+        // its own class: an n x n comparison, spread over ALL thread
         // slots -- with n candidates rounded up to n2 (a power of two) each candidate gets 1024 / n2 slots, each sweeping
         // its share of the list (every read an LDS broadcast); the partial counts meet in LDS.
         {
@@ -603,12 +701,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             }
         }
         __syncthreads();
+        DET_STAMP(3);      // ranking sweep
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             const int i = tid + DET_THREADS * r;
             pos[r] = s_pos[i]; cpos[r] = s_cpos[i];
         }
-        const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
         // class groups in first-appearance order (defaultdict, ssdutils.py:311-314)
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
@@ -636,7 +734,9 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
                 segstart[p.do_nms ? np : 0] = m;
             }
         }
+        }
         __syncthreads();
+        DET_STAMP(4);      // class groups
         // place, decode
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
@@ -644,7 +744,9 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             if (i < n && pos[r] < m) {
                 const u64 key = mykey[r];
                 const int q = p.do_nms ? segstart[crank[(int)(key & 31ull)]] + cpos[r] : pos[r];
-                int bx[4] = {mybox[r].x, mybox[r].y, mybox[r].z, mybox[r].w}, nb[4];
+                const int a = 32767 - (int)((key >> 8) & 0xFFFFull);
+                int bx[4], nb[4];
+                decode_box(loc[r], anc[r], bx);
                 nms_roundtrip(bx, nb);
                 okey[q] = key;
                 box[q] = make_int4(bx[0], bx[1], bx[2], bx[3]);
@@ -653,15 +755,18 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             }
         }
         __syncthreads();
+        DET_STAMP(5);      // decode
         for (int r = wave; r < s_npresent; r += DET_WAVES) nms_segment(nbox, alive, segstart[r], segstart[r + 1] - segstart[r], lane);
         __syncthreads();
+        DET_STAMP(6);      // NMS
         detect_emit(p, b, m, alive, [&](int q) { return okey[q]; }, [&](int q) { return box[q]; }, s_wtot);
+        DET_STAMP(7);      // emit
         return;
     }
 
     // ================= general path: bitonic sorts, boxes in (L2-resident) global memory =================
     u64* lkeys = reinterpret_cast<u64*>(smem);
-    volatile unsigned char* alive = smem + DET_LDS_KEYS * 8;
+    unsigned char* alive = smem + DET_LDS_KEYS * 8;
     u64* g2 = p.keys2 + (size_t)b * p.A2;
     int4* box = reinterpret_cast<int4*>(p.box + (size_t)b * p.A * 4);
     int4* nbox = reinterpret_cast<int4*>(p.nbox + (size_t)b * p.A * 4);
@@ -756,7 +861,7 @@ static size_t det_head_bytes(int B, int A) {      // bcount [scan workgroups][2]
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
-    return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 3 * (size_t)B * A * 16;
+    return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
@@ -774,22 +879,43 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
     int* box = (int*)base; base += (size_t)B * A * 16;
-    int* nbox = (int*)base; base += (size_t)B * A * 16;
-    int4* dense_box = (int4*)base;
+    int* nbox = (int*)base;
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
     {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
-                           conf_thr, anchors, dense, dense_box, bcount);
+                           conf_thr, dense, bcount);
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
-    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense; a.dense_box = dense_box;
+    a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
-    ProfScope prof("detect_image", 0.0, 0.0, s);
-    hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
+    static const bool stamps_on = [] { const char* v = getenv("SSD_DETECT_STAMPS"); return v && v[0] == '1'; }();
+    static unsigned long long* stamps_dev = nullptr;
+    if (stamps_on && !stamps_dev) {
+        HIP_OK(hipMalloc((void**)&stamps_dev, 16 * 2 * sizeof(unsigned long long)));
+        HIP_OK(hipMemset(stamps_dev, 0, 16 * 2 * sizeof(unsigned long long)));
+    }
+    a.stamps = stamps_on ? stamps_dev : nullptr;
+    {
+        ProfScope prof("detect_image", 0.0, 0.0, s);
+        hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
+    }
     HIP_OK(hipGetLastError());
+    if (stamps_on) {      // measurement aid: workgroup 0's shader cycles / 100 MHz ticks per phase of the LDS path
+        static int calls = 0;
+        if (++calls % 64 == 0) {
+            unsigned long long h[16];
+            HIP_OK(hipStreamSynchronize(s));
+            HIP_OK(hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost));
+            static const char* const names[7] = {"segments", "loads", "rank", "classes", "decode", "nms", "emit"};
+            fprintf(stderr, "[detect stamps]");
+            for (int k = 1; k < 8; ++k)
+                fprintf(stderr, " %s %llu cyc %.2f us;", names[k - 1], h[2 * k] - h[2 * k - 2], (double)(h[2 * k + 1] - h[2 * k - 1]) / 100.0);
+            fprintf(stderr, " total %.2f us\n", (double)(h[15] - h[1]) / 100.0);
+        }
+    }
 }
 
 // =================================================================================

@@ -91,10 +91,6 @@ public:
     std::vector<std::pair<size_t, size_t>> backward_ranges(size_t min_floats) const;
     void set_wgrad_stream(hipStream_t s);      // caller-owned side stream for the weight gradients
     void apply_gradients(float grad_scale);
-    // the update of ONE range of the arena on a caller's stream (a data-parallel caller updates every bucket behind its
-    // all-reduce while backward still runs); finish_step() then counts the step once every range has been applied
-    void apply_gradients_range(size_t off, size_t count, float grad_scale, hipStream_t s);
-    void finish_step() { ++global_step; }
     void backward_apply(int b, const float* y, float grad_scale);      // backward + update, the optimizer overlapped with backward's tail
     void set_loss_normalizer(float bnorm) { loss_bnorm_ = bnorm; }      // <= 0: every step's own batch size
     void null_gradients_step();                                         // gradient arena of a step without samples

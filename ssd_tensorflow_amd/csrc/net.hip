@@ -811,15 +811,6 @@ void Net::apply_gradients(float grad_scale) {
     ++global_step;
 }
 
-void Net::apply_gradients_range(size_t off, size_t count, float grad_scale, hipStream_t s) {
-    SSD_REQUIRE(training_, "handle was created with training = 0");
-    SSD_REQUIRE(off % 4 == 0 && count % 4 == 0 && off + count <= nparams_, "range [%zu, +%zu) outside the arena or not a multiple of 4", off, count);
-    if (count == 0) return;
-    g_prof = &prof_;
-    prof_.layer = "optimizer";
-    momentum_update(params_ + off, mom_ + off, grads_ + off, count, current_lr(), momentum_, grad_scale, s);
-}
-
 // backward + update of a single-GPU step with the optimizer overlapped: the filter region of the arena completes from its
 // end (heads, conv11 ... conv1), so once the bulk of it is final its momentum update runs on the weight-gradient stream
 // beside the data gradients of the first layers; only the small remainder (conv1_x / conv2_x filters, biases, scale) is

@@ -90,11 +90,6 @@ def mean_scalars(values, world, device=None):
     return (t / world).tolist()
 
 
-# A/B switch: 1 = all-reduce + update per bucket on a communication stream (see train_step_dp); 0 = collectives enqueued
-# behind the weight-gradient stream, ONE update after the last of them
-BUCKET_UPDATE = os.environ.get('SSD_DP_BUCKET_UPDATE', '0') != '0'
-
-
 def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, force_collectives=False):
     """One data-parallel step on this rank's shard (device tensors).
 
@@ -141,31 +136,6 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
             else:
                 net.forward_dev(x_dev, y_dev)
                 ranges = net.backward_staged(y_dev, b, bucket_floats, sync_main=False)
-            if BUCKET_UPDATE:
-                # Every bucket is all-reduced AND applied on a communication stream of its own, behind an event of the
-                # weight-gradient stream: neither that stream (the next layers' weight gradients) nor the main one (the
-                # data gradients) ever waits for a collective, and the optimizer's pass over the arena (5 x 105 MB of
-                # HBM traffic) runs in pieces beside backward instead of after the last all-reduce.
-                comm = net.use_torch_comm_stream()
-                cur = torch.cuda.current_stream(side.device)
-                scale = 1.0 / world
-                for off, cnt in ranges:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(ev)
-                        dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True).wait()
-                        net.apply_gradients_range_dev(off, cnt, scale, comm.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(cur)              # the last stage has joined the streams: the bias / scale tail is final
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev)
-                    tail = net.arena_floats - net.filter_floats
-                    dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True).wait()
-                    net.apply_gradients_range_dev(net.filter_floats, tail, scale, comm.cuda_stream)
-                cur.wait_stream(comm)       # the next step reads the parameters / rewrites the gradients
-                net.finish_step_dev()
-                return
             works = []
             for off, cnt in ranges:
                 with torch.cuda.stream(side):

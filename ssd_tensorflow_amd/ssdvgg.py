@@ -441,19 +441,6 @@ class SSDVGG:
     def apply_gradients_dev(self, grad_scale=1.0):
         check(lib.ssd_apply_gradients_dev(self._h, float(grad_scale)))
 
-    def apply_gradients_range_dev(self, off, count, grad_scale, stream_ptr):
-        check(lib.ssd_apply_gradients_range_dev(self._h, int(off), int(count), float(grad_scale), stream_ptr))
-
-    def finish_step_dev(self):
-        check(lib.ssd_finish_step_dev(self._h))
-
-    def use_torch_comm_stream(self):
-        """A torch-owned stream for a data-parallel caller's collectives and per-bucket updates (parallel.train_step_dp)."""
-        import torch
-        if getattr(self, 'comm_stream', None) is None:
-            self.comm_stream = torch.cuda.Stream(device=self.device)
-        return self.comm_stream
-
     def train_step_dev(self, x_t, y_t):
         check(lib.ssd_train_step_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))
 

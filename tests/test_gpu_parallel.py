@@ -39,11 +39,8 @@ def _net(b, w, dtype='f32'):
     return sess, net
 
 
-@pytest.mark.parametrize('overlap,bucket_update', [(True, False), (False, False), (True, True), (False, True)])
-def test_bucketed_allreduce_over_rccl_equals_plain_step(nccl_group, overlap, bucket_update, monkeypatch):
-    """bucket_update: every bucket all-reduced and APPLIED on the communication stream while backward still runs
-    (SSD_DP_BUCKET_UPDATE), instead of one update after the last collective."""
-    monkeypatch.setattr(parallel, 'BUCKET_UPDATE', bucket_update)
+@pytest.mark.parametrize('overlap', [True, False])
+def test_bucketed_allreduce_over_rccl_equals_plain_step(nccl_group, overlap):
     b = 2
     preset = ob.get_preset('vgg300')
     w = ref.init_params(preset, 20, seed=3, alive=True)
