@@ -183,10 +183,21 @@ static void encode_labels_impl(const char* preset, int num_classes, int device, 
     std::lock_guard<std::mutex> lock(ec.mu);
     EncodeCache::Anchors& an = ec.anchors[{p.name, device}];
     if (!an.anc) {
-        HIP_OK(hipMalloc((void**)&an.anc, A * 4 * sizeof(double)));
-        HIP_OK(hipMalloc((void**)&an.aabs, A * 4 * sizeof(int)));
-        anchors_device(p, an.anc, an.aabs, nullptr);
-        HIP_OK(hipDeviceSynchronize());
+        // built into locals and published only once complete: a failure half way must not leave a table that looks ready
+        double* anc = nullptr;
+        int* aabs = nullptr;
+        try {
+            HIP_OK(hipMalloc((void**)&anc, A * 4 * sizeof(double)));
+            HIP_OK(hipMalloc((void**)&aabs, A * 4 * sizeof(int)));
+            anchors_device(p, anc, aabs, nullptr);
+            HIP_OK(hipDeviceSynchronize());
+        } catch (...) {
+            if (anc) (void)hipFree(anc);
+            if (aabs) (void)hipFree(aabs);
+            throw;
+        }
+        an.aabs = aabs;
+        an.anc = anc;
     }
     const size_t nt = ntot ? ntot : 1;
     const size_t n = (size_t)b * A * (num_classes + 5);
@@ -204,14 +215,19 @@ static void encode_labels_impl(const char* preset, int num_classes, int device, 
     double* dgt = (double*)(sc.p + o_gt);
     int* dcls = (int*)(sc.p + o_cls);
     int* doff = (int*)(sc.p + o_off);
-    if (ntot) {
-        HIP_OK(hipMemcpyAsync(dgt, gt, (size_t)ntot * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_OK(hipMemcpyAsync(dcls, cls, (size_t)ntot * sizeof(int), hipMemcpyHostToDevice, s));
-    }
-    HIP_OK(hipMemcpyAsync(doff, offsets, (size_t)(b + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     float* out = vec_dev ? vec_dev : (float*)(sc.p + o_tmp);
-    encode_labels(p, num_classes, an.anc, an.aabs, dgt, dcls, doff, b, ntot, out, sc.p + o_ws, s);
-    if (vec_host) HIP_OK(hipMemcpyAsync(vec_host, out, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    try {
+        if (ntot) {
+            HIP_OK(hipMemcpyAsync(dgt, gt, (size_t)ntot * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_OK(hipMemcpyAsync(dcls, cls, (size_t)ntot * sizeof(int), hipMemcpyHostToDevice, s));
+        }
+        HIP_OK(hipMemcpyAsync(doff, offsets, (size_t)(b + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        encode_labels(p, num_classes, an.anc, an.aabs, dgt, dcls, doff, b, ntot, out, sc.p + o_ws, s);
+        if (vec_host) HIP_OK(hipMemcpyAsync(vec_host, out, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    } catch (...) {
+        (void)hipStreamSynchronize(s);   // nothing of this call may still be using the shared scratch when the lock is released
+        throw;
+    }
     HIP_OK(hipStreamSynchronize(s));     // the shared scratch is free for the next call
 }
 

@@ -1669,7 +1669,10 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
     }
     // (multibox heads of the small maps: a handful of workgroups, latency-bound -- the per-tap kernel's shorter units win:
     // head of the 10x10 map 45 -> 36 us, gpurun r02_b heads_tiles_bf16)
-    if (gather_rows_applicable(d, false) && d.Co >= 128 && !(y_f32 && a.M < 4096)) {
+    // A/B switch: the fp32-out layers (multibox heads) below this many pixels take the per-tap kernel; 4096 keeps the
+    // 19x19 map's head (M = 11552, N = 152: 182 kernel-row workgroups, 281 TFLOP/s) on the kernel-row gather
+    static const int heads_rows_min_m = env_int("SSD_HEADS_ROWS_MIN_M", 4096);
+    if (gather_rows_applicable(d, false) && d.Co >= 128 && !(y_f32 && a.M < heads_rows_min_m)) {
         if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
         else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
         return;

@@ -73,5 +73,21 @@ def test_apcalculator_mirror():
                            rt(g[f'gt_box_{c}']).astype(np.float64), g[f'gt_cls_{c}'], g[f'gt_sample_{c}'])
     assert {int(k[1:]): v for k, v in aps.items()} == want
     assert apm.APs2mAP(aps) == oap.aps2map(want)
+    # data parallel (train.py gathered_aps): every rank's state() merged on rank 0 gives the AP of the whole sample --
+    # here the samples are dealt to three "ranks" round-robin and merged in rank order
+    import pickle
+    states = [dict(det_params=[], det_confidence=[], det_labels=[], det_sample_ids=[], gt_boxes=[]) for _ in range(3)]
+    for s in range(ns):
+        st = states[s % 3]
+        local = len(st['gt_boxes'])
+        st['gt_boxes'].append(calc.gt_boxes[s])
+        for pr, cf, l, sm in zip(calc.det_params, calc.det_confidence, calc.det_labels, calc.det_sample_ids):
+            if sm == s:
+                st['det_params'].append(pr); st['det_confidence'].append(cf); st['det_labels'].append(l); st['det_sample_ids'].append(local)
+    merged = apm.APCalculator()
+    for st in states:
+        merged.merge(pickle.loads(pickle.dumps(st)))
+    assert merged.compute_aps() == aps
+    assert len(merged.gt_boxes) == ns and len(merged.det_confidence) == len(calc.det_confidence)
     calc.clear()
     assert calc.compute_aps() == {}
