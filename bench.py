@@ -657,7 +657,7 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline block = null)')
-    ap.add_argument('--e2e-workers', type=int, default=0, help='train_e2e: feeder worker processes (0 = 4)')
+    ap.add_argument('--e2e-workers', type=int, default=0, help='train_e2e: feeder worker processes (0 = 8)')
     ap.add_argument('--e2e-steps', type=int, default=0, help='train_e2e: steps per epoch (0 = 20 fp32 / 60 bf16)')
     ap.add_argument('--e2e-epochs', type=int, default=1, help='train_e2e: timed epochs')
     ap.add_argument('--e2e-serial-steps', type=int, default=3, help='train_e2e: steps of the serial-feeder comparison (0 = skip)')
@@ -696,7 +696,7 @@ def main():
     def e2e(dtype):
         sub = argparse.Namespace(**vars(args))
         sub.dtype = dtype
-        sub.e2e_workers = args.e2e_workers or 4
+        sub.e2e_workers = args.e2e_workers or 8
         sub.e2e_steps = args.e2e_steps or (60 if dtype == 'bf16' else 20)
         return run_train_e2e(sub, rank, world, local)
 

@@ -49,6 +49,8 @@ SIGNATURES = {
     'ssd_jaccard_overlap': (i32, [i32, vp, vp, i32, vp]),
     'ssd_encode_labels': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp]),
     'ssd_encode_labels_dev': (i32, [cstr, i32, i32, vp, vp, vp, i32, vp, vp]),
+    'ssd_encode_labels_ws_bytes': (sz, [i32]),
+    'ssd_encode_labels_resident': (i32, [cstr, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp]),
     'ssd_decode_nms': (i32, [cstr, i32, i32, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'ssd_decode_nms_ws_bytes': (sz, [cstr, i32]),
     'ssd_decode_nms_dev': (i32, [cstr, i32, vp, vp, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -168,19 +168,9 @@ int ssd_jaccard_overlap(int device, const double* box, const double* boxes, int 
     API_END
 }
 
-static void encode_labels_impl(const char* preset, int num_classes, int device, const double* gt, const int* cls,
-                               const int* offsets, int b, float* vec_dev, float* vec_host, hipStream_t s) {
-    const Preset& p = get_preset(preset);
-    SSD_REQUIRE(b >= 1, "batch must be >= 1");
-    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27");
-    DeviceGuard dev_guard_(device);
-    const int ntot = offsets[b];
-    SSD_REQUIRE(offsets[0] == 0 && ntot >= 0, "gt_offsets must start at 0 and be non-decreasing");
-    for (int i = 0; i < ntot; ++i)
-        SSD_REQUIRE(cls[i] >= 0 && cls[i] < num_classes, "gt_cls[%d] = %d outside 0..%d", i, cls[i], num_classes - 1);
+// the preset's anchor tables on `device`, built once (caller holds ec.mu)
+static EncodeCache::Anchors& encode_anchors(EncodeCache& ec, const Preset& p, int device) {
     const size_t A = p.num_anchors;
-    EncodeCache& ec = encode_cache();
-    std::lock_guard<std::mutex> lock(ec.mu);
     EncodeCache::Anchors& an = ec.anchors[{p.name, device}];
     if (!an.anc) {
         // built into locals and published only once complete: a failure half way must not leave a table that looks ready
@@ -199,6 +189,23 @@ static void encode_labels_impl(const char* preset, int num_classes, int device, 
         an.aabs = aabs;
         an.anc = anc;
     }
+    return an;
+}
+
+static void encode_labels_impl(const char* preset, int num_classes, int device, const double* gt, const int* cls,
+                               const int* offsets, int b, float* vec_dev, float* vec_host, hipStream_t s) {
+    const Preset& p = get_preset(preset);
+    SSD_REQUIRE(b >= 1, "batch must be >= 1");
+    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27");
+    DeviceGuard dev_guard_(device);
+    const int ntot = offsets[b];
+    SSD_REQUIRE(offsets[0] == 0 && ntot >= 0, "gt_offsets must start at 0 and be non-decreasing");
+    for (int i = 0; i < ntot; ++i)
+        SSD_REQUIRE(cls[i] >= 0 && cls[i] < num_classes, "gt_cls[%d] = %d outside 0..%d", i, cls[i], num_classes - 1);
+    const size_t A = p.num_anchors;
+    EncodeCache& ec = encode_cache();
+    std::lock_guard<std::mutex> lock(ec.mu);
+    EncodeCache::Anchors& an = encode_anchors(ec, p, device);
     const size_t nt = ntot ? ntot : 1;
     const size_t n = (size_t)b * A * (num_classes + 5);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -242,6 +249,28 @@ int ssd_encode_labels_dev(const char* preset, int num_classes, int device, const
                           const int* gt_offsets, int b, float* vec_out_dev, void* stream) {
     API_BEGIN
     encode_labels_impl(preset, num_classes, device, gt_boxes, gt_cls, gt_offsets, b, vec_out_dev, nullptr, (hipStream_t)stream);
+    API_END
+}
+
+size_t ssd_encode_labels_ws_bytes(int ntot) { return (encode_labels_ws_bytes(ntot) + 255) / 256 * 256; }
+
+int ssd_encode_labels_resident(const char* preset, int num_classes, int device, const double* gt_boxes_dev, const int* gt_cls_dev,
+                               const int* gt_offsets_dev, int b, int ntot, float* vec_out_dev, void* ws_dev, void* stream) {
+    API_BEGIN
+    const Preset& p = get_preset(preset);
+    SSD_REQUIRE(b >= 1 && ntot >= 0, "batch must be >= 1 and ntot >= 0");
+    SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "num_classes must be in 1..27");
+    SSD_REQUIRE(gt_offsets_dev && vec_out_dev && ws_dev && (ntot == 0 || (gt_boxes_dev && gt_cls_dev)), "null argument");
+    DeviceGuard dev_guard_(device);
+    const double* anc;
+    const int* aabs;
+    {
+        EncodeCache& ec = encode_cache();
+        std::lock_guard<std::mutex> lock(ec.mu);
+        EncodeCache::Anchors& an = encode_anchors(ec, p, device);
+        anc = an.anc; aabs = an.aabs;
+    }
+    encode_labels(p, num_classes, anc, aabs, gt_boxes_dev, gt_cls_dev, gt_offsets_dev, b, ntot, vec_out_dev, ws_dev, (hipStream_t)stream);
     API_END
 }
 

@@ -66,6 +66,18 @@ def _gt_arrays(gts):
     return bxs, cls
 
 
+def _gt_packed(gts, num_classes):
+    """The batch's boxes as the label encoder's three arrays (what ssd_encode_labels* take): [ntot, 4] float64
+    proportional (cx, cy, w, h), [ntot] int32 class ids, [b + 1] int32 offsets.  They ride in the batch's slot and
+    reach the GPU with the images' bytes; the class range is checked here (the resident encoder does not)."""
+    from .ssdutils import _pack_gt
+    bxs, cls = _gt_arrays(gts)
+    gt, gcls, goff = _pack_gt(bxs, cls)
+    if gcls.size and (gcls.min() < 0 or gcls.max() >= num_classes):
+        raise ValueError('a ground-truth class id lies outside 0..%d' % (num_classes - 1))
+    return {'gt': gt, 'gcls': gcls, 'goff': goff}
+
+
 class _Recipe:
     """One data set of a TrainingData (train or valid): where its samples come from and how a list of sample
     indices becomes the host half of a batch.  Lives in the parent and, by fork, in the workers."""
@@ -88,7 +100,7 @@ class _Recipe:
                     if has_positive_anchor(td.preset, gt):
                         break
                 imgs.append(img); gts.append(gt)
-            return {'images': np.stack(imgs)}, gts
+            return dict({'images': np.stack(imgs)}, **_gt_packed(gts, td.num_classes)), gts
         from . import transforms as T
         host_tfs = [t for t in self.transforms if not isinstance(t, T.LabelCreatorTransform)]
         loader = host_tfs[0]
@@ -115,14 +127,14 @@ class _Recipe:
         finally:
             loader.images = preset_images
         arr, packed = T.plan_params(plans, td.preset.image_size.w, td.preset.image_size.h)
-        return {'params': np.frombuffer(arr, np.uint8).copy(), 'packed': packed}, gts
+        return dict({'params': np.frombuffer(arr, np.uint8).copy(), 'packed': packed}, **_gt_packed(gts, td.num_classes)), gts
 
     def slot_bytes(self, batch_size):
         td = self.td
         W, H = td.preset.image_size.w, td.preset.image_size.h
         if self.transforms is None:
-            return batch_size * H * W * 3 * 4 + 4096
-        return batch_size * (td._max_image_bytes + 16 + 256) + 4096
+            return batch_size * (H * W * 3 * 4 + 4096) + 8192
+        return batch_size * (td._max_image_bytes + 16 + 256 + 4096) + 8192
 
 
 def _worker_main(recipe, tasks, results):
@@ -347,7 +359,7 @@ class TrainingData:
         d = {'batch': batch_size, 'stream': torch.cuda.Stream(device=dev),
              'images': [torch.empty((batch_size, H, W, 3), dtype=torch.float32, device=dev) for _ in range(DEVICE_SLOTS)],
              'labels': [torch.empty((batch_size, A, nv), dtype=torch.float32, device=dev) for _ in range(DEVICE_SLOTS)],
-             'packed': [None] * DEVICE_SLOTS,
+             'packed': [None] * DEVICE_SLOTS, 'enc_ws': [None] * DEVICE_SLOTS,
              'ws': [torch.empty((lib.ssd_augment_ws_bytes(batch_size, W, H),), dtype=torch.uint8, device=dev) for _ in range(DEVICE_SLOTS)]}
         self._dev = d
         return d
@@ -388,6 +400,47 @@ class TrainingData:
             if not self.device_tensors:
                 images = images.cpu().numpy()
         labels = self._labels(gts, out=ring['labels'][slot][:b] if ring is not None else None)
+        return images, labels
+
+    def _upload_async(self, slot_arr, arrays, gts, dslot):
+        """The prefetching feeder's upload: ONE host-to-device transfer of the slot's used prefix (source bytes, parameter
+        records, boxes), then the augmentation and label kernels, all enqueued on torch's current stream; nothing is waited
+        for.  `arrays` are views into slot_arr (pinned when the registration succeeded): the slot must stay untouched until
+        the returned work has run."""
+        import ctypes as C
+        import torch
+        from ._lib import lib, check
+        b = len(gts)
+        dev = torch.device('cuda', self.device)
+        W, H = self.preset.image_size.w, self.preset.image_size.h
+        ring = self._dev
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        base = slot_arr.ctypes.data
+        offs = {k: v.ctypes.data - base for k, v in arrays.items()}
+        big = 'images' if 'images' in arrays else None
+        small = [k for k in arrays if k != big]
+        lo = min(offs[k] for k in small)
+        hi = max(offs[k] + arrays[k].nbytes for k in small)
+        need = hi - lo
+        staged = ring['packed'][dslot]
+        if staged is None or staged.numel() < need:
+            cap = max(need, ring['batch'] * (getattr(self, '_max_image_bytes', 0) + 16 + 256 + 4096) + 8192)
+            staged = ring['packed'][dslot] = torch.empty((cap,), dtype=torch.uint8, device=dev)
+        staged[:need].copy_(torch.from_numpy(slot_arr[lo:hi]), non_blocking=True)
+        sp = staged.data_ptr() - lo
+        images = ring['images'][dslot][:b]
+        if big:
+            images.copy_(torch.from_numpy(arrays['images']), non_blocking=True)
+        else:
+            check(lib.ssd_augment_batch_dev(sp + offs['packed'], C.c_void_p(arrays['params'].ctypes.data), b, W, H, images.data_ptr(),
+                                            ring['ws'][dslot].data_ptr(), stream))
+        ntot = int(arrays['gcls'].shape[0])
+        ws_need = lib.ssd_encode_labels_ws_bytes(ntot)
+        if ring['enc_ws'][dslot] is None or ring['enc_ws'][dslot].numel() < ws_need:
+            ring['enc_ws'][dslot] = torch.empty((max(ws_need, lib.ssd_encode_labels_ws_bytes(ring['batch'] * 16)),), dtype=torch.uint8, device=dev)
+        labels = ring['labels'][dslot][:b]
+        check(lib.ssd_encode_labels_resident(self.preset.name.encode(), self.num_classes, self.device, sp + offs['gt'], sp + offs['gcls'],
+                                             sp + offs['goff'], b, ntot, labels.data_ptr(), ring['enc_ws'][dslot].data_ptr(), stream))
         return images, labels
 
     # ---- the generators ----------------------------------------------------------------------------------------------
@@ -435,14 +488,26 @@ class TrainingData:
         for s in range(DEVICE_SLOTS):
             dev_free.put((s, None))
         cancel = threading.Event()
-        stats = self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, batches=0)
+        stats = self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, host_slot_wait=0.0, batches=0)
         clock = time.perf_counter
+        inflight = []          # (host slot, event behind its upload): the slot returns to the pool when the event has passed
+
+        def reap(block):
+            """host slots whose upload has run; block: wait for the oldest one when none is free"""
+            while inflight and (inflight[0][1] is None or inflight[0][1].query()):
+                pool.free_slots.append(inflight.pop(0)[0])
+            if block and inflight and not pool.free_slots:
+                t0 = clock()
+                inflight[0][1].synchronize()
+                stats['host_slot_wait'] += clock() - t0
+                pool.free_slots.append(inflight.pop(0)[0])
 
         def feeder():
             try:
                 next_submit = next_upload = 0
                 done = {}
                 while next_upload < nb and not cancel.is_set():
+                    reap(block=next_submit < nb and next_upload not in done and len(pool.outstanding) == 0)
                     while next_submit < nb and (len(batches[next_submit][0]) == 0 or pool.free_slots):
                         idx = batches[next_submit][0]
                         if len(idx) == 0:
@@ -471,19 +536,25 @@ class TrainingData:
                         t1 = clock()
                         stats['slot_wait'] += t1 - t0
                         if use_gpu:
+                            slot_arr = pool.results.array_pool[hslot]
+                            in_slot = all(isinstance(v, np.ndarray) and v.base is not None and
+                                          slot_arr.ctypes.data <= v.ctypes.data < slot_arr.ctypes.data + slot_arr.nbytes for v in arrays.values())
                             with torch.cuda.stream(fstream):
                                 if released is not None:
                                     fstream.wait_event(released)
-                                images, labels = self._upload(arrays, gts, dslot)
+                                if in_slot:      # enqueue and move on: the consumer's stream waits for the event, not this thread
+                                    images, labels = self._upload_async(slot_arr, arrays, gts, dslot)
+                                else:            # a batch that did not fit its slot came through the pipe: the serial upload
+                                    images, labels = self._upload(arrays, gts, dslot)
                                 ev = torch.cuda.Event()
                                 ev.record(fstream)
-                                ev.synchronize()          # the slot's bytes have left the host
+                            inflight.append((hslot, ev))
                         else:
                             images, labels = self._upload(arrays, gts, dslot)
                             ev = None
+                            pool.free_slots.append(hslot)
                         stats['upload'] += clock() - t1
                         stats['batches'] += 1
-                        pool.free_slots.append(hslot)
                         ready.put((next_upload, dslot, len(gts), (images, labels, gts), count, ev))
                         next_upload += 1
                         continue
@@ -507,6 +578,14 @@ class TrainingData:
                     done[tag[1]] = (hslot, arrays, gts)
             except BaseException as e:
                 ready.put(e)
+            finally:
+                for hslot, ev in inflight:
+                    if ev is not None:
+                        try:
+                            ev.synchronize()
+                        except Exception:
+                            pass
+                del inflight[:]
 
         recipe.active = True
         th = threading.Thread(target=feeder, name='ssd-feeder-' + recipe.which, daemon=True)
