@@ -21,10 +21,13 @@ namespace ssd {
 constexpr int AUG_TMAX = 16;          // taps per axis (INTER_AREA shrinking by up to 14x)
 enum { ALG_NEAREST = 0, ALG_LINEAR = 1, ALG_CUBIC = 2, ALG_AREA = 3, ALG_LANCZOS4 = 4 };
 
+// TAP-MAJOR: the taps of neighbouring output coordinates sit next to each other, so a wave of the gather kernel (64
+// consecutive output pixels of a row) reads tap i of its 64 columns as ONE 256-byte run.  Round 2's coordinate-major
+// layout ([dst][AUG_TMAX]) put every lane on its own 64-byte line for each of the two loads per tap.
 struct TapTable {
-    int* idx;         // [b][2][dst][AUG_TMAX]
+    int* idx;         // [b][2][AUG_TMAX][pitch]   pitch = max(out_w, out_h)
     float* w;         // same
-    int* n;           // [b][2][dst]
+    int* n;           // [b][2][pitch]
 };
 
 __device__ static void cubic_w(float x, float* c) {
@@ -121,8 +124,16 @@ __global__ __launch_bounds__(256) void augment_taps_kernel(const ssd_augment_par
     const int dst = axis ? out_h : out_w;
     const ssd_augment_params& p = prm[img];
     const int src = axis ? p.crop_h : p.crop_w;
-    const size_t row = ((size_t)(img * 2 + axis)) * (out_w > out_h ? out_w : out_h) + d;
-    t.n[row] = axis_taps(src, dst, p.resize_alg, d, t.idx + row * AUG_TMAX, t.w + row * AUG_TMAX);
+    const int pitch = out_w > out_h ? out_w : out_h;
+    const size_t plane = (size_t)(img * 2 + axis);
+    int li[AUG_TMAX];
+    float lw[AUG_TMAX];
+    const int nt = axis_taps(src, dst, p.resize_alg, d, li, lw);
+    t.n[plane * pitch + d] = nt;
+    for (int i = 0; i < nt; ++i) {
+        t.idx[(plane * AUG_TMAX + i) * pitch + d] = li[i];
+        t.w[(plane * AUG_TMAX + i) * pitch + d] = lw[i];
+    }
 }
 
 // ---- photometric chain on one uint8 BGR pixel (oracle/augment.py brightness / contrast / hue / saturation) ----
@@ -195,8 +206,38 @@ __device__ static void photometric(const ssd_augment_params& p, int row, float* 
     }
 }
 
+// Pass 0 (round 3): the photometric chain depends on the SOURCE pixel only, yet the gather evaluated it per tap -- up to 64
+// taps per output pixel (Lanczos), two HSV round trips each.  Its result is an exact uint8 value (every step ends in a
+// truncation / rounding to 0..255), so images whose chain is not the identity are transformed once, pixel by pixel, into a
+// uint8 copy in the workspace (AUG_PRE_BYTES per image; a larger image keeps the per-tap path) and the gather reads bytes.
+constexpr size_t AUG_PRE_BYTES = 1310720;      // 1.25 MiB: a 660 x 660 BGR image
+
+__device__ __forceinline__ bool aug_has_photometric(const ssd_augment_params& p) { return p.brightness_on || p.n_distort > 0; }
+__device__ __forceinline__ bool aug_uses_pre(const ssd_augment_params& p) {
+    return aug_has_photometric(p) && (size_t)p.src_w * p.src_h * 3 <= AUG_PRE_BYTES;
+}
+
+__global__ __launch_bounds__(256) void augment_photometric_kernel(const unsigned char* __restrict__ images, const ssd_augment_params* __restrict__ prm,
+                                                                  unsigned char* __restrict__ pre) {
+    const int img = blockIdx.y;
+    const ssd_augment_params& p = prm[img];
+    if (!aug_uses_pre(p)) return;
+    const int npix = p.src_w * p.src_h;
+    const unsigned char* src = images + p.src_off;            // 16-byte aligned (the packing pads every image to 16 bytes)
+    unsigned char* dst = pre + (size_t)img * AUG_PRE_BYTES;
+    // (one pixel per thread: the chain is ALU-bound -- two HSV round trips -- not byte-bound; four pixels per thread with dword
+    // loads and stores measured 55 instead of 42 us per batch)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const unsigned char* q = src + (size_t)i * 3;
+        float raw[3] = {(float)q[0], (float)q[1], (float)q[2]};
+        photometric(p, i / p.src_w, raw);
+        for (int c = 0; c < 3; ++c) dst[(size_t)i * 3 + c] = (unsigned char)(int)raw[c];      // exact: integers in 0..255
+    }
+}
+
 __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char* __restrict__ images, const ssd_augment_params* __restrict__ prm,
-                                                             int b, int out_w, int out_h, TapTable t, float* __restrict__ out) {
+                                                             int b, int out_w, int out_h, TapTable t, const unsigned char* __restrict__ pre,
+                                                             float* __restrict__ out) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)b * out_w * out_h;
     if (gid >= total) return;
@@ -205,26 +246,39 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
     const int img = (int)(gid / ((size_t)out_w * out_h));
     const ssd_augment_params p = prm[img];
     const int pitch = out_w > out_h ? out_w : out_h;
-    const size_t rx = ((size_t)(img * 2 + 0)) * pitch + ox, ry = ((size_t)(img * 2 + 1)) * pitch + oy;
-    const int nx = t.n[rx], ny = t.n[ry];
-    const unsigned char* src = images + p.src_off;
+    const size_t px_ = (size_t)(img * 2 + 0), py_ = (size_t)(img * 2 + 1);
+    const int nx = t.n[px_ * pitch + ox], ny = t.n[py_ * pitch + oy];
+    const int* xi = t.idx + px_ * AUG_TMAX * pitch + ox;       // tap i at xi[i * pitch]
+    const float* xw = t.w + px_ * AUG_TMAX * pitch + ox;
+    const int* yi = t.idx + py_ * AUG_TMAX * pitch + oy;
+    const float* yw = t.w + py_ * AUG_TMAX * pitch + oy;
+    const bool from_pre = aug_uses_pre(p);                 // the chain has been applied by pass 0
+    const bool per_tap = aug_has_photometric(p) && !from_pre;
+    const unsigned char* src = from_pre ? pre + (size_t)img * AUG_PRE_BYTES : images + p.src_off;
     const double mean[3] = {104.0, 117.0, 123.0};
     double acc[3] = {0, 0, 0};
     for (int j = 0; j < ny; ++j) {
-        const int sy = t.idx[ry * AUG_TMAX + j] + p.crop_y0;               // row in the (expanded) frame
-        const double wy = t.w[ry * AUG_TMAX + j];
+        const int sy = yi[(size_t)j * pitch] + p.crop_y0;                  // row in the (expanded) frame
+        const double wy = yw[(size_t)j * pitch];
         double rowacc[3] = {0, 0, 0};
         for (int i = 0; i < nx; ++i) {
-            int sx = t.idx[rx * AUG_TMAX + i];
+            int sx = xi[(size_t)i * pitch];
             if (p.flip) sx = p.crop_w - 1 - sx;
             sx += p.crop_x0;
-            const double wx = t.w[rx * AUG_TMAX + i];
+            const double wx = xw[(size_t)i * pitch];
             const int y0 = sy - p.exp_hoff, x0 = sx - p.exp_woff;         // position in the loaded image (offsets are 0 when not expanded)
             float px[3];
             if ((unsigned)y0 < (unsigned)p.src_h && (unsigned)x0 < (unsigned)p.src_w) {
                 const unsigned char* q = src + ((size_t)y0 * p.src_w + x0) * 3;
-                float raw[3] = {(float)q[0], (float)q[1], (float)q[2]};
-                photometric(p, y0, raw);
+                // one (unaligned) dword instead of three byte loads -- except for the image's very last pixel, whose fourth
+                // byte may lie outside the caller's buffer
+                typedef unsigned u32_unaligned __attribute__((aligned(1)));
+                const bool last_px = (y0 == p.src_h - 1) & (x0 == p.src_w - 1);
+                unsigned v;
+                if (last_px) v = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
+                else v = *reinterpret_cast<const u32_unaligned*>(q);
+                float raw[3] = {(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u)};
+                if (per_tap) photometric(p, y0, raw);
                 for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
             } else {
                 for (int c = 0; c < 3; ++c) px[c] = (float)mean[c];
@@ -246,7 +300,8 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
 
 size_t augment_ws_bytes(int b, int out_w, int out_h) {
     const size_t rows = (size_t)b * 2 * (out_w > out_h ? out_w : out_h);
-    return rows * AUG_TMAX * (sizeof(int) + sizeof(float)) + rows * sizeof(int) + (size_t)b * sizeof(ssd_augment_params) + 256;
+    return rows * AUG_TMAX * (sizeof(int) + sizeof(float)) + rows * sizeof(int) + ((size_t)b * sizeof(ssd_augment_params) + 255) / 256 * 256 + 512 +
+           (size_t)b * AUG_PRE_BYTES;
 }
 
 void augment_batch(const unsigned char* images_dev, const ssd_augment_params* params_host, int b, int out_w, int out_h, float* out_dev,
@@ -270,8 +325,21 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
     t.idx = reinterpret_cast<int*>(base);
     t.w = reinterpret_cast<float*>(base + rows * AUG_TMAX * sizeof(int));
     t.n = reinterpret_cast<int*>(base + rows * AUG_TMAX * (sizeof(int) + sizeof(float)));
-    ssd_augment_params* prm = reinterpret_cast<ssd_augment_params*>(base + ((rows * AUG_TMAX * 8 + rows * 4 + 255) / 256) * 256);
+    const size_t prm_off = ((rows * AUG_TMAX * 8 + rows * 4 + 255) / 256) * 256;
+    ssd_augment_params* prm = reinterpret_cast<ssd_augment_params*>(base + prm_off);
+    unsigned char* pre = reinterpret_cast<unsigned char*>(base + prm_off + ((size_t)b * sizeof(ssd_augment_params) + 255) / 256 * 256);
     HIP_OK(hipMemcpyAsync(prm, params_host, (size_t)b * sizeof(ssd_augment_params), hipMemcpyHostToDevice, s));
+    int pre_pixels = 0;      // the largest image pass 0 has to transform (0: no image needs it)
+    for (int i = 0; i < b; ++i) {
+        const ssd_augment_params& p = params_host[i];
+        const size_t bytes = (size_t)p.src_w * p.src_h * 3;
+        if ((p.brightness_on || p.n_distort > 0) && bytes <= AUG_PRE_BYTES && p.src_w * p.src_h > pre_pixels) pre_pixels = p.src_w * p.src_h;
+    }
+    if (pre_pixels > 0) {
+        ProfScope prof("augment_photometric", 0.0, (double)b * pre_pixels * 6, s);
+        const int gx = cdiv(pre_pixels, 256 * 4) < 1 ? 1 : cdiv(pre_pixels, 256 * 4);      // four strided pixels per thread
+        hipLaunchKernelGGL(augment_photometric_kernel, dim3(gx, b), dim3(256), 0, s, images_dev, prm, pre);
+    }
     {
         const int n = b * (out_w + out_h);
         ProfScope prof("augment_taps", 0.0, (double)n * AUG_TMAX * 8, s);
@@ -280,7 +348,7 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
     {
         const size_t total = (size_t)b * out_w * out_h;
         ProfScope prof("augment_gather", 0.0, (double)total * 12, s);
-        hipLaunchKernelGGL(augment_gather_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, s, images_dev, prm, b, out_w, out_h, t, out_dev);
+        hipLaunchKernelGGL(augment_gather_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, s, images_dev, prm, b, out_w, out_h, t, pre, out_dev);
     }
     HIP_OK(hipGetLastError());
 }
