@@ -9,8 +9,11 @@ the HIP library.  Same flags (train.py:55-80) plus --preset / --synthetic-train 
 
 A batch never leaves the GPU: the feeder hands out device tensors, the step runs on them, decode + NMS
 for the AP bookkeeping runs on the result where it lies (the reference fetches `result` to the host for
-decode_boxes, train.py:262-277).  Data parallel: one process per GPU, rank-sharded batches, bucketed
-all-reduce of the gradient arena overlapped with backward (parallel.train_step_dp)."""
+decode_boxes, train.py:262-277).  --num-workers N means what the reference's means: N forked processes
+prepare the next batches beside the step (training_data.py).  The loop (StepLoop) never waits for the step
+it has just launched: losses are read one step late, detections one pass late.  Data parallel: one process
+per GPU, rank-sharded batches, bucketed all-reduce of the gradient arena overlapped with backward
+(parallel.train_step_dp); losses are summed and detections gathered over ranks for the epoch summaries."""
 import argparse
 import math
 import os

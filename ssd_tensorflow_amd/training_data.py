@@ -145,8 +145,14 @@ def _worker_main(recipe, tasks, results):
         signal.signal(signal.SIGINT, signal.SIG_IGN)
     except Exception:
         pass
+    parent = os.getppid()
     while True:
-        task = tasks.get()
+        try:
+            task = tasks.get(timeout=5.0)
+        except queue.Empty:
+            if os.getppid() != parent:      # the training process is gone (killed): do not linger
+                break
+            continue
         if task is None:
             break
         gen, seq, slot, epoch, idx = task
