@@ -722,10 +722,24 @@ def main():
             except (Exception, SystemExit) as e:      # noqa: BLE001 -- a secondary block never costs the headline line
                 out[name] = {'error': f'{type(e).__name__}: {e}'}
         if not args.no_e2e:
-            # the driver loop end to end, beside the resident-input numbers above (same process, same box)
+            # The driver loop end to end, beside the resident-input numbers above (same box).  Each block runs in a FRESH
+            # process, as train.py would: which streams end up sharing a hardware queue depends on how many streams the
+            # process has created and destroyed before, and after eight configurations in this process the
+            # feeder's stream measured 0.87 of the resident-input bf16 step instead of the 0.94-0.95 of a fresh process.
+            import subprocess
+
+            def e2e_child(dtype):
+                cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'train_e2e', '--dtype', dtype, '--preset', args.preset,
+                       '--batch', str(args.batch), '--e2e-workers', str(args.e2e_workers), '--e2e-steps', str(args.e2e_steps),
+                       '--e2e-epochs', str(args.e2e_epochs), '--e2e-serial-steps', str(args.e2e_serial_steps)]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+                if r.returncode != 0 or not lines:
+                    raise RuntimeError('train_e2e child failed (rc %d): %s' % (r.returncode, r.stderr[-400:]))
+                return json.loads(lines[-1])
             for name, dtype, resident in (('train_e2e', 'f32', out), ('train_e2e_bf16', 'bf16', out.get('bf16'))):
                 try:
-                    r = e2e(dtype)
+                    r = e2e_child(dtype)
                     if resident and 'value' in resident:
                         r['resident_input_value'] = resident['value']
                         r['vs_resident_input'] = round(r['value'] / resident['value'], 4)
