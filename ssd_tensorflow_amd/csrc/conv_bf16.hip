@@ -996,7 +996,15 @@ struct WgradRowsArgs {
     int schunk, nsplit;     // k-slots per split (multiple of 64)
 };
 
-template <int TM, int TN>
+template <int L>
+__device__ __forceinline__ void wait_pieces(int ahead) {            // leave `ahead` stages of L pieces in flight
+    static_assert(2 * L <= 63, "vmcnt field");
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TM, int TN, int NS = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs p) {
     constexpr int BKT = 64 * TM, BNT = 64 * TN, BP = 64, XROWS = 72;
     constexpr int XROWB = BKT * 2, YROWB = BNT * 2;
@@ -1005,6 +1013,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
     constexpr int YCPR = BNT / 8, YRPP = 256 / YCPR, Y_N = BP / YRPP;
     constexpr int X_LDS = XROWS * XROWB, STAGE = X_LDS + BP * YROWB;
     static_assert(TM * TN <= 2, "3 taps x TM x TN accumulator tiles per wave");
+    static_assert(NS >= 2 && NS <= 4 && NS * STAGE <= 160 * 1024, "ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -1173,11 +1182,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
         }
     };
 
-    if (niter > 0) issue(0, 0);
+    // NS = 2 (default): one tile in flight while one is multiplied -- a stage is 12..24 MFMAs per wave (400..800 cycles)
+    // against a DMA round trip of 1300..2500, so a workgroup idles most of the time and the CU's other resident
+    // workgroups fill in.  NS = 3 / 4 (SSD_WGRAD_ROWS_NS): a ring with two / three tiles in flight per workgroup -- measured
+    // SLOWER (profiles/r03_o_rows_wgrad_ring_sweep_bf16.txt: conv1_2 0.374 -> 0.42..0.46 -> 0.52 ms, conv2_1 0.206 -> 0.208 ->
+    // 0.283): the deeper ring costs resident workgroups (4 -> 3 -> 2 per CU), and four independent two-stage pipelines hide
+    // more than two four-stage ones -- the same answer the gather kernels gave in round 1.
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < niter) issue(t, t);
+    int st_c = 0, st_i = NS - 1;
     for (int it = 0; it < niter; ++it) {
-        wait_tiles_and_sync<1>(0);
-        if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
-        compute(it & 1);
+        const int later = niter - 1 - it;
+        const int ahead = later < NS - 2 ? later : NS - 2;
+        if (wave < XTAIL_WAVES) wait_pieces<X_N + 1 + Y_N>(ahead);
+        else wait_pieces<X_N + Y_N>(ahead);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + NS - 1 < niter) issue(it + NS - 1, st_i);
+        compute(st_c);
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+        st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
 
     const size_t wcount = (size_t)9 * p.Ci * p.Co;
@@ -1210,14 +1235,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
 // (6 accumulator tiles); the bias gradient rides on the matrix cores too (a ones operand against the dy fragments in
 // the two waves of the kh = 0, ct = 0 workgroups) instead of a scalar LDS sweep.
 // =================================================================================
-template <int L>
-__device__ __forceinline__ void wait_pieces(int ahead) {            // leave `ahead` stages of L pieces in flight
-    static_assert(2 * L <= 63, "vmcnt field");
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 template <int NS, bool STAGGER = true>
 __global__ __launch_bounds__(512) void conv_wgrad_bf16_rows8_kernel(WgradRowsArgs p) {
     constexpr int BKT = 128, BNT = 128, BP = 64, XROWS = 72, ROWB = 256, CPR = 16;
@@ -1858,15 +1875,22 @@ static void launch_wgrad_rows8(WgradRowsArgs& a, const char* label, double flops
     HIP_OK(hipGetLastError());
 }
 
-template <int TM, int TN>
-static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(72 * 128 * TM + 64 * 128 * TN);
-    auto kern = conv_wgrad_bf16_rows_kernel<TM, TN>;
+template <int TM, int TN, int NS>
+static void launch_wgrad_rows_ns(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr size_t lds = NS * (size_t)(72 * 128 * TM + 64 * 128 * TN);
+    auto kern = conv_wgrad_bf16_rows_kernel<TM, TN, NS>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     ProfScope prof(label, flops, bytes, s);
     hipLaunchKernelGGL(kern, dim3(a.nsplit * 3 * a.CT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
+}
+template <int TM, int TN>
+static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    static const int ns = env_int("SSD_WGRAD_ROWS_NS", 2);      // A/B switch: ring depth of the 4-wave kernel-row weight gradient
+    if (ns == 3) launch_wgrad_rows_ns<TM, TN, 3>(a, label, flops, bytes, s);
+    else if (ns >= 4) launch_wgrad_rows_ns<TM, TN, 4>(a, label, flops, bytes, s);
+    else launch_wgrad_rows_ns<TM, TN, 2>(a, label, flops, bytes, s);
 }
 
 size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
