@@ -1226,6 +1226,200 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
 }
 
 // =================================================================================
+// Column-walk weight gradient for the <= 64-input-channel layers (conv1_2, conv2_1), round 3.
+// The kernel-row variant above gives one workgroup ONE kernel row kh: the three workgroups of a pixel range read the same dy
+// tiles and x tiles that are the same pixels one image row apart.  With 1024 workgroups streaming at once an XCD's 4-MB L2
+// does not hold a tile for the ~5 iterations until the sibling kernel row needs it: rocprofv3 FETCH_SIZE of conv1_2's weight
+// gradient is 1.8 GB per launch against 0.74 GB of tensors (profiles/r03_g_bf16_pmc_FETCH_SIZE.txt) -- the layer runs at the HBM
+// roofline of 2.4x its own bytes.  The reduction index of a weight gradient is the pixel, in ANY order, so here a workgroup
+// owns a strip of 64 image columns and walks DOWN its rows: per step it stages one x row tile (66 pixels with the halo) into
+// a ring of five and one dy row tile (ring of three), and multiplies all NINE taps -- x rows y-1, y, y+1 are the ring's previous fills.
+// Every byte of x and dy is fetched once (+ 2 halo columns per 64, + 2 halo rows per unit), 36 MFMAs per wave follow 17 KB of
+// LDS-DMA (kernel-row: 12), and the addressing is a constant per thread plus one row stride per step (no slot walk).
+// 4 waves as 2 x 2: each 32 input x 32 output channels x 9 taps (nine accumulator tiles); Co > 64 runs as NT column tiles of 64
+// (x re-read per tile).  Slabs: one per (image, strip, row chunk) unit, reduced by wgrad_reduce like the other variants'.
+// =================================================================================
+struct WgradColArgs {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* ws;              // [nunits][9*Ci*Co + Co]
+    int B, H, W, Ci, Co;
+    int NT;                 // output-channel tiles of 64
+    int nstrips, rpu, RC;   // 64-column strips per image row, image rows per unit, units per (image, strip)
+    int ablate;             // measurement aid (SSD_WGRAD_COL_ABLATE): 1 no multiply, 2 no staging after the first tiles -- WRONG results
+};
+
+// (two waves per SIMD = two workgroups per CU: left alone the scheduler hoists all 36 fragment reads of a step -- 316 registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_bf16_col_kernel(WgradColArgs p) {
+    constexpr int ROWB = 128, XROWS = 72, X_TILE = XROWS * ROWB, Y_TILE = 64 * ROWB, NXR = 5, NYB = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NXR x tiles][NYB dy tiles]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = wg % p.NT, unit = wg / p.NT;
+    const int rc = unit % p.RC;
+    const int us = unit / p.RC;
+    const int strip = us % p.nstrips, b = us / p.nstrips;
+    const int r0 = rc * p.rpu, r1 = r0 + p.rpu < p.H ? r0 + p.rpu : p.H;
+    const int c0x = strip * 64, n0 = nt * 64;
+
+    auto swz = [](int r) { return ((r >> 1) & 1) * 4; };       // 128-byte rows: slot s of row r holds chunk s ^ swz(r)
+    // ---- staging: thread -> tile row (tid >> 3) + 32 j, 16-byte slot tid & 7; the COLUMN of a row is fixed for the whole walk
+    const int sr = tid >> 3, ss = tid & 7;
+    unsigned xoff[2], xmk[2], yoff[2], ymk[2], xtoff, xtmk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = sr + 32 * j;
+        const int xcol = c0x - 1 + row, xchunk = ss ^ swz(row);
+        xmk[j] = 0u - (unsigned)((unsigned)xcol < (unsigned)p.W && xchunk * 8 < p.Ci);
+        xoff[j] = (unsigned)((xcol * p.Ci + xchunk * 8) * 2);
+        const int ycol = c0x + row, ychunk = ss ^ swz(row);
+        ymk[j] = 0u - (unsigned)(ycol < p.W && n0 + ychunk * 8 < p.Co);
+        yoff[j] = (unsigned)((ycol * p.Co + n0 + ychunk * 8) * 2);
+    }
+    {
+        const int row = 64 + sr;                               // wave 0 stages rows 64..71; the halo needs 64 and 65
+        const int xcol = c0x - 1 + row, xchunk = ss ^ swz(row);
+        xtmk = 0u - (unsigned)(row <= 65 && (unsigned)xcol < (unsigned)p.W && xchunk * 8 < p.Ci);
+        xtoff = (unsigned)((xcol * p.Ci + xchunk * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Ci * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (unsigned)((size_t)p.B * p.H * p.W * p.Co * 2u), 0x00020000);
+    const unsigned x_row_bytes = (unsigned)(p.W * p.Ci * 2), y_row_bytes = (unsigned)(p.W * p.Co * 2);
+
+    // ring slots: x row yy lives in slot (yy - (r0 - 1)) % 5, dy row y in buffer (y - r0) % 3 (two steps are in flight)
+    auto xslot = [&](int yy) { return (yy - (r0 - 1)) % NXR; };
+    auto yslot = [&](int y) { return (y - r0) % NYB; };
+    auto issue_x = [&](int yy) {                               // image row yy (may lie outside the image: zero tile)
+        unsigned char* Xs = smem + xslot(yy) * X_TILE + wave * 1024;
+        const unsigned ok = 0u - (unsigned)((unsigned)yy < (unsigned)p.H);
+        const unsigned base = (unsigned)(b * p.H + yy) * x_row_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned mk = xmk[j] & ok;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + j * 4096), 16, (int)(((base + xoff[j]) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        }
+        if (wave == 0) {
+            const unsigned mk = xtmk & ok;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, LDS_PTR(Xs + 2 * 4096), 16, (int)(((base + xtoff) & mk) | (OOBH & ~mk)), 0, 0, 0);
+        }
+    };
+    auto issue_y = [&](int y) {                                // rows r0 <= y < r1 only
+        unsigned char* Ys = smem + NXR * X_TILE + yslot(y) * Y_TILE + wave * 1024;
+        const unsigned base = (unsigned)(b * p.H + y) * y_row_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, LDS_PTR(Ys + j * 4096), 16, (int)(((base + yoff[j]) & ymk[j]) | (OOBH & ~ymk[j])), 0, 0, 0);
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+    f32x16 accb;                                               // bias gradient on the matrix cores: ones^T dy (waves with wm == 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    s16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;       // bf16 1.0
+
+    const int wm = wave >> 1, wn = wave & 1;               // 2 x 2 waves: 32 input channels x 32 output channels each
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = lane & 15, cb = (lane >> 4) & 1;
+    const int prow = lh * 8 + (q >> 2);
+    int xa[3], ya;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                           // tap kw = t reads x tile rows (pixel + t): tile row 0 is column c0x - 1
+        const int r = prow + t;
+        const int ch = wm * 4 + cb * 2 + ((q >> 1) & 1);
+        xa[t] = r * ROWB + ((ch ^ swz(r)) * 16) + (q & 1) * 8;
+    }
+    {
+        const int ch = wn * 4 + cb * 2 + ((q >> 1) & 1);
+        ya = prow * ROWB + ((ch ^ swz(prow)) * 16) + (q & 1) * 8;
+    }
+    auto tr8 = [&](const unsigned char* S, int off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(S + off + 4 * ROWB));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    // A step = 12 blocks (k-step st, kernel row a) of three MFMAs (+ the bias MFMA); the fragments of block k + 1 are read
+    // while block k multiplies (two register sets, the order pinned with sched_barrier as in the other kernels: left alone
+    // the scheduler either hoists all 40 fragment reads -- 316 registers -- or parks every block on its own reads).  Rows
+    // outside the image are ZERO tiles (issue_x masks their loads), so no block is conditional.
+    auto compute = [&](int y) {
+        const unsigned char* Ys = smem + NXR * X_TILE + yslot(y) * Y_TILE;
+        const unsigned char* Xr[3] = {smem + xslot(y - 1) * X_TILE, smem + xslot(y) * X_TILE, smem + xslot(y + 1) * X_TILE};
+        s16x8 afr[2][3], bfr[2];
+        auto load_block = [&](int k) {
+            const int st = k / 3, a = k % 3;
+            if (a == 0) bfr[st & 1] = tr8(Ys, ya + st * 16 * ROWB);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) afr[k & 1][t] = tr8(Xr[a], xa[t] + st * 16 * ROWB);
+        };
+        load_block(0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int st = k / 3, a = k % 3;
+            if (k + 1 < 12) load_block(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[k & 1][t]), __builtin_bit_cast(bf16x8, bfr[st & 1]),
+                                                                   acc[a][t], 0, 0, 0);
+            if (a == 0 && wm == 0)      // (a scalar LDS sweep of the tile by one wave made that wave every step's straggler)
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bfr[st & 1]), accb, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- the walk.  Bytes in flight set the rate (a workgroup that keeps ONE 17-KB step in flight: 512 x 17 KB / 3 us of loaded
+    // round trip = 2.9 TB/s, measured 0.32 ms): two steps stay in flight.  Step y multiplies x rows y-1, y, y+1 with dy row y
+    // while x row y+2 / dy row y+1 are landing and x row y+3 / dy row y+2 are being issued.
+    issue_x(r0 - 1); issue_x(r0); issue_x(r0 + 1); issue_y(r0);
+    if (r0 + 1 < r1) { issue_x(r0 + 2); issue_y(r0 + 1); }
+    for (int y = r0; y < r1; ++y) {
+        // everything but the most recent step's group (if there is one) has to have landed
+        if (y + 1 < r1) {
+            if (wave == 0) wait_pieces<5>(1); else wait_pieces<4>(1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (y + 2 < r1 && !(p.ablate & 2)) { issue_x(y + 3); issue_y(y + 2); }
+        if (!(p.ablate & 1)) compute(y);
+    }
+
+    const size_t wcount = (size_t)9 * p.Ci * p.Co;
+    float* slab = p.ws + (size_t)unit * (wcount + p.Co);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int n = n0 + wn * 32 + li;
+            if (n >= p.Co) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci >= p.Ci) continue;
+                slab[((size_t)(a * 3 + t) * p.Ci + ci) * p.Co + n] = acc[a][t][r];
+            }
+        }
+    if (wm == 0 && lh == 0) {      // every row of ones^T dy is the column sum: row 0 lives in r = 0 of lanes 0..31
+        const int n = n0 + wn * 32 + li;
+        if (n < p.Co) slab[wcount + n] = accb[0];
+    }
+}
+
+// =================================================================================
 // Kernel-row weight gradient, 8 waves: 128 input channels x 128 output channels x the three taps of a kernel row per
 // workgroup (padded-raster k order as above), ONE workgroup per CU, an NS-deep ring of 34-KB stages.
 // Why: a CU's LDS-DMA path moves ~55 B/clk at best (tools/probes/dma_rate.hip) and every 1-KB piece costs its issuing
@@ -1893,9 +2087,44 @@ static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops,
     else launch_wgrad_rows_ns<TM, TN, 2>(a, label, flops, bytes, s);
 }
 
+// ---- column-walk variant (3x3, stride 1, SAME, <= 64 input channels): SSD_WGRAD_COL_BF16 = 0 off, 1 on (default), 2 also small
+// layers (tests).  Measured (profiles/r03_r_col_wgrad_sweep_bf16.txt, r03_s_col_wgrad_ablation_bf16.txt, r03_t_ab_col_wgrad_bf16.txt;
+// kernel + slab reduce, batch 32, post-relu operands): conv1_2 0.386 -> 0.252 ms (551 -> 844 TFLOP/s), conv2_1 0.206 -> 0.175;
+// 512 workgroups (one round of two per CU) beat 768 / 1024; step 7.53 / 7.55 -> 7.41 / 7.38 ms.  Ablations of conv1_2: multiply
+// only 0.212, staging only 0.166, neither 0.049 (launch, first tiles, slabs, reduce): the multiply phase alone runs at
+// 1.3 PFLOP/s, the power-limited rate of the big layers -- what is left is the part of the staging the multiply does not hide.
+static int col_mode() {
+    static const int v = env_int("SSD_WGRAD_COL_BF16", 1);
+    return v;
+}
+static bool col_applicable(const ConvDesc& d) {
+    const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo;
+    if (!shape || col_mode() == 0 || d.Ci > 64) return false;
+    return col_mode() >= 2 || (long long)d.B * d.Ho * d.Wo >= 64LL * 1024;      // enough pixels for a round of units
+}
+struct ColPlan { int NT, nstrips, rpu, RC, nunits; };
+static ColPlan plan_col(const ConvDesc& d) {
+    ColPlan p{};
+    p.NT = cdiv(d.Co, 64);
+    p.nstrips = cdiv(d.Wo, 64);
+    // two workgroups per CU (nine accumulator tiles per wave: ~220 registers) = 512 slots; a unit of fewer than 8 rows would
+    // spend more than a quarter of its loads on the two halo rows
+    static const int target = env_int("SSD_WGRAD_COL_WGS_BF16", 512);
+    const int per_row_chunk = d.B * p.nstrips * p.NT;
+    int rc = target / (per_row_chunk > 0 ? per_row_chunk : 1);
+    if (rc < 1) rc = 1;
+    const int max_rc = cdiv(d.Ho, 8);
+    if (rc > max_rc) rc = max_rc;
+    p.rpu = cdiv(d.Ho, rc);
+    p.RC = cdiv(d.Ho, p.rpu);
+    p.nunits = d.B * p.nstrips * p.RC;
+    return p;
+}
+
 size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
     const size_t per = (size_t)d.KH * d.KW * d.Ci * d.Co + d.Co;
     size_t n = (size_t)plan_wgrad_h(d).nsplit * per;
+    if (col_applicable(d)) n = std::max(n, (size_t)plan_col(d).nunits * per);
     if (rows_applicable(d)) n = std::max(n, (size_t)plan_rows(d).nsplit * per);
     if (rows8_applicable(d)) n = std::max(n, (size_t)plan_rows8(d).nsplit * per);
     return n;
@@ -1904,6 +2133,25 @@ size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d) {
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s) {
     check_desc_h(d);
+    if (col_applicable(d)) {
+        const ColPlan cp = plan_col(d);
+        WgradColArgs c{};
+        c.x = x; c.dy = dy; c.ws = ws;
+        c.B = d.B; c.H = d.Ho; c.W = d.Wo; c.Ci = d.Ci; c.Co = d.Co;
+        c.NT = cp.NT; c.nstrips = cp.nstrips; c.rpu = cp.rpu; c.RC = cp.RC;
+        static const int ablate = env_int("SSD_WGRAD_COL_ABLATE", 0);
+        c.ablate = ablate;
+        constexpr size_t lds = 5 * 72 * 128 + 3 * 64 * 128;
+        static bool once = (set_lds(conv_wgrad_bf16_col_kernel, lds), true);
+        (void)once;
+        {
+            ProfScope prof("conv_wgrad_bf16_col_64x64", conv_flops(d), 2.0 * conv_elems(d), s);
+            hipLaunchKernelGGL(conv_wgrad_bf16_col_kernel, dim3(cp.nunits * cp.NT), dim3(256), lds, s, c);
+            HIP_OK(hipGetLastError());
+        }
+        wgrad_reduce(ws, cp.nunits, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+        return;
+    }
     if (rows8_applicable(d)) {
         const RowsPlan rp = plan_rows8(d);
         WgradRowsArgs r{};
