@@ -161,3 +161,35 @@ def test_native_sampler_trials_are_the_python_loops():
     picker = [t for t in host if isinstance(t, T.SamplePickerTransform)][0]
     with pytest.raises(ValueError):
         picker(T.ImagePlan(np.zeros((50, 50, 3), np.uint8)), None, Sample('e', [], Size(50, 50)))
+
+
+def test_native_sampler_exhausted_trials_and_degenerate_pickers():
+    """Samplers that never find a window (a tiny box against min_jaccard_overlap = 1.0: all max_trials spent), pickers with a
+    single pass-through sampler, and few trials: the native loop consumes exactly the draws the Python loops consume."""
+    from ssd_tensorflow_amd import transforms as T
+    from ssd_tensorflow_amd.utils import Box, Point, Sample, Size
+    tiny = Sample('t', [Box('x', 0, Point(0.5, 0.5), Size(0.01, 0.01))], Size(333, 222))
+    big = Sample('b', [Box('x', 0, Point(0.5, 0.5), Size(0.9, 0.9)), Box('y', 1, Point(0.2, 0.3), Size(0.1, 0.2))], Size(640, 480))
+    pickers = [
+        T.SamplePickerTransform(samplers=[T.SamplerTransform(sample=False)]),
+        T.SamplePickerTransform(samplers=[T.SamplerTransform(sample=False), T.build_sampler(1.0, 7), T.build_sampler(0.9, 3)]),
+        T.SamplePickerTransform(samplers=[T.SamplerTransform(sample=False)] + [T.build_sampler(o, 50) for o in (0.1, 0.3, 0.5, 0.7, 0.9, 1.0)]),
+    ]
+    for gt in (tiny, big):
+        for pk in pickers:
+            for seed in range(25):
+                outs = []
+                for native in (False, True):
+                    saved, T.NATIVE_SAMPLER = T.NATIVE_SAMPLER, native
+                    try:
+                        random.seed(seed)
+                        plan = T.ImagePlan(np.zeros((gt.imgsize.h, gt.imgsize.w, 3), np.uint8))
+                        d, _, g = pk(plan, None, gt)
+                        outs.append((d.crop, g.boxes, g.imgsize, random.getstate()))
+                    finally:
+                        T.NATIVE_SAMPLER = saved
+                assert outs[0] == outs[1], (gt.filename, seed)
+    # the tiny box never satisfies overlap 1.0: only the pass-through candidate (and sometimes 0.9's) remains
+    random.seed(3)
+    d, _, g = pickers[1](T.ImagePlan(np.zeros((222, 333, 3), np.uint8)), None, tiny)
+    assert d.crop is None or d.crop[2] > 0
