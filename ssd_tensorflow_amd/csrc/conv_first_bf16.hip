@@ -42,9 +42,8 @@ __device__ __forceinline__ u32x4 pack8(const float* v) {
 // forward: one wave = 32 pixels x NT*32 channels per step, grid-stride over pixel tiles
 // ---------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
+__device__ __forceinline__ void conv_first_fwd_body(const FirstArgs& p, unsigned char* smem) {
     constexpr int ROWB = NT * 64 + 16;                      // LDS row: NT*32 channels bf16 + pad
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * ROWB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
     unsigned char* T = smem + wave * 32 * ROWB;
@@ -150,6 +149,14 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
         }
     }
 }
+// (A wave handles one 32-pixel tile at a time -- 16 gathers -> 4 MFMAs -> LDS -> 4 KB of stores, a dependent chain of ~4.6 us --
+// so the rate follows the resident waves: 160 registers = 3 per SIMD.  Capped at 128 registers (4 per SIMD, 9 spilled)
+// the kernel measured 0.135 instead of 0.132 ms: not kept, gpurun r03_u.)
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * (NT * 64 + 16)];
+    conv_first_fwd_body<NT>(p, smem);
+}
 
 // ---------------------------------------------------------------------------------
 // weight gradient: dW[k][n] = sum_m xcol[m][k] * dy[m][n], k = tap*Ci + c < 32
@@ -221,10 +228,12 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstArgs p) {
         }
     };
 
-    f32x16 acc;
+    f32x16 acc, accb;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = accb[r] = 0.f;
+    s16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;       // bf16 1.0
     const int kh = wave >> 1, nh = wave & 1;
     const int lh = lane >> 5, q = lane & 15, cb = (lane >> 4) & 1;
     const int prow = kh * 32 + lh * 8 + (q >> 2);
@@ -250,15 +259,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstArgs p) {
             const s16x8 a = tr8(S, xa + st * 16 * XROWB, XROWB);
             const s16x8 bq = tr8(S, ya + st * 16 * YROWB, YROWB);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), acc, 0, 0, 0);
-        }
-        if (tid < 64) {        // bias gradient: channel tid over the 64 pixel rows of the tile
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < BP; ++r) {
-                const int slot = (tid >> 3) ^ (((r >> 1) & 1) * 4);
-                s += bf2f(*reinterpret_cast<const unsigned short*>(S + X_LDS + r * YROWB + slot * 16 + (tid & 7) * 2));
-            }
-            bsum += s;
+            // bias gradient on the matrix cores: every row of ones^T dy is the column sum over this wave's 32 pixels (a
+            // scalar LDS sweep of the tile by wave 0 made that wave every tile's straggler)
+            accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bq), accb, 0, 0, 0);
         }
     }
     // two partial slabs per split (pixel halves): slab index = 2*split + kh; the fixed-order reduce adds them
@@ -271,10 +274,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstArgs p) {
         const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (k < K) slab[(size_t)k * p.Co + n] = acc[r];
     }
-    if (tid < 64) {
-        slab[wcount + tid] = bsum;                                           // kh == 0 slab of this split
-        p.ws[(size_t)(2 * split + 1) * (wcount + p.Co) + wcount + tid] = 0.f;   // the kh == 1 slab carries no bias part
-    }
+    if (lh == 0) slab[wcount + n] = accb[0];      // row 0 of ones^T dy: this wave's pixel half, its 32 channels
 }
 
 // ---------------------------------------------------------------------------------
@@ -306,7 +306,12 @@ void conv_first_fwd_bf16(const ConvDesc& d, const float* x, const float* w, cons
 static int first_wgrad_splits(const ConvDesc& d, int* mchunk) {
     const int M = d.B * d.Ho * d.Wo;
     int ns = cdiv(M, 64 * 24);                 // >= 24 iterations per workgroup
-    if (ns > 1024) ns = 1024;
+    // Bytes in flight set this kernel's rate (one 8-KB dy tile per workgroup: 1024 x 8 KB / ~3 us of loaded round trip =
+    // 2.8 TB/s, measured 2.5): 88 registers let five workgroups share a CU -> 1280 (SSD_FIRST_WGRAD_WGS; 1024 = round 2).
+    // Round 3, per-layer events of the step: 0.159 ms -> 0.136 with the bias gradient on the matrix cores -> 0.129 with
+    // 1280 workgroups; 1536 (a second, partial round) gains nothing.
+    static const int cap = env_int("SSD_FIRST_WGRAD_WGS", 1280);
+    if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     *mchunk = cdiv(cdiv(M, ns), 64) * 64;
     return cdiv(M, *mchunk);
