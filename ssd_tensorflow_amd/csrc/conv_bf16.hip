@@ -880,9 +880,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum = 0.f;
+    // bias gradient (workgroups of tap 0, channel tile 0) on the matrix cores: ones^T dy in the waves with wm == 0 -- round 3;
+    // the scalar LDS sweep of the dy tile by one wave made those workgroups the grid's stragglers
+    f32x16 accb[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[b][r] = 0.f;
+    s16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;       // bf16 1.0
 
     const int wm = wave / WN, wn = wave - wm * WN;
+    const bool bias_wave = do_bias && wm == 0;
     const int li = lane & 31, lh = lane >> 5;
     // transpose-read addressing (bf16_probe.hip): inside a 16-lane group lane q supplies the 8 bytes at
     // (pixel row q>>2, channel quad q&3); lane l receives, for j = 0..3, pixel row j of channel l&15.
@@ -928,18 +938,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
                 for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[st & 1][mi]),
                                                                          __builtin_bit_cast(bf16x8, b[st & 1][ni]), acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (do_bias && tid < BNT) {
-            // column sums of dy for the bias gradient, from the same LDS tile (channel tid of every pixel row)
-            const unsigned char* Ys = S + X_LDS;
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < BP; ++r) {
-                const int slot = (tid >> 3) ^ swz(r, YCPR);
-                s += bf2f(*reinterpret_cast<const unsigned short*>(Ys + r * YROWB + slot * 16 + (tid & 7) * 2));
+            if (bias_wave) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    accb[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, b[st & 1][ni]),
+                                                                      accb[ni], 0, 0, 0);
             }
-            bsum += s;
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -972,7 +977,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
             }
         }
     }
-    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[wcount + n0 + tid] = bsum;
+    if (bias_wave && lh == 0) {      // every row of ones^T dy is the column sum: row 0 lives in r = 0 of lanes 0..31
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 32 * TN + ni * 32 + li;
+            if (n < p.Co) slab[wcount + n] = accb[ni][0];
+        }
+    }
 }
 
 // =================================================================================
