@@ -240,8 +240,10 @@ def expected_losses(preset, batch, dtype):
 def self_check(out, serialized):
     """Cross-checks a block must pass before it is printed (a block that fails is replaced by its error, the headline
     aborts): the dominant kernel cannot take longer per step than the step; kernels measured one at a time (serialized
-    pass) cannot sum to much more than the overlapped step that ran them side by side -- 1.2x, the overlap's gain is
-    4-17 % -- nor, measured inside a region that does not overlap (decode), to more than the step; no fraction above 1."""
+    pass) cannot sum to much more than the overlapped step that ran them side by side -- 1.3x: the overlap's measured gain
+    is 2-17 % (bf16 training 1.16-1.17), while per-launch events taken INSIDE an overlapped region sum to ~2x (round 2's
+    inference block) -- nor, measured inside a region that does not overlap (decode), to more than the step; no fraction
+    above 1."""
     problems = []
     ms = out['ms_per_step']
     kms = out.get('kernel_ms_per_step') or {}
@@ -251,15 +253,15 @@ def self_check(out, serialized):
         dom, dom_ms = max(kms.items(), key=lambda kv: kv[1])
         if dom_ms > ms:
             problems.append(f'dominant kernel {dom} {dom_ms:.3f} ms/step > ms_per_step {ms:.3f}')
-    if ksum is not None and ksum > (1.2 if serialized else 1.0) * ms:
-        problems.append(f'kernel sum {ksum:.3f} ms/step > {"1.2 x " if serialized else ""}ms_per_step {ms:.3f}')
+    if ksum is not None and ksum > (1.3 if serialized else 1.0) * ms:
+        problems.append(f'kernel sum {ksum:.3f} ms/step > {"1.3 x " if serialized else ""}ms_per_step {ms:.3f}')
     if r is not None and not (0.0 < r['frac'] <= 1.0):
         problems.append(f'roofline.frac {r["frac"]} outside (0, 1]')
     if out.get('model_mfma_frac') is not None and not (0.0 < out['model_mfma_frac'] <= 1.0):
         problems.append(f'model_mfma_frac {out["model_mfma_frac"]} outside (0, 1]')
     if problems:
         raise SystemExit('[bench] self-check failed: ' + '; '.join(problems))
-    return 'dominant kernel <= step, kernel sum <= %sstep, fractions in (0, 1]' % ('1.2 x ' if serialized else '')
+    return 'dominant kernel <= step, kernel sum <= %sstep, fractions in (0, 1]' % ('1.3 x ' if serialized else '')
 
 
 def run_config(a, rank, world, local):
