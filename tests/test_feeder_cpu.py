@@ -139,3 +139,19 @@ def test_abandoned_epoch_and_failing_worker():
         _same(want, _collect(td, td.train_generator, 4, 2))
     finally:
         td.close()
+
+
+def test_batches_that_do_not_fit_a_slot_travel_through_the_pipe():
+    """A slot sized for smaller images than the data set holds (a source whose annotations understate its files): the
+    worker sends that batch through the result pipe instead of the slot; nothing changes for the consumer."""
+    _prime()
+    td = TrainingData(None, 'vgg300', num_train=12, num_valid=4, augment=True, device_tensors=False)
+    td._upload_hook = _host_upload
+    try:
+        want = _collect(td, td.train_generator, 4, 0)
+        td._max_image_bytes = 1000                      # every batch overflows its slot now
+        got = _collect(td, td.train_generator, 4, 2)
+        _same(want, got)
+        assert td._recipes['train'].pool.slot_bytes < sum(v.nbytes for v in want[0][0].values())
+    finally:
+        td.close()

@@ -143,3 +143,18 @@ def test_two_ranks_with_workers_stay_in_lock_step(tmp_path):
         assert set(got) == {'0', '1'} and got['0'] == got['1'], r.stdout[-2000:]
         sums[workers] = (got['0'], [l for l in r.stdout.splitlines() if l.startswith(('[i] Train', '[i] Valid', '[i] mAP'))])
     assert sums[0] == sums[2]
+
+
+def test_batch_larger_than_its_slot_takes_the_serial_upload():
+    """A batch that does not fit its host slot comes through the result pipe; the feeder thread then uploads it with the
+    serial path (own copies, label encoder with host arrays) into the same device slot ring: same tensors."""
+    td = TrainingData(None, 'vgg300', num_train=10, num_valid=4, augment=True)
+    try:
+        serial = _drain(td.train_generator, 4, 0)
+        td._max_image_bytes = 1000
+        got = _drain(td.train_generator, 4, 2)
+        assert len(got) == len(serial) == 3
+        for (xa, ya, ga), (xb, yb, gb) in zip(serial, got):
+            assert np.array_equal(xa, xb) and np.array_equal(ya, yb) and ga == gb
+    finally:
+        td.close()
