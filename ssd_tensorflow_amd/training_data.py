@@ -486,6 +486,9 @@ class TrainingData:
             ring = self._device_ring(batch_size)
             fstream = ring['stream']
             dev = torch.device('cuda', self.device)
+            # the device slots start out free: whatever the caller still has enqueued on batches of an earlier generator
+            # (the last steps of the previous epoch) reads them and must have run before the first uploads land
+            fstream.wait_stream(torch.cuda.current_stream(dev))
         pool.generation += 1
         gen = pool.generation
         nb = len(batches)
