@@ -64,9 +64,26 @@ struct OutMap { int M, DH, DW, ph, pw, ODH, ODW; };      // parity class: virtua
 // A raw s_barrier, not __syncthreads(): the latter's fence drains vmcnt to 0 and with it the tiles that
 // are meant to stay in flight across the barrier.  Every ds_read of the previous tile has already been
 // consumed by an MFMA (lgkmcnt) when a wave arrives here, so the stage it frees can be refilled at once.
-template <int L>
+template <int L, int MAXA = 2>
 __device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
-    static_assert(2 * L <= 63, "vmcnt field");
+    static_assert(2 * L <= 63 && MAXA * L <= 63, "vmcnt field");
+    // (deep rings of the small-layer configurations: up to MAXA tiles stay in flight; the branches are wave-uniform)
+    if constexpr (MAXA >= 4) {
+        if (ahead >= 4) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * L) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            return;
+        }
+    }
+    if constexpr (MAXA >= 3) {
+        if (ahead == 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            return;
+        }
+    }
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     int st_c = 0, st_i = NS - 1;
     for (int k = 0; k < nk; ++k) {
         const int later = nk - 1 - k;
-        wait_tiles_and_sync<A_N + B_N>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
+        wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
         if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
         compute(st_c);
         st_c = st_c + 1 == NS ? 0 : st_c + 1;
@@ -1755,14 +1772,15 @@ static void check_desc_h(const ConvDesc& d) {
 //   0: 128x128 x2 (2/CU)   1: 128x64 x2 (2/CU)   2: 64x128 x2 (2/CU)
 //   3: 256x128 x3 (1/CU)   4: 128x128 x4 (1/CU)  5: 128x64 x3 (2/CU)
 //   6: 256x128 x3, 8 waves (1/CU)   7: 256x128 x2, 8 waves (1/CU)   8: 256x64 x2, 8 waves (2/CU)
-constexpr int NCFG_H = 9;
+//   9: 64x64 x6 (1/CU): the latency-bound small layers (see pick_tile_h)
+constexpr int NCFG_H = 10;
 static int pick_tile_h(long long M, int N, int mode) {
     static const int forced = env_int("SSD_TILE_BF16", -1);      // tuning override
     if (forced >= 0 && forced < NCFG_H) return forced;
-    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64};
-    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2};
+    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256, 64}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64, 64};
+    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2, 1};
     // > 0: in the automatic choice.  256x64 (8 waves) serves the 64-channel layers: conv1_2 forward 427 -> 462, data gradient 423 -> 474 TF/s
-    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93};
+    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93, 0.0};
     int best = 0;
     double bc = 1e300;
     for (int c = 0; c < NCFG_H; ++c) {
@@ -1783,6 +1801,12 @@ static int pick_tile_h(long long M, int N, int mode) {
         if (wgs <= 256 * small_deep) {
             if (best == 0) best = 4;           // 128x128 x4
             else if (best == 1) best = 5;      // 128x64 x3
+            // Round 4: such a launch's time IS its serial k loop (conv9_2: 18 iterations, the 10x10 map's head: 72) at
+            // ~0.7 us per iteration -- one DMA round trip for two tiles in flight.  64x64 tiles stage 16 KB per iteration
+            // instead of 24 and a ring of SIX keeps four in flight; the launch also spreads over up to four times the
+            // CUs.  Taken while it still fits one workgroup per CU.  SSD_SMALL_TILE=0 switches it off (A/B).
+            static const int small_tile = env_int("SSD_SMALL_TILE", 1);
+            if (small_tile && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256) best = 9;
         }
     }
     return best;
@@ -1792,10 +1816,10 @@ template <int MODE>
 static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hipStream_t s) {
     static const char* const names[2][NCFG_H] = {
         {"conv_fwd_bf16_128x128", "conv_fwd_bf16_128x64", "conv_fwd_bf16_64x128", "conv_fwd_bf16_256x128x3", "conv_fwd_bf16_128x128x4",
-         "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w"},
+         "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w", "conv_fwd_bf16_64x64x6"},
         {"conv_dgrad_bf16_128x128", "conv_dgrad_bf16_128x64", "conv_dgrad_bf16_64x128", "conv_dgrad_bf16_256x128x3",
          "conv_dgrad_bf16_128x128x4", "conv_dgrad_bf16_128x64x3", "conv_dgrad_bf16_256x128x3_8w", "conv_dgrad_bf16_256x128x2_8w",
-         "conv_dgrad_bf16_256x64_8w"}};
+         "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6"}};
     const char* label = names[MODE][cfg];
     switch (cfg) {
     case 0: launch_gather_h<MODE, 2, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
@@ -1806,7 +1830,8 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
     case 5: launch_gather_h<MODE, 4, 1, 1, 2, false, 3>(a, label, fl, by, s); break;
     case 6: launch_gather_h<MODE, 4, 2, 2, 2, false, 3>(a, label, fl, by, s); break;
     case 7: launch_gather_h<MODE, 4, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
-    default: launch_gather_h<MODE, 8, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
+    case 8: launch_gather_h<MODE, 8, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
+    default: launch_gather_h<MODE, 2, 2, 1, 1, false, 6>(a, label, fl, by, s); break;
     }
 }
 

@@ -1435,6 +1435,11 @@ void wgrad_reduce_flush(ReduceBatch& batch, hipStream_t s) {
 
 void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
                   hipStream_t s) {
+    // measurement aid (tools/step_time.py): SSD_ABLATE=reduce drops the slab reduces to price them inside the overlapped step
+    {
+        const char* v = getenv("SSD_ABLATE");
+        if (v && strstr(v, "reduce")) return;
+    }
     if (g_reduce_batch) {
         const size_t total4 = (wcount + Co) / 4;
         // enough workgroups to spread over the chip, enough slabs per thread to be worth a thread

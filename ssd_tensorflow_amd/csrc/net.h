@@ -19,6 +19,8 @@ struct Tensor {
     bool relu_out = false;   // produced by conv+relu: gradients written into it get the relu mask
     int consumers = 0;       // ops reading it in forward
     int done = 0;            // backward bookkeeping
+    int gstream = 0;         // backward: stream class (0 main, 1 side) of the last kernel that wrote grad ...
+    long gseq = 0;           // ... and its number in that class' issue order (net.hip bw_need)
     bool data_f32 = true;    // storage of data: fp32, or bf16 (bf16 configuration, every tensor but the image and the head outputs)
     bool grad_f32 = true;    // storage of grad
     void* data = nullptr;
@@ -169,7 +171,27 @@ private:
     } bw_lane_[2] = {};
     int bw_nl_ = 1;
     int tail_first_ = 0;                 // op index of conv8_1: the extra layers behind it form backward's side chain
-    bool bw_heads_side_ = false;         // head data gradients in flight on the side stream (backward)
+    // Issue orders (net.hip build_orders): forward walks fwd_order_ (every multibox head right behind its feature map), backward
+    // walks bwd_order_ (the latency-bound chain of small heads and extra layers first, the 38x38 head deferred beside mod_conv6)
+    std::vector<int> fwd_order_, bwd_order_;
+    int bw_gate_op_ = -1;                // backward: the main stream waits for the side chain before this op (head 1), -1: none
+    std::vector<char> bw_conv_done_;     // backward: conv ops processed so far (indexed like ops_)
+    // backward stream classes: 0 = a lane's main stream, 1 = its side stream.  bw_issued_[c] counts the kernels class c has been
+    // given that write a gradient, bw_seen_[x][y] is the count of class y that class x has already been made to wait for
+    long bw_issued_[2] = {0, 0}, bw_seen_[2][2] = {{0, 0}, {0, 0}};
+    hipEvent_t ev_m2s_[2] = {nullptr, nullptr};      // main -> side hand-off, per lane
+    bool bw_first_on_main_ = false;      // the first layer's weight gradient was issued on the main stream (backward_step)
+    std::vector<int> bw_deferred_;       // backward: head ops whose weight gradient waits for the chain to be issued
+    bool bw_chain_done_ = false;
+    bool defers_head_wgrads() const;
+    void launch_wgrad(int op_index, int b, hipStream_t ws);
+    void flush_deferred_wgrads();
+    void build_orders();
+    int bw_class(const Op& op, int op_index) const;
+    void bw_sync(int x, int y);          // class x waits for everything class y has been given so far (every lane)
+    void bw_need(int x, const Tensor& t) { if (t.gstream != x && t.gseq > bw_seen_[x][t.gstream]) bw_sync(x, t.gstream); }
+    void bw_wrote(int x, Tensor& t) { t.gstream = x; t.gseq = ++bw_issued_[x]; }
+    size_t bw_final_lo() const;          // lowest arena offset such that every filter at or above it has its final gradient
     bool overlap_ = true;
     bool own_wstream_ = true;
     bool h2_is_s2_ = false;                // the second lane's heads run on its main stream (no side stream of its own)
@@ -213,7 +235,7 @@ private:
     float momentum_ = 0.9f, wd_ = 0.0005f;
     float loss_bnorm_ = 0.f;
     Profiler prof_;
-    int bw_next_ = -1, bw_b_ = 0;
+    int bw_pos_ = 0, bw_b_ = 0;          // next entry of bwd_order_
     size_t bw_done_off_ = 0;
 };
 

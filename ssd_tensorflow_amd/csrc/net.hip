@@ -135,6 +135,7 @@ void Net::build_graph() {
     tail_first_ = (int)ops_.size();
     for (size_t i = 0; i < ops_.size(); ++i)
         if (ops_[i].name == "conv8_1") tail_first_ = (int)i;
+    build_orders();
     // ---- arena layout: all filters (forward order), all biases, the l2-norm scale ----
     size_t off = 0;
     for (auto& op : ops_)
@@ -178,6 +179,141 @@ void Net::build_graph() {
         }
     }
     add_var("l2_norm_conv4_3/scale", 1, 512, 0, 0, 0, scale_off_, 1, 512, 512);
+}
+
+// Measurement aid (tools/step_time.py), never set in a product run: SSD_ABLATE=<tokens> drops groups of launches from the
+// step so their price INSIDE the overlapped step can be read off (results are wrong by construction).  Tokens: pool, tail
+// (conv8_2 ... conv11_2 and the small maps' heads), heads01, conv1, conv5, l2norm, reduce (conv_igemm.hip).
+static bool ablated(const char* token) {
+    const char* v = getenv("SSD_ABLATE");      // (not cached: the tool switches it on after un-ablated warmup steps)
+    return v && strstr(v, token);
+}
+static bool op_ablated(const std::string& name, int kind, int head, int k) {
+    if (!getenv("SSD_ABLATE")) return false;
+    if (kind == 1) return k == 2 && ablated("pool");
+    if (kind == 2) return ablated("l2norm");
+    if (head >= 2) return ablated("tail");
+    if (head >= 0) return ablated("heads01");
+    if (name.rfind("conv1_", 0) == 0 && name.size() == 7) return ablated("conv1");
+    if (name.rfind("conv5_", 0) == 0) return ablated("conv5");
+    if (name.rfind("conv8_2", 0) == 0 || name.rfind("conv9_", 0) == 0 || name.rfind("conv10_", 0) == 0 || name.rfind("conv11_", 0) == 0 ||
+        name.rfind("conv12_", 0) == 0)
+        return ablated("tail");
+    return false;
+}
+
+static int env_i(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Issue orders.  The op list is the reference's graph order (ssdvgg.py:190-372: trunk, extra layers, l2-norm, classifiers); the
+// arena layout and the variables follow it.  What is ISSUED when is a separate matter:
+//  * Forward: a branch op (the l2-norm, a fused multibox head) is issued right behind the tensor it reads.  In graph order
+//    all of them sat behind conv11_2, and because the heads of a lane share one in-order side stream whose first entry
+//    (head 0) needs the l2-norm, the six heads ran back to back AFTER the trunk on a nearly empty chip: 340 us of a
+//    7.47 ms bf16 step with fewer than 256 workgroups in flight (profiles/r04_a_timeline_bf16.txt; fp32: 0.6 ms).
+//  * Backward: the latency-bound chain (small heads' data gradients -> conv11_2 ... conv8_2) is what the first big data
+//    gradient (conv8_1 -> mod_conv7 -> mod_conv6) waits for, and its launches queue for LDS behind whatever fills the CUs
+//    beside them (gaps of 35-40 us between two chain kernels in the same trace).  So: the chain first; head 1's data
+//    gradient (main stream) gated behind a point of the chain (SSD_BW_HEAD1_POS chain ops, default: its end); head 0's data
+//    gradient and the l2-norm backward deferred to the side stream beside mod_conv6's data gradient (1.4 rounds of
+//    workgroups, idle CUs in its tail) -- they are needed by pool4's backward only.
+// SSD_FWD_ORDER=0 / SSD_BW_ORDER=0 restore graph order (A/B switches).
+void Net::build_orders() {
+    const int n = (int)ops_.size();
+    fwd_order_.clear();
+    if (env_i("SSD_FWD_ORDER", 1) == 0) {
+        for (int i = 0; i < n; ++i) fwd_order_.push_back(i);
+    } else {
+        std::vector<char> placed(n, 0);
+        std::vector<int> stack;
+        for (int i0 = 0; i0 < n; ++i0) {
+            if (placed[i0]) continue;
+            stack.assign(1, i0);
+            while (!stack.empty()) {
+                const int i = stack.back();
+                stack.pop_back();
+                if (placed[i]) continue;
+                placed[i] = 1;
+                fwd_order_.push_back(i);
+                for (int j = n - 1; j > i; --j)      // (pushed in reverse: popped in graph order)
+                    if (!placed[j] && ops_[j].in == ops_[i].out && (ops_[j].kind == OP_L2NORM || ops_[j].head >= 0)) stack.push_back(j);
+            }
+        }
+    }
+    bwd_order_.clear();
+    bw_gate_op_ = -1;
+    std::vector<int> R;
+    for (int i = n - 1; i >= 0; --i) R.push_back(i);
+    int h0 = -1, h1 = -1, l2 = -1;
+    for (int i = 0; i < n; ++i) {
+        if (ops_[i].kind == OP_CONV && ops_[i].head == 0) h0 = i;
+        if (ops_[i].kind == OP_CONV && ops_[i].head == 1) h1 = i;
+        if (ops_[i].kind == OP_L2NORM) l2 = i;
+    }
+    if (env_i("SSD_BW_ORDER", 0) == 0 || h0 < 0 || h1 < 0 || l2 < 0) {
+        bwd_order_ = R;
+        return;
+    }
+    std::vector<int> small, tail, rest;
+    for (int i : R) {
+        const Op& op = ops_[i];
+        if (i == h0 || i == h1 || i == l2) continue;
+        if (op.kind == OP_CONV && op.head >= 2) small.push_back(i);
+        else if (op.kind == OP_CONV && op.head < 0 && i > tail_first_) tail.push_back(i);
+        else rest.push_back(i);
+    }
+    int k = env_i("SSD_BW_HEAD1_POS", (int)tail.size());
+    k = std::max(0, std::min(k, (int)tail.size()));
+    bwd_order_ = small;
+    for (int j = 0; j < k; ++j) bwd_order_.push_back(tail[j]);
+    bwd_order_.push_back(h1);
+    if (k > 0) bw_gate_op_ = h1;
+    for (int j = k; j < (int)tail.size(); ++j) bwd_order_.push_back(tail[j]);
+    bool deferred = false;
+    const bool defer = env_i("SSD_BW_DEFER_HEAD0", 1) != 0;
+    if (!defer) { bwd_order_.push_back(h0); bwd_order_.push_back(l2); deferred = true; }
+    for (int i : rest) {
+        bwd_order_.push_back(i);
+        if (!deferred && ops_[i].out == ops_[h1].in) {      // behind the producer of head 1's feature map (mod_conv7)
+            bwd_order_.push_back(h0);
+            bwd_order_.push_back(l2);
+            deferred = true;
+        }
+    }
+    SSD_REQUIRE(deferred && (int)bwd_order_.size() == n, "backward order construction failed");
+}
+
+// stream class of an op's data gradient in backward: 0 = main stream, 1 = side stream (see build_orders)
+int Net::bw_class(const Op& op, int op_index) const {
+    static const bool bw_side_on = env_i("SSD_BW_SIDE", 1) != 0;      // A/B switch
+    static const bool defer = env_i("SSD_BW_ORDER", 0) != 0 && env_i("SSD_BW_DEFER_HEAD0", 1) != 0;
+    if (!(hstream_ && overlap_ && bw_side_on)) return 0;
+    if (op.kind == OP_CONV && op.head >= 2) return 1;                              // small maps' heads: a few workgroups each
+    if (op.kind == OP_CONV && op.head < 0 && op_index > tail_first_) return 1;     // conv11_2 ... conv8_2 behind them
+    if (defer && ((op.kind == OP_CONV && op.head == 0) || op.kind == OP_L2NORM)) return 1;
+    return 0;
+}
+
+void Net::bw_sync(int x, int y) {
+    for (int li = 0; li < bw_nl_; ++li) {
+        const BwLane& ln = bw_lane_[li];
+        hipEvent_t ev = y == 1 ? ln.ev_h : ev_m2s_[li];
+        HIP_OK(hipEventRecord(ev, y == 1 ? ln.h : ln.s));
+        HIP_OK(hipStreamWaitEvent(x == 1 ? ln.h : ln.s, ev, 0));
+    }
+    bw_seen_[x][y] = bw_issued_[y];
+}
+
+size_t Net::bw_final_lo() const {
+    size_t lo = nfilters_;
+    for (int i = (int)ops_.size() - 1; i >= 0; --i) {
+        if (ops_[i].kind != OP_CONV) continue;
+        if (!bw_conv_done_[i]) break;
+        lo = ops_[i].w_off;      // conv ops own descending, adjacent filter ranges
+    }
+    return lo;
 }
 
 size_t Net::arena_floats(const char* preset, int num_classes) {
@@ -352,6 +488,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     HIP_OK(hipEventCreateWithFlags(&ev2_dy_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_l2_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ev_m2s_[i], hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev2_fmap_[i], hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev_fmap_[i], hipEventDisableTiming));
     if (training_) {
@@ -404,6 +541,7 @@ Net::~Net() {
         (void)hipEventDestroy(ev2_dy_);
         (void)hipEventDestroy(ev_l2_);
         (void)hipEventDestroy(ev_join_);
+        for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev_m2s_[i]);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev2_fmap_[i]);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev_fmap_[i]);
     }
@@ -436,6 +574,11 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     static const int lanes_env = [] { const char* v = getenv("SSD_FWD_LANES"); return v ? atoi(v) : 0; }();
     const int want_lanes = lanes_env > 0 ? lanes_env : 2;
     const int nl = (want_lanes >= 2 && side && s2_ && b >= 8) ? 2 : 1;
+    // A/B switch: with two lanes the multibox heads run as full-batch launches (see the head ops below)
+    static const bool heads_full_on = env_i("SSD_HEADS_FULL", 1) != 0;
+    const bool heads_full = heads_full_on && nl == 2;
+    static const long long merge_m = env_i("SSD_FWD_MERGE_M", 0);      // A/B switch, default OFF (0 = the lanes never merge; 12000 = at the 19x19 maps)
+    int nl_cur = nl;
     struct Lane {
         hipStream_t s, h;
         hipEvent_t* ev_fmap;
@@ -471,31 +614,57 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         l2_partials(params_, nfilters_, lw_, side ? hstream_ : stream_);
         if (nl == 2) HIP_OK(hipEventRecord(ev_l2_, hstream_));
     }
-    for (const Op& op : ops_) {
+    for (const int op_index : fwd_order_) {
+        const Op& op = ops_[op_index];
         const Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
         prof_.layer = op.name.c_str();
-        for (int li = 0; li < nl; ++li) {
+        if (op_ablated(op.name, op.kind, op.head, op.k)) continue;
+        // Optional (SSD_FWD_MERGE_M, default off): the lanes MERGE where the trunk gets small (the 19x19 maps and below at
+        // batch 32).  There a half-batch launch takes as long as the full batch's when it runs alone -- conv5_2 forward 52 us
+        // at batch 16, 61 us at batch 32; mod_conv7 22 / 39 (profiles/r04_f_tile_sweep_19x19_bf16.txt) -- so two lanes looked
+        // like paying the layer twice.  Measured in the step (three interleaved rounds on one box,
+        // profiles/r04_g_ab_schedule_bf16.txt) the merged tail is SLOWER: 7.325 vs 7.274 ms -- side by side the two lanes' kernels
+        // fill each other's partial rounds, which is what the lanes are for.  Kept as a switch.
+        if (nl_cur == 2 && heads_full && op.head < 0 && op.kind != OP_L2NORM && (long long)b * out.H * out.W <= merge_m) {
+            HIP_OK(hipEventRecord(ev_join_, s2_));
+            HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
+            lane[0].nb = b;
+            nl_cur = 1;
+        }
+        for (int li = 0; li < nl_cur; ++li) {
             Lane& ln = lane[li];
             const int nb = ln.nb;
             switch (op.kind) {
             case OP_CONV: {
                 hipStream_t cs = ln.s;
+                int run_nb = nb, run_b0 = ln.b0;
                 if (op.head >= 0 && side) {
                     // the multibox heads hang off the trunk: they run on a side stream behind their feature
                     // map and fill the CUs the trunk's kernels leave idle between waves of workgroups
                     HIP_OK(hipEventRecord(ln.ev_fmap[op.head], ln.s));
-                    HIP_OK(hipStreamWaitEvent(ln.h, ln.ev_fmap[op.head], 0));
-                    cs = ln.h;
-                    ln.heads_on_side = true;
+                    if (heads_full) {
+                        // ONE launch over the whole batch on lane 0's side stream, behind both lanes' feature maps: half the
+                        // launches, twice the workgroups each, and lane 1's trunk (whose own "side" stream is its main
+                        // stream) does not queue behind its heads
+                        if (li < nl_cur - 1) break;
+                        for (int l = 0; l < nl_cur; ++l) HIP_OK(hipStreamWaitEvent(hstream_, lane[l].ev_fmap[op.head], 0));
+                        cs = hstream_;
+                        run_nb = b; run_b0 = 0;
+                        lane[0].heads_on_side = true;
+                    } else {
+                        HIP_OK(hipStreamWaitEvent(ln.h, ln.ev_fmap[op.head], 0));
+                        cs = ln.h;
+                        ln.heads_on_side = true;
+                    }
                 }
-                const ConvDesc d = conv_desc(op, nb);
+                const ConvDesc d = conv_desc(op, run_nb);
                 if (ln.cast_pending && !in.data_f32) {
                     HIP_OK(hipStreamWaitEvent(ln.s, ev_cast_, 0));
                     ln.cast_pending = false;
                 }
-                const float* xin = reinterpret_cast<const float*>(at(in, ln.b0));
-                void* yout = at(out, ln.b0);
+                const float* xin = reinterpret_cast<const float*>(at(in, run_b0));
+                void* yout = at(out, run_b0);
                 if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
                 else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
@@ -531,7 +700,15 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     // lane's has been enqueued, the count never reaches the step's total and the ticket would stay non-zero for the life
     // of the handle -- drain the device and clear it before the error leaves.
     try {
-    for (int li = 0; li < nl; ++li) {
+    if (heads_full) {      // full-batch heads: one loss / result launch on the main stream behind the side stream and lane 1
+        HIP_OK(hipEventRecord(ev_h_, hstream_));
+        HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
+        HIP_OK(hipEventRecord(ev_join_, s2_));
+        HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
+        if (train_mode) multibox_loss(heads_, b, 0, b, result_, y, lw_, wd_, loss_bnorm_, stream_);
+        else heads_result(heads_, b, result_, stream_);
+    }
+    for (int li = 0; li < nl && !heads_full; ++li) {
         Lane& ln = lane[li];
         if (ln.heads_on_side) {
             HIP_OK(hipEventRecord(ln.ev_h, ln.h));
@@ -571,6 +748,47 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
 // backward, whose scale gradient sums over the batch).  Default is ONE lane: backward already has the weight-gradient
 // stream filling the data gradients' tails, a third concurrent half-batch kernel only shrinks the tiles' reuse --
 // measured on one box (profiles/r02_l_ab_bwd_lanes_*.txt): fp32 -0.3 %, bf16 -7 %.
+bool Net::defers_head_wgrads() const {
+    static const bool on = env_i("SSD_BW_DEFER_HEAD_WGRAD", 0) != 0;      // default OFF: measured 7.456 vs 7.325 ms (r04_g)
+    return on && wstream_ && overlap_ && tail_first_ + 1 < (int)ops_.size() && bw_class(ops_[tail_first_ + 1], tail_first_ + 1) == 1;
+}
+
+void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
+    const Op& op = ops_[op_index];
+    const Tensor& in = tensors_[op.in];
+    const Tensor& out = tensors_[op.out];
+    const ConvDesc d = conv_desc(op, b);
+    float* slab = wgrad_ws_ + op.ws_off;
+    prof_.layer = op.name.c_str();
+    if (!bf16_) {
+        conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+    } else if (in.data_f32) {   // conv1_1
+        if (first_layer_kernel(d))
+            conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+        else
+            conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+    } else {
+        conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
+    }
+}
+
+// the heads' weight gradients held back by backward_step: behind everything the lanes' main streams have been given (their dy
+// is the loss gradient), in the order they were met
+void Net::flush_deferred_wgrads() {
+    if (bw_deferred_.empty()) return;
+    for (int li = 0; li < bw_nl_; ++li) {
+        HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, bw_lane_[li].s));
+        HIP_OK(hipStreamWaitEvent(wstream_, bw_lane_[li].ev_dy, 0));
+    }
+    const char* layer = prof_.layer;
+    for (int i : bw_deferred_) {
+        launch_wgrad(i, bw_b_, wstream_);
+        bw_conv_done_[i] = 1;
+    }
+    prof_.layer = layer;
+    bw_deferred_.clear();
+}
+
 void Net::backward_begin(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
@@ -586,20 +804,23 @@ void Net::backward_begin(int b, const float* y) {
         HIP_OK(hipEventRecord(ev_join_, stream_));
         HIP_OK(hipStreamWaitEvent(s2_, ev_join_, 0));
     }
+    for (Tensor& t : tensors_) { t.done = 0; t.gstream = 0; t.gseq = 0; }
+    bw_issued_[0] = bw_issued_[1] = 0;
+    bw_seen_[0][0] = bw_seen_[0][1] = bw_seen_[1][0] = bw_seen_[1][1] = 0;
     for (int li = 0; li < bw_nl_; ++li) {
         const BwLane& ln = bw_lane_[li];
         HeadLayout hl = heads_;
         for (int i = 0; i < hl.nmaps; ++i)
             hl.dbuf[i] = static_cast<char*>(heads_.dbuf[i]) + (size_t)ln.b0 * hl.hw[i] * hl.ld[i] * (hl.grad_bf16 ? 2 : 4);
         multibox_loss_grad(hl, ln.nb, ln.b0, result_ + (size_t)ln.b0 * A * nv, y + (size_t)ln.b0 * A * nv, lw_, ln.s);
-        if (side) {      // the small maps' head data gradients run beside the two big ones (backward_step)
-            HIP_OK(hipEventRecord(ln.ev_h, ln.s));
-            HIP_OK(hipStreamWaitEvent(ln.h, ln.ev_h, 0));
-        }
     }
-    bw_heads_side_ = false;
-    for (Tensor& t : tensors_) t.done = 0;
-    bw_next_ = (int)ops_.size() - 1;
+    for (int t : head_t_) bw_wrote(0, tensors_[t]);      // the loss gradient, on the lanes' main streams
+    if (side) bw_sync(1, 0);      // the side streams start behind it (the small maps' head data gradients: backward_step)
+    bw_conv_done_.assign(ops_.size(), 0);
+    bw_deferred_.clear();
+    bw_chain_done_ = false;
+    bw_first_on_main_ = false;
+    bw_pos_ = 0;
     bw_b_ = b;
     bw_done_off_ = nfilters_;
 }
@@ -622,34 +843,30 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     auto at = [](const Tensor& t, int b0, bool grad) -> char* {      // first element of sample b0
         return static_cast<char*>(grad ? t.grad : t.data) + (size_t)b0 * t.per_image() * ((grad ? t.grad_f32 : t.data_f32) ? 4 : 2);
     };
-    while (bw_next_ >= 0 && hi - lo < min_floats) {
-        const Op& op = ops_[bw_next_--];
+    // A/B switch: the first layer's weight gradient (no data gradient behind it: the main stream has gone idle by then) runs
+    // on the MAIN stream beside conv1_2's weight gradient instead of queueing behind it -- both are HBM-bound at half the
+    // achievable bandwidth (profiles/r04_a_timeline_bf16.txt: 7013 .. 7391 us of the step ran one such kernel at a time)
+    static const bool first_main = [] { const char* v = getenv("SSD_BW_FIRST_ON_MAIN"); return !(v && v[0] == '0'); }();
+    const int n_order = (int)bwd_order_.size();
+    while (bw_pos_ < n_order && hi - lo < min_floats) {
+        const int op_index = bwd_order_[bw_pos_++];
+        const Op& op = ops_[op_index];
         Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
         const bool need_dx = op.in != input_t_;
         const bool last = in.done + 1 == in.consumers;
         prof_.layer = op.name.c_str();
-        // Side region of backward.  (1) The multibox heads' data gradients are independent of each other (each is the
-        // first writer of its feature map's gradient): those of the small maps (a few workgroups, latency-bound) go to
-        // the side stream.  (2) So does the chain of extra layers behind them (conv11_2 ... conv8_2: eight dependent,
-        // latency-bound launches): it only needs the small heads' results and runs beside the two big heads' data
-        // gradients and the l2-norm backward on the main stream.  conv8_1 (which needs the chain's result and
-        // accumulates into mod_conv7's gradient after head 1) joins the streams.  (Per lane: each has its side stream.)
-        const int op_index = bw_next_ + 1;
-        static const bool bw_side_on = [] { const char* v = getenv("SSD_BW_SIDE"); return !(v && v[0] == '0'); }();      // A/B switch
-        const bool side_ok = hstream_ && overlap_ && bw_side_on;
-        const bool small_head = side_ok && op.kind == OP_CONV && op.head >= 2 && in.done == 0;
-        const bool in_tail = side_ok && op.kind == OP_CONV && op.head < 0 && op_index > tail_first_ && bw_heads_side_;
-        const bool independent = (op.kind == OP_CONV && op.head >= 0) || op.kind == OP_L2NORM;      // main-stream ops beside the region
-        if (bw_heads_side_ && !small_head && !in_tail && !independent) {
-            for (int li = 0; li < bw_nl_; ++li) {
-                HIP_OK(hipEventRecord(bw_lane_[li].ev_h, bw_lane_[li].h));
-                HIP_OK(hipStreamWaitEvent(bw_lane_[li].s, bw_lane_[li].ev_h, 0));
-            }
-            bw_heads_side_ = false;
+        // Where this op's data gradient runs (build_orders / bw_class): the small maps' heads, the chain of extra layers behind
+        // them and -- deferred -- head 0 with the l2-norm backward on the lanes' side streams, everything else on their main
+        // streams.  Hand-offs between the two are events placed where a kernel reads or accumulates into a gradient that the
+        // other class wrote last (bw_need): conv8_1 joins the chain, pool4's backward joins the deferred pair.
+        const int cls = bw_class(op, op_index);
+        if (op_ablated(op.name, op.kind, op.head, op.k)) {
+            if (op.kind == OP_CONV) { bw_conv_done_[op_index] = 1; lo = bw_final_lo(); }
+            in.done++;
+            continue;
         }
-        const bool on_side = small_head || in_tail;      // this op's data gradient runs on the lanes' side streams
-        if (small_head) bw_heads_side_ = true;
+        if (op_index == bw_gate_op_ && cls == 0 && bw_issued_[1] > bw_seen_[0][1]) bw_sync(0, 1);
         switch (op.kind) {
         case OP_CONV: {
             const ConvDesc d = conv_desc(op, b);
@@ -657,34 +874,47 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             // path.  They read the same dy and write disjoint buffers, so the weight gradient goes
             // to a side stream: its workgroups fill the CUs the data-gradient's last partial wave
             // of workgroups leaves idle (and vice versa).  It is ONE launch over the whole batch: it waits for the dy
-            // of every lane (final on the lane's side stream inside the tail chain, on its main stream elsewhere).
+            // of every lane, on the stream class that wrote it.
             const bool side = wstream_ && overlap_;
-            hipStream_t ws = side ? wstream_ : stream_;
+            const bool on_main = side && !need_dx && first_main && bw_nl_ == 1;
+            hipStream_t ws = (side && !on_main) ? wstream_ : stream_;
             float* slab = wgrad_ws_ + op.ws_off;
-            if (side) {
+            // Optional (SSD_BW_DEFER_HEAD_WGRAD=1, default off): the heads' weight gradients (one-round kernels of up to 252
+            // workgroups x 136 KB of LDS that live for 60-80 us) held back until the latency-bound chain behind the small heads
+            // has been ISSUED: beside it they take every CU's LDS and a chain kernel of a handful of workgroups waits tens of
+            // microseconds for a slot (profiles/r04_d_timeline_bf16.txt: a 4-workgroup launch "running" for 67 us).  The chain
+            // does get shorter, the step does not (+1.8 %): the held-back kernels then run beside conv8_1 / mod_conv7 / mod_conv6's
+            // data gradients on a full chip instead of beside the chain on an empty one.  Flushed at conv8_1.
+            const bool defer_w = op.head >= 0 && !bw_chain_done_ && defers_head_wgrads();
+            if (op_index == tail_first_) {      // conv8_1: the chain has been issued
+                bw_chain_done_ = true;
+                if (!bw_deferred_.empty()) { flush_deferred_wgrads(); side_used = true; }
+            }
+            if (defer_w) {
+                // (nothing to wait for yet: flush_deferred_wgrads orders the launch behind the main streams)
+            } else if (side && !on_main) {
+                // (dy written on the main streams but already waited for by the side streams, and this op lives there: the
+                // side stream is the one that is less far ahead -- head 0's weight gradient need not wait for mod_conv7)
+                const bool from_side = out.gstream == 1 || (cls == 1 && bw_seen_[1][0] >= out.gseq);
                 for (int li = 0; li < bw_nl_; ++li) {
-                    HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, in_tail ? bw_lane_[li].h : bw_lane_[li].s));
+                    HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, from_side ? bw_lane_[li].h : bw_lane_[li].s));
                     HIP_OK(hipStreamWaitEvent(wstream_, bw_lane_[li].ev_dy, 0));
                 }
                 side_used = true;
+            } else {
+                bw_need(0, out);
+                if (on_main) bw_first_on_main_ = true;
             }
             const bool mask = last && in.relu_out;
-            if (!bf16_) {
-                conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
-            } else if (in.data_f32) {   // conv1_1
-                if (first_layer_kernel(d))
-                    conv_first_wgrad_bf16(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
-                else
-                    conv_wgrad_smallc_bf16dy(d, in.f(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
-                                             slab, ws);
-            } else {
-                conv_wgrad_bf16(d, in.h(), out.gh(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
-            }
-            if (need_dx)
+            if (defer_w) bw_deferred_.push_back(op_index);
+            else launch_wgrad(op_index, b, ws);
+            if (need_dx) {
+                bw_need(cls, out);
+                if (in.done > 0) bw_need(cls, in);      // accumulates into what the other class wrote
                 for (int li = 0; li < bw_nl_; ++li) {
                     const BwLane& ln = bw_lane_[li];
                     const ConvDesc dl = conv_desc(op, ln.nb);
-                    hipStream_t ds = on_side ? ln.h : ln.s;
+                    hipStream_t ds = cls == 1 ? ln.h : ln.s;
                     if (!bf16_)
                         conv_dgrad(dl, reinterpret_cast<const float*>(at(out, ln.b0, true)), params_ + op.w_off,
                                    reinterpret_cast<float*>(at(in, ln.b0, true)), mask ? reinterpret_cast<const float*>(at(in, ln.b0, false)) : nullptr,
@@ -694,13 +924,18 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                                         reinterpret_cast<bf16_t*>(at(in, ln.b0, true)),
                                         mask ? reinterpret_cast<const bf16_t*>(at(in, ln.b0, false)) : nullptr, in.done > 0, ds);
                 }
-            lo = op.w_off;          // conv ops own descending, adjacent filter ranges
+                bw_wrote(cls, in);
+            }
+            if (!defer_w) bw_conv_done_[op_index] = 1;
+            lo = bw_final_lo();
             // a handful of layers per grouped reduce: few launches, yet interleaved with the data gradients instead of
             // one long pass after the last layer (which nothing would hide)
             if (reduce_batch_.items.size() >= 6) wgrad_reduce_flush(reduce_batch_, ws);
             break;
         }
         case OP_POOL:
+            bw_need(0, out);
+            if (in.done > 0) bw_need(0, in);
             for (int li = 0; li < bw_nl_; ++li) {
                 const BwLane& ln = bw_lane_[li];
                 PoolDesc d{ln.nb, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
@@ -717,24 +952,29 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                     maxpool_bwd(d, reinterpret_cast<const float*>(at(in, ln.b0, false)), reinterpret_cast<const float*>(at(out, ln.b0, true)),
                                 reinterpret_cast<float*>(at(in, ln.b0, true)), in.done > 0, last && in.relu_out, pws, ln.s);
             }
+            bw_wrote(0, in);
             break;
-        case OP_L2NORM:
+        case OP_L2NORM: {
             SSD_REQUIRE(in.done == 0 && !last, "l2norm backward must be the first of several consumers");
-            // the scale gradient sums over the batch: one launch on lane 0 behind lane 1's head gradient; lane 1 continues
-            // (pool4's backward accumulates into the same tensor) behind it
+            bw_need(cls, out);
+            // the scale gradient sums over the batch: one launch on lane 0's stream (of this op's class) behind lane 1's head
+            // gradient; lane 1 continues (pool4's backward accumulates into the same tensor) behind it
+            hipStream_t s0 = cls == 1 ? bw_lane_[0].h : bw_lane_[0].s, s1 = cls == 1 ? bw_lane_[1].h : bw_lane_[1].s;
             if (bw_nl_ == 2) {
-                HIP_OK(hipEventRecord(bw_lane_[1].ev_dy, bw_lane_[1].s));
-                HIP_OK(hipStreamWaitEvent(stream_, bw_lane_[1].ev_dy, 0));
+                HIP_OK(hipEventRecord(bw_lane_[1].ev_dy, s1));
+                HIP_OK(hipStreamWaitEvent(s0, bw_lane_[1].ev_dy, 0));
             }
             if (bf16_)
-                l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, stream_);
+                l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, s0);
             else
-                l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, stream_);
+                l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, s0);
             if (bw_nl_ == 2) {
-                HIP_OK(hipEventRecord(ev_l2_, stream_));
-                HIP_OK(hipStreamWaitEvent(s2_, ev_l2_, 0));
+                HIP_OK(hipEventRecord(ev_l2_, s0));
+                HIP_OK(hipStreamWaitEvent(s1, ev_l2_, 0));
             }
+            bw_wrote(cls, in);
             break;
+        }
         }
         in.done++;
     }
@@ -742,39 +982,71 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         prof_.layer = "stage";
         wgrad_reduce_flush(reduce_batch_, (wstream_ && overlap_) ? wstream_ : stream_);
     }
-    if (bw_next_ < 0 && bw_nl_ == 2) {      // the end of backward: lane 1 joins the main stream
+    const bool finished = bw_pos_ >= n_order;
+    if (finished && !bw_deferred_.empty()) {
+        flush_deferred_wgrads();
+        lo = bw_final_lo();
+    }
+    if (finished && bw_issued_[1] > bw_seen_[0][1]) bw_sync(0, 1);      // (every side-stream result has a main-stream reader: a no-op)
+    if (finished && bw_nl_ == 2) {      // the end of backward: lane 1 joins the main stream
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
     // The returned range is final in the weight-gradient stream's order.  Make it final in
     // main-stream order too unless the caller consumes it on the weight-gradient stream itself
     // (sync_main = false keeps the data gradients running ahead); the last stage always joins.
-    if (wstream_ && overlap_ && (side_used || bw_next_ < 0) && (sync_main || bw_next_ < 0)) {
+    if (wstream_ && overlap_ && (side_used || finished) && (sync_main || finished)) {
         HIP_OK(hipEventRecord(ev_w_, wstream_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_w_, 0));
     }
     // Overlap switched off (ssd_set_overlap(0) / SSD_OVERLAP_WGRAD=0): the weight gradients ran on the main
     // stream.  A caller that consumes the range on the weight-gradient stream (sync_main = false) must still
-    // find it final there, so that stream waits for the main stream instead.
-    if (wstream_ && !overlap_ && !sync_main) {
+    // find it final there, so that stream waits for the main stream instead.  The same holds for the first layer's weight
+    // gradient when it was issued on the main stream (above).
+    if (wstream_ && !sync_main && (!overlap_ || (finished && bw_first_on_main_))) {
         HIP_OK(hipEventRecord(ev_dy_, stream_));
         HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
     }
     bw_done_off_ = lo;
     *off = lo;
     *count = hi - lo;
-    return bw_next_ >= 0;
+    return !finished;
 }
 
 std::vector<std::pair<size_t, size_t>> Net::backward_ranges(size_t min_floats) const {
     std::vector<std::pair<size_t, size_t>> out;
-    size_t hi = nfilters_;
-    int next = (int)ops_.size() - 1;
-    while (next >= 0) {
+    std::vector<char> done(ops_.size(), 0);
+    auto final_lo = [&] {
+        size_t lo = nfilters_;
+        for (int i = (int)ops_.size() - 1; i >= 0; --i) {
+            if (ops_[i].kind != OP_CONV) continue;
+            if (!done[i]) break;
+            lo = ops_[i].w_off;
+        }
+        return lo;
+    };
+    size_t hi = nfilters_, pos = 0;
+    const bool defers = defers_head_wgrads();
+    bool chain_done = false;
+    std::vector<int> deferred;
+    while (pos < bwd_order_.size()) {
         size_t lo = hi;
-        while (next >= 0 && hi - lo < min_floats) {
-            const Op& op = ops_[next--];
-            if (op.kind == OP_CONV) lo = op.w_off;      // conv ops own descending, adjacent filter ranges (backward_step)
+        while (pos < bwd_order_.size() && hi - lo < min_floats) {      // exactly backward_step's loop
+            const int i = bwd_order_[pos++];
+            if (ops_[i].kind != OP_CONV) continue;
+            if (i == tail_first_) {
+                chain_done = true;
+                for (int j : deferred) done[j] = 1;
+                deferred.clear();
+            }
+            if (ops_[i].head >= 0 && !chain_done && defers) deferred.push_back(i);
+            else done[i] = 1;
+            lo = final_lo();
+        }
+        if (pos >= bwd_order_.size() && !deferred.empty()) {
+            for (int j : deferred) done[j] = 1;
+            deferred.clear();
+            lo = final_lo();
         }
         if (hi > lo) out.emplace_back(lo, hi - lo);
         hi = lo;

@@ -250,7 +250,10 @@ class TrainingData:
         # for a batch, the feeder thread waiting for the workers / for a free device slot / uploading
         self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, batches=0)
         from . import transforms as T
-        if data_dir not in (None, '', 'synthetic'):
+        # 'shapes': the learnable synthetic set (textured rectangles, class = texture; _shapes_canvas) -- same plumbing as
+        # 'synthetic', whose uniform-noise images carry nothing a detector could learn
+        self._shapes = data_dir == 'shapes'
+        if data_dir not in (None, '', 'synthetic', 'shapes'):
             # ---- a real dataset directory (training_data.py:41-69 + process_dataset.py:199-252) ----
             try:
                 source = load_data_source(data_source)
@@ -316,6 +319,39 @@ class TrainingData:
             return encode_labels_batch_dev(self.preset, self.num_classes, bxs, cls, self.device, out=out)
         return encode_labels_batch(self.preset, self.num_classes, bxs, cls)
 
+    # ---- the learnable synthetic set ('shapes') --------------------------------------------------------------------
+    SHAPE_CLASSES = 4      # textures, booked under the first four of the 20 class ids (the net keeps the benchmark's shape)
+
+    def _shapes_canvas(self, rng, W, H):
+        """uint8 BGR image [H, W, 3] + boxes: 1..3 non-overlapping rectangles of 20..50 % of the frame on low-contrast
+        noise, each filled with a two-colour texture that IS its class -- 0 horizontal stripes, 1 vertical stripes,
+        2 checkerboard, 3 diagonal stripes (either direction: a horizontal flip keeps every class).  Texture, not colour,
+        because the reference's training recipe permutes channels and shifts hue / saturation / contrast
+        (process_dataset.py:66-140, transforms.py:117-240): a colour code would not survive it."""
+        img = rng.integers(104, 152, (H, W, 3), dtype=np.uint8)
+        n = int(rng.integers(1, 4))
+        placed = []
+        for _ in range(n):
+            for _try in range(20):
+                w, h = rng.uniform(0.2, 0.5, 2)
+                cx, cy = rng.uniform(w / 2, 1 - w / 2), rng.uniform(h / 2, 1 - h / 2)
+                if all(abs(cx - q[0]) >= (w + q[2]) / 2 or abs(cy - q[1]) >= (h + q[3]) / 2 for q in placed):
+                    placed.append((float(cx), float(cy), float(w), float(h)))
+                    break
+        boxes = []
+        for cx, cy, w, h in placed:
+            c = int(rng.integers(0, self.SHAPE_CLASSES))
+            x0, x1 = int(round((cx - w / 2) * W)), int(round((cx + w / 2) * W))
+            y0, y1 = int(round((cy - h / 2) * H)), int(round((cy + h / 2) * H))
+            p = int(rng.integers(5, 12)) * max(1, min(W, H) // 300)          # stripe width in pixels
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            sgn = 1 if rng.integers(0, 2) else -1
+            pat = [(yy // p) % 2, (xx // p) % 2, (yy // p + xx // p) % 2, ((yy + sgn * xx) // p) % 2][c].astype(bool)
+            lo, hi = rng.integers(0, 64, 3), rng.integers(192, 256, 3)
+            img[y0:y1, x0:x1] = np.where(pat[..., None], hi, lo).astype(np.uint8)
+            boxes.append(Box(self.lid2name[c], c, Point(cx, cy), Size(w, h)))
+        return img, boxes
+
     # ---- a dataset of variously sized uint8 images through the reference's transform recipe ---------------------
     def _dataset_sample(self, index, salt):
         """Deterministic synthetic "file" #index: ({name: uint8 BGR image}, Sample record with 1..5 boxes)."""
@@ -325,6 +361,14 @@ class TrainingData:
             return hit
         rng = np.random.default_rng([self.seed, salt, index, 77])
         W, H = int(rng.integers(200, 640)), int(rng.integers(200, 640))
+        if self._shapes:
+            W, H = int(rng.integers(280, 420)), int(rng.integers(280, 420))
+            img, boxes = self._shapes_canvas(rng, W, H)
+            name = 'shapes/%d/%d' % (salt, index)
+            out = ({name: img}, Sample(name, boxes, Size(W, H)))
+            if len(self._synthetic_cache) < CACHE_SYNTHETIC_UP_TO:
+                self._synthetic_cache[key] = out
+            return out
         img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         n = int(rng.integers(1, 6))
         w = rng.uniform(0.1, 0.6, n); h = rng.uniform(0.1, 0.6, n)
@@ -343,6 +387,9 @@ class TrainingData:
         """Deterministic synthetic sample #index: image + 1..5 GT boxes."""
         rng = np.random.default_rng([self.seed, salt, index])
         H, W = self.preset.image_size.h, self.preset.image_size.w
+        if self._shapes:
+            img, gt = self._shapes_canvas(rng, W, H)
+            return img.astype(np.float32), gt
         img = rng.integers(0, 256, (H, W, 3)).astype(np.float32)        # BGR 0..255, training_data.py:100
         n = int(rng.integers(1, 6))
         w = rng.uniform(0.1, 0.6, n); h = rng.uniform(0.1, 0.6, n)
