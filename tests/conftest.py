@@ -16,7 +16,7 @@ def pytest_collection_modifyitems(config, items):
     fresh process a fork takes 6-8 ms (profiles/r03_b_fork_probe.txt), at the end of this suite -- a hundred handles created
     and destroyed, tens of GB mapped and unmapped -- it takes seconds (the same five tests: 17 s first, 230 s last), so
     they run first."""
-    items.sort(key=lambda it: 0 if 'test_gpu_feeder' in it.nodeid else 1)      # stable: everything else keeps its order
+    items.sort(key=lambda it: 0 if 'test_gpu_feeder' in it.nodeid else (1 if 'test_gpu_learning' in it.nodeid else 2))      # stable: everything else keeps its order
     try:
         import torch
         has_gpu = torch.cuda.is_available()

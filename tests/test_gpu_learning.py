@@ -1,0 +1,122 @@
+"""-m gpu: does the step LEARN?  The parity tests compare single steps with the oracle; this file trains.
+
+The reference validates itself by mAP (README.md:26-29; train.py:311-331 computes the AP of the training and the
+validation sample every epoch).  No dataset can be downloaded here, so the data is the learnable synthetic set
+`TrainingData('shapes')`: 1..3 textured rectangles per image on low-contrast noise, class = texture (horizontal /
+vertical / diagonal stripes, checkerboard) -- texture, not colour, because the reference's training recipe permutes
+channels and shifts hue / saturation.  Everything runs through the product's own driver, `ssd_tensorflow_amd.train.main`
+(feeder with worker processes, StepLoop, decode + NMS of every batch from epoch 2 on, GPU APCalculator), from Xavier
+weights (there is no vgg.zip), SGD + momentum at the reference's magnitude of learning rate.
+
+Schedule: 96 steps at 3e-4, the reference's 7.5e-4 (train.py:66) until step 768, then 1e-4 -- 1280 steps at batch 32 over
+1024 training images.  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
+fp32 passes mAP 0.5 on the training sample at step ~480, 0.9 at ~670 and sits at 1.000 / 1.000 (training / held-out)
+from step ~900 on, total loss 16.5 -> 2.6 (of which 2.18 is the l2 term); bf16 follows the same curve to 0.95 at step
+~930.  Left at 7.5e-4 or 1e-3 for thousands of steps, a run in EITHER dtype occasionally collapses (a loss spike, mAP back to
+~0, then it re-learns: profiles/r04_k_learning_probe.txt) -- VGG-16 from Xavier weights on raw 0..255 inputs without
+normalisation layers is at the edge of stability at these rates, which is what the final decay is for.  With the full
+augmentation recipe on (--augment true) the same net learns more slowly (training mAP 0.28 after 1600 steps and rising), so
+the thresholds are asserted on the un-augmented set and the augmented run is asserted to make progress."""
+import contextlib
+import io
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import ssdvgg_ref as ref
+from ssd_tensorflow_amd import train
+from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session, LearningRate
+from ssd_tensorflow_amd.training_data import TrainingData
+
+pytestmark = pytest.mark.gpu
+
+EPOCHS, NTRAIN, NVALID, BATCH = 40, 1024, 128, 32
+LR_VALUES, LR_BOUNDARIES = '0.0003;0.00075;0.0001', '96;768'
+
+
+def run_driver(tmp_path, tag, dtype, epochs=EPOCHS, augment='false', workers=4):
+    out = io.StringIO()
+    argv = ['--name', str(tmp_path / ('run_' + tag)), '--tensorboard-dir', str(tmp_path / ('tb_' + tag)), '--data-dir', 'shapes',
+            '--synthetic-train', str(NTRAIN), '--synthetic-valid', str(NVALID), '--num-workers', str(workers), '--batch-size', str(BATCH),
+            '--checkpoint-interval', '1000', '--lr-values', LR_VALUES, '--lr-boundaries', LR_BOUNDARIES, '--epochs', str(epochs), '--dtype', dtype,
+            '--augment', augment]
+    with contextlib.redirect_stdout(out):
+        rc = train.main(argv)
+    text = out.getvalue()
+    assert rc == 0, text[-2000:]
+    tr = [tuple(map(float, m.groups())) for m in re.finditer(r'\[i\] Train +\d+/\d+ +total ([\d.naninf]+) +localization ([\d.naninf]+) +confidence ([\d.naninf]+)', text)]
+    va = [tuple(map(float, m.groups())) for m in re.finditer(r'\[i\] Valid +\d+/\d+ +total ([\d.naninf]+) +localization ([\d.naninf]+) +confidence ([\d.naninf]+)', text)]
+    maps = [tuple(map(float, m.groups())) for m in re.finditer(r'\[i\] mAP +\d+/\d+ +training ([\d.]+) +validation ([\d.]+)', text)]
+    assert len(tr) == epochs and len(va) == epochs and len(maps) == epochs - 1, text[-2000:]
+    return dict(train=tr, valid=va, maps=maps, text=text)
+
+
+def test_shapes_training_converges_in_both_dtypes(tmp_path):
+    """1280 steps of the HIP training step from Xavier weights: the loss falls, the detector detects -- in fp32 and, from the
+    same seed and the same batches, in bf16."""
+    res = {}
+    for dtype in ('bf16', 'f32'):
+        r = res[dtype] = run_driver(tmp_path, dtype, dtype)
+        first, last = r['train'][0], r['train'][-1]
+        tmap, vmap = r['maps'][-1]
+        print(f'    {dtype}: train loss {first[0]:.3f} -> {last[0]:.3f} (localization {first[1]:.3f} -> {last[1]:.3f}, confidence '
+              f'{first[2]:.3f} -> {last[2]:.3f}); valid loss {r["valid"][-1][0]:.3f}; mAP training {tmap:.4f} validation {vmap:.4f}; '
+              f'mAP by epoch {[round(m[0], 2) for m in r["maps"][::5]]}')
+        assert np.isfinite(last[0])
+        assert last[0] * 3.0 <= first[0], 'the total loss must fall by at least 3x'
+        assert last[1] * 3.0 <= first[1] and last[2] * 3.0 <= first[2], 'both data terms must fall by at least 3x'
+        assert tmap >= 0.5, 'training-sample mAP (train.py:311-331) must reach 0.5'
+        assert vmap >= 0.5, 'held-out mAP must reach 0.5'
+    # bf16 against fp32, same seed, same batches, at the end of training.  Measured (profiles/r04_m_gpu_learning_tests.log): mAP
+    # 0.976 / 0.977 (bf16, training / held-out) against 0.999 / 0.976 (fp32); total loss 3.019 against 2.903 (+4.0 %), held-out
+    # 3.395 against 3.293 (+3.1 %).  The two are different trajectories of the same chaotic training run, so the bounds leave room.
+    a, b = res['bf16'], res['f32']
+    assert abs(a['maps'][-1][0] - b['maps'][-1][0]) <= 0.05 and abs(a['maps'][-1][1] - b['maps'][-1][1]) <= 0.05
+    assert abs(a['train'][-1][0] - b['train'][-1][0]) <= 0.08 * b['train'][-1][0]
+    assert abs(a['valid'][-1][0] - b['valid'][-1][0]) <= 0.08 * b['valid'][-1][0]
+
+
+def test_augmented_shapes_training_makes_progress(tmp_path):
+    """The whole training recipe (expand, sample-picker crops, photometric distortion, flip: process_dataset.py:66-140) in front
+    of the same step: slower (see the module docstring), so only progress is asserted -- and that decode + NMS of the training
+    batches yields true positives."""
+    r = run_driver(tmp_path, 'aug', 'bf16', epochs=20, augment='true', workers=8)
+    first, last = r['train'][0], r['train'][-1]
+    print(f'    augmented bf16: train loss {first[0]:.3f} -> {last[0]:.3f}; valid loss {r["valid"][0][0]:.3f} -> {r["valid"][-1][0]:.3f}; '
+          f'training mAP by epoch {[round(m[0], 3) for m in r["maps"][::3]]}')
+    assert np.isfinite(last[0])
+    assert r['valid'][-1][0] < 0.7 * r['valid'][0][0]
+
+
+def test_first_training_steps_track_the_oracle_on_shapes():
+    """fp32, batch 4, momentum 0.9, lr 1e-4: the HIP losses against oracle.RefModel.train_step on the same batches, twelve
+    optimizer steps in a row.  The two trajectories are separate computations of a chaotic system (tests/test_gpu_model.py
+    header: a relu mask or pool argmax flips wherever two fp32 values agree to ~1e-6), so the agreement decays with the step
+    count -- measured 1e-7, 9e-6, 8e-5, 5e-4, 8e-4, 8e-4, then 7e-4 .. 7e-3 (at lr 1e-3, where the loss itself jumps 22 -> 60 ->
+    21 in the first three steps, 5e-2 by step 3).  Asserted: 1e-3 on every loss for the first six steps, 1e-2 for all twelve."""
+    import os
+    b, steps, exact = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 12)), 6
+    preset = ob.get_preset('vgg300')
+    td = TrainingData('shapes', 'vgg300', num_train=b * steps, num_valid=b, seed=5, device_tensors=False)
+    w = ref.init_params(preset, 20, seed=11, alive=True)
+    m = ref.RefModel('vgg300', params=w)
+    lr = LearningRate([float(os.environ.get('SSD_TEST_TRACK_LR', 1e-4))], [])
+    m.set_optimizer(lr.values, lr.boundaries, 0.9, 0.0005)
+    errs = []
+    with Session(0) as sess:
+        net = SSDVGG(sess, 'vgg300')
+        net.build_from_vgg(None, 20, max_batch=b, weights=w)
+        net.build_optimizer(learning_rate=lr, weight_decay=0.0005, momentum=0.9)
+        for k, (x, y, gt) in enumerate(td.train_generator(b)):
+            x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+            _, L_ref = m.train_step(x, y)
+            L, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+            e = max(abs(L[n] - L_ref[n]) / abs(L_ref[n]) for n in ('total', 'localization', 'confidence', 'l2'))
+            errs.append(e)
+            print(f'    step {k}: total {L["total"]:.5f} (oracle {L_ref["total"]:.5f}), worst relative loss error {e:.2e}')
+    assert len(errs) == steps
+    assert max(errs[:exact]) < 1e-3
+    assert max(errs) < 1e-2
