@@ -520,6 +520,9 @@ def run_config(a, rank, world, local):
             if tr is not None:
                 roofline['traffic'] = tr
                 roofline['traffic_source'] = src
+                # NOT counted in this run: rocprofv3 --pmc cannot wrap a run from inside it; the counters come from the
+                # newest committed passes over the same command (tools/profile_round.sh), whose kernels are the same binary
+                roofline['traffic_measured_in'] = 'builder profile (committed rocprofv3 --pmc passes under profiles/), not this run'
         if use_events:
             tot = sum(k['ms'] for k in kernels.values())
             out['kernel_ms_per_step'] = {k: round(v['ms'] / a.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}
@@ -554,12 +557,20 @@ def run_train_e2e(a, rank, world, local):
     b = a.batch
     n_samples = b * a.e2e_steps
     t0 = time.perf_counter()
-    td = TrainingData(None, a.preset, num_train=n_samples, num_valid=b, augment=True, device=local, seed=1234 + rank)
+    # With --e2e-checkpoint the loop runs on the learnable 'shapes' set from weights trained on it (bench.py --mode pretrain): the
+    # decode + NMS pass of every batch then HAS detections to emit and the host their boxes to collect, as the reference's loop
+    # does from its second epoch on (train.py:273-281).  From Xavier weights no class ever passes 0.5 and the collection is free.
+    ckpt = getattr(a, 'e2e_checkpoint', None) or None
+    td = TrainingData('shapes' if ckpt else None, a.preset, num_train=n_samples, num_valid=b, augment=True, device=local, seed=1234 + rank)
     t_data = time.perf_counter() - t0
     sess = Session(local)
     net = SSDVGG(sess, a.preset)
-    net.build_from_vgg(None, 20, max_batch=b, training=True, seed=42, dtype=a.dtype)
-    net.build_optimizer(learning_rate=0.00075, weight_decay=0.0005, momentum=0.9)
+    if ckpt:
+        net.build_from_metagraph(None, ckpt, max_batch=b, training=True, dtype=a.dtype)
+        net.build_optimizer_from_metagraph()
+    else:
+        net.build_from_vgg(None, 20, max_batch=b, training=True, seed=42, dtype=a.dtype)
+        net.build_optimizer(learning_rate=0.00075, weight_decay=0.0005, momentum=0.9)
     net.set_stream(torch.cuda.current_stream().cuda_stream)
     res = {}
     try:
@@ -601,8 +612,41 @@ def run_train_e2e(a, rank, world, local):
             'feeder_workers': r['workers'], 'host_cores': os.cpu_count(), 'dataset_build_s': round(t_data, 2),
             'serial_feeder': res.get('serial'), 'mean_losses': r['mean_losses'], 'detections_collected': r['detections_collected'],
             'feeder_ms_per_step': r.get('feeder_ms_per_step'),
-            'config': {'workload': f"{a.preset} train.py StepLoop, {b} images/step, {n_samples} synthetic uint8 images of 200..640 px through the reference's "
+            'weights': ('trained %s (bench.py --mode pretrain on the shapes set)' % os.path.basename(ckpt)) if ckpt else 'Xavier (no detections above 0.5)',
+            'config': {'workload': f"{a.preset} train.py StepLoop, {b} images/step, {n_samples} synthetic uint8 images of 200..640 px "
+                                   f"({'textured rectangles' if ckpt else 'uniform noise'}) through the reference's "
                                    'train recipe (process_dataset.py:66-140), --num-workers %d' % r['workers']}}
+
+
+def ordered_for_tail(out):
+    """The line is long (a dozen blocks) and a reader that keeps only its tail should still see what matters: the per-kernel
+    table goes first, the secondary blocks next, the contract's own keys after them and a compact `summary` of every block
+    last.  (Key order means nothing to a JSON parser.)"""
+    bulky = ('kernel_ms_per_step',)
+    blocks = [k for k, v in out.items() if isinstance(v, dict) and k not in ('config', 'roofline', 'cpu_baseline', 'losses_check', 'losses_last_step') + bulky]
+    o = {k: out[k] for k in bulky if k in out}
+    o.update({k: out[k] for k in blocks if k != 'bf16'})
+    if 'bf16' in out:
+        o['bf16'] = out['bf16']
+    o.update({k: v for k, v in out.items() if k not in o})
+    summ = {}
+    for k in blocks:
+        v = out[k]
+        if 'error' in v:
+            summ[k] = 'error'
+            continue
+        e = {}
+        for f in ('value', 'unit', 'ms_per_step', 'ms_per_image', 'model_mfma_frac', 'vs_resident_input', 'detections_collected', 'final_map_training'):
+            if v.get(f) is not None:
+                e[f] = v[f]
+        if isinstance(v.get('roofline'), dict):
+            e['roofline_frac'] = v['roofline'].get('frac')
+        if isinstance(v.get('losses_check'), dict):
+            e['losses_ok'] = v['losses_check'].get('ok')
+        summ[k] = e
+    if summ:
+        o['summary'] = summ
+    return o
 
 
 # configurations BASELINE.json names beside the headline; timed by the default invocation with a few steps each so
@@ -644,7 +688,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--preset', default='vgg300')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment', 'train_e2e'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'detect', 'decode', 'augment', 'train_e2e', 'pretrain'])
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = BASELINE.json configs[1] (the headline); bf16 = configs[2]'s per-GPU step (bf16 MFMA, fp32 masters)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -665,6 +709,10 @@ def main():
     ap.add_argument('--e2e-serial-steps', type=int, default=3, help='train_e2e: steps of the serial-feeder comparison (0 = skip)')
     ap.add_argument('--e2e-both', action='store_true', help='train_e2e: run both dtypes in this process')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end blocks of the default invocation')
+    ap.add_argument('--e2e-checkpoint', default='', help='train_e2e: start from this checkpoint and feed the learnable shapes set (detections to collect)')
+    ap.add_argument('--pretrain-dir', default='', help='pretrain: directory that receives final.npz')
+    ap.add_argument('--pretrain-epochs', type=int, default=40, help='pretrain: epochs of 1024 shapes images at batch 32 (bf16)')
+    ap.add_argument('--no-pretrain', action='store_true', help='default invocation: end-to-end blocks from Xavier weights (no detections)')
     args = ap.parse_args()
 
     import torch
@@ -694,6 +742,23 @@ def main():
 
     if args.mode == 'augment':
         return bench_augment(args, rank, world, local)
+    if args.mode == 'pretrain':
+        # trains a detector on the learnable shapes set with the product's own driver (the schedule of tests/test_gpu_learning.py:
+        # bf16, 1280 steps) so that the end-to-end blocks have detections to decode and collect; prints {checkpoint, final mAP}
+        import contextlib, io, re
+        from ssd_tensorflow_amd import train
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            rc = train.main(['--name', args.pretrain_dir, '--tensorboard-dir', os.path.join(args.pretrain_dir, 'tb'), '--data-dir', 'shapes',
+                             '--synthetic-train', '1024', '--synthetic-valid', '128', '--num-workers', '8', '--batch-size', '32',
+                             '--checkpoint-interval', '1000', '--lr-values', '0.0003;0.00075;0.0001', '--lr-boundaries', '96;768',
+                             '--epochs', str(args.pretrain_epochs), '--dtype', 'bf16', '--augment', 'false'])
+        maps = re.findall(r'mAP +\d+/\d+ +training ([\d.]+) +validation ([\d.]+)', buf.getvalue())
+        _OUT.emit(json.dumps({'rc': rc, 'checkpoint': os.path.join(args.pretrain_dir, 'final.npz'), 'seconds': round(time.perf_counter() - t0, 1),
+                              'steps': args.pretrain_epochs * 32, 'final_map_training': float(maps[-1][0]) if maps else None,
+                              'final_map_validation': float(maps[-1][1]) if maps else None}))
+        return
 
     def e2e(dtype):
         sub = argparse.Namespace(**vars(args))
@@ -729,16 +794,29 @@ def main():
             # process has created and destroyed before, and after eight configurations in this process the
             # feeder's stream measured 0.87 of the resident-input bf16 step instead of the 0.94-0.95 of a fresh process.
             import subprocess
+            import tempfile
 
-            def e2e_child(dtype):
-                cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'train_e2e', '--dtype', dtype, '--preset', args.preset,
-                       '--batch', str(args.batch), '--e2e-workers', str(args.e2e_workers), '--e2e-steps', str(args.e2e_steps),
-                       '--e2e-epochs', str(args.e2e_epochs), '--e2e-serial-steps', str(args.e2e_serial_steps)]
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            def child(cmd, what):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
                 lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 if r.returncode != 0 or not lines:
-                    raise RuntimeError('train_e2e child failed (rc %d): %s' % (r.returncode, r.stderr[-400:]))
+                    raise RuntimeError('%s child failed (rc %d): %s' % (what, r.returncode, r.stderr[-400:]))
                 return json.loads(lines[-1])
+            tmpdir = tempfile.mkdtemp(prefix='ssd_bench_')
+            ckpt = ''
+            if not args.no_pretrain:
+                try:
+                    out['e2e_pretrain'] = child(['--mode', 'pretrain', '--pretrain-dir', tmpdir, '--pretrain-epochs', str(args.pretrain_epochs)], 'pretrain')
+                    if out['e2e_pretrain'].get('rc') == 0 and os.path.exists(out['e2e_pretrain']['checkpoint']):
+                        ckpt = out['e2e_pretrain']['checkpoint']
+                except (Exception, SystemExit) as e:      # noqa: BLE001 -- the end-to-end blocks then run from Xavier weights
+                    out['e2e_pretrain'] = {'error': f'{type(e).__name__}: {e}'}
+
+            def e2e_child(dtype):
+                return child(['--mode', 'train_e2e', '--dtype', dtype, '--preset', args.preset,
+                              '--batch', str(args.batch), '--e2e-workers', str(args.e2e_workers), '--e2e-steps', str(args.e2e_steps),
+                              '--e2e-epochs', str(args.e2e_epochs), '--e2e-serial-steps', str(args.e2e_serial_steps)]
+                             + (['--e2e-checkpoint', ckpt] if ckpt and args.preset == 'vgg300' else []), 'train_e2e')
             for name, dtype, resident in (('train_e2e', 'f32', out), ('train_e2e_bf16', 'bf16', out.get('bf16'))):
                 try:
                     r = e2e_child(dtype)
@@ -748,8 +826,10 @@ def main():
                     out[name] = r
                 except (Exception, SystemExit) as e:      # noqa: BLE001
                     out[name] = {'error': f'{type(e).__name__}: {e}'}
+            import shutil
+            shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
-        _OUT.emit(json.dumps(out))
+        _OUT.emit(json.dumps(ordered_for_tail(out)))
     if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 

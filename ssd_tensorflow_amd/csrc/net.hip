@@ -607,8 +607,19 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             lane[0].cast_pending = lane[1].cast_pending = true;
         }
     }
+    // A forward pass that fails after it has taken a slot of the loss ring gives the slot back: its event was never
+    // recorded, and a reader one step late (get_losses_step) would otherwise be handed a slot of four passes ago.
+    struct LossSlotGuard {
+        long long& seq;
+        bool armed = false;
+        bool done = false;
+        explicit LossSlotGuard(long long& s) : seq(s) {}
+        void failed() { if (armed && !done) { --seq; armed = false; } }
+        ~LossSlotGuard() { if (armed && !done) --seq; }
+    } fwd_guard(loss_seq_);
     if (train_mode) {
         begin_loss_slot();
+        fwd_guard.armed = true;
         // the l2 term reads every filter once (105 MB): on the side stream beside the first (matrix-bound) layers
         prof_.layer = "loss";
         l2_partials(params_, nfilters_, lw_, side ? hstream_ : stream_);
@@ -729,6 +740,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
             (void)hipDeviceSynchronize();
             (void)hipMemset(lw_.ticket, 0, sizeof(unsigned));
         }
+        fwd_guard.failed();
         throw;
     }
     if (nl == 2) {
@@ -736,6 +748,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
     if (train_mode) HIP_OK(hipEventRecord(ev_loss_[loss_seq_ % LOSS_RING], stream_));
+    fwd_guard.done = true;
 }
 
 // Backward runs the op list in reverse.  It can be driven in stages so a data-parallel caller can

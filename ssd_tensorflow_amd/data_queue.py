@@ -39,8 +39,8 @@ class WorkerError(RuntimeError):
 
 
 class DataQueue:
-    """maxsize slots of slot_bytes each, created before the workers fork (anonymous shared memory, like the
-    reference's mp.Array('c', n, lock=False) slots)."""
+    """maxsize slots of slot_bytes each, created before the workers start (shared memory, like the reference's
+    mp.Array('c', n, lock=False) slots)."""
 
     def __init__(self, slot_bytes, maxsize, ctx=None):
         ctx = ctx or mp.get_context('fork')
@@ -49,6 +49,16 @@ class DataQueue:
         self._buffers = [ctx.RawArray('c', self.slot_bytes) for _ in range(self.maxsize)]
         self.array_pool = [np.frombuffer(b, dtype=np.uint8) for b in self._buffers]
         self.queue = ctx.Queue()
+
+    # ---- travelling to a worker started through the fork server: the slots by handle, the views rebuilt over them -----------
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['array_pool'] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.array_pool = [np.frombuffer(b, dtype=np.uint8) for b in self._buffers]
 
     # ---- worker side ------------------------------------------------------------------------------------------
     def put(self, tag, arr_id, arrays, boxes):

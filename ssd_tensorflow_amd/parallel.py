@@ -105,6 +105,12 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
     force_collectives: take the collective path even for world == 1 (a single-rank group: hardware test of the
     stream ordering)."""
     b = 0 if x_dev is None else int(x_dev.shape[0])
+    if b == 0 and global_count is not None and global_count >= world:
+        # a shard is only ever empty in a global batch with fewer samples than ranks: anything else means this rank's feeder
+        # disagrees with the others'.  The step still runs (identical collectives on every rank: no hang), but loudly.
+        import warnings
+        warnings.warn('rank got an EMPTY shard of a global batch of %d samples on %d ranks: the feeders disagree' % (global_count, world),
+                      RuntimeWarning, stacklevel=2)
     if world <= 1 and not force_collectives:
         if b == 0:
             return

@@ -39,13 +39,26 @@ class _DetectionList:
     is indexed, so collecting a batch costs the host one event wait and no per-image work it does not ask for.  Valid
     until the second-next pass is launched (two slots alternate); copy what must live longer."""
 
-    def __init__(self, count, conf, cls, idx, box, out_cap):
+    def __init__(self, count, conf, cls, idx, box, out_cap, net=None, serial=0):
         self.count, self.conf, self.cls, self.idx, self.box, self.out_cap = count, conf, cls, idx, box, out_cap
+        self.net, self.serial = net, serial      # the views point into pinned memory the handle owns: checked on every access
 
     def __len__(self):
         return len(self.count)
 
+    def _check_alive(self):
+        """The slot behind these views is rewritten by the second-next pass, moved (freed) when it has to grow and freed with the
+        handle: an access after any of these is an error here, not a read of freed memory."""
+        net = self.net
+        if net is None:
+            return
+        if net._h is None:
+            raise RuntimeError('these detections belong to a closed SSDVGG handle: copy what must outlive it')
+        if net._det_serial - self.serial not in (0, 1):
+            raise RuntimeError('these detections were overwritten: only the two most recent passes are kept (copy what must live longer)')
+
     def __getitem__(self, i):
+        self._check_alive()
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
         if i < 0:
@@ -85,7 +98,7 @@ class _Detections:
             if len(self.net._det_views) > 8:
                 self.net._det_views.clear()
             self.net._det_views[key] = views
-        return _DetectionList(*views, oc)
+        return _DetectionList(*views, oc, net=self.net, serial=self.serial)
 
 
 class LearningRate:
@@ -214,6 +227,8 @@ class SSDVGG:
         if self._h is not None:
             lib.ssd_destroy(self._h)
             self._h = None
+            if hasattr(self, '_det_views'):
+                self._det_views.clear()      # (views of pinned memory that ssd_destroy has just freed)
 
     def __del__(self):
         try:
@@ -425,9 +440,12 @@ class SSDVGG:
     def backward_ranges(self, min_floats):
         """[(offset, count)] exactly as backward_staged(..., min_floats) yields them, without running backward."""
         cap = 128
-        offs = (C.c_size_t * cap)(); cnts = (C.c_size_t * cap)(); n = C.c_int()
-        check(lib.ssd_backward_ranges(self._h, int(min_floats), offs, cnts, cap, C.byref(n)))
-        return [(offs[i], cnts[i]) for i in range(min(n.value, cap))]
+        while True:
+            offs = (C.c_size_t * cap)(); cnts = (C.c_size_t * cap)(); n = C.c_int()
+            check(lib.ssd_backward_ranges(self._h, int(min_floats), offs, cnts, cap, C.byref(n)))
+            if n.value <= cap:      # (a truncated list would desynchronise the ranks' collectives: ask again with room for all)
+                return [(offs[i], cnts[i]) for i in range(n.value)]
+            cap = n.value
 
     def set_loss_normalizer(self, batch):
         """reduce_mean over `batch` samples instead of the step's own b (<= 0 restores the default): data

@@ -87,9 +87,27 @@ class _Recipe:
         self.sample_at, self.transforms = sample_at, transforms
         self.pool = None
         self.active = False
+        self.dev = None                        # this data set's device-side slot ring + feeder stream (TrainingData._device_ring)
+
+    def __getstate__(self):      # what a worker needs: not the pool it belongs to, nothing that lives on the GPU
+        st = dict(self.__dict__)
+        st['pool'] = None
+        st['dev'] = None
+        st['active'] = False
+        return st
 
     # ---- host half of a batch: runs in a worker process or, for num_workers == 0, in the caller --------------------
     def plan(self, epoch, idx):
+        """(The transforms draw from the module-level `random`, seeded per sample below.  In the serial generator this runs in the
+        caller's process: its generator state is put back afterwards -- the reference never reseeds, and whatever else draws from
+        `random` in the driver must not become a function of the last sample index.)"""
+        state = random.getstate()
+        try:
+            return self._plan(epoch, idx)
+        finally:
+            random.setstate(state)
+
+    def _plan(self, epoch, idx):
         td = self.td
         if self.transforms is None:                              # preset-sized float32 synthetic images
             imgs, gts = [], []
@@ -137,9 +155,12 @@ class _Recipe:
         return batch_size * (td._max_image_bytes + 16 + 256 + 4096) + 8192
 
 
-def _worker_main(recipe, tasks, results):
-    """batch_producer of the reference (training_data.py:109-134).  The workers never touch the GPU: the HIP
-    runtime they inherited by fork is not called (the anchor table of the redraw test is primed before the fork)."""
+def _worker_main(recipe, tasks, results, anchors_abs=None):
+    """batch_producer of the reference (training_data.py:109-134).  The workers never touch the GPU: the anchor table of
+    the redraw test is computed by the training process before they start and handed over (`anchors_abs`; a forked worker
+    has inherited it as well)."""
+    if anchors_abs is not None:
+        prime_anchor_table(recipe.td.preset, anchors_abs)
     try:
         import signal
         signal.signal(signal.SIGINT, signal.SIG_IGN)
@@ -163,9 +184,77 @@ def _worker_main(recipe, tasks, results):
             results.put_error((gen, seq), slot, traceback.format_exc())
 
 
+class _SharedImageCache:
+    """The synthetic data sets' "files" (uint8 images) in shared memory: written once by the training process while it builds
+    its sample list, read as views by every worker however it was started (a forked worker used to inherit a dict of arrays;
+    one that comes from the fork server inherits nothing).  A real source reads its files in the workers instead."""
+    CHUNK = 128 << 20
+
+    def __init__(self, limit):
+        self.limit, self.chunks, self.used, self.index, self.records = limit, [], 0, {}, {}
+
+    def get(self, key):
+        e = self.index.get(key)
+        if e is None:
+            return None
+        c, off, h, w = e
+        name, sample = self.records[key]
+        img = np.frombuffer(self.chunks[c], dtype=np.uint8, count=h * w * 3, offset=off).reshape(h, w, 3)
+        return {name: img}, sample
+
+    def put(self, key, name, img, sample):
+        if len(self.index) >= self.limit:
+            return
+        n = int(img.nbytes)
+        if not self.chunks or self.used + n > len(self.chunks[-1]):
+            self.chunks.append(mp.get_context('fork').RawArray('B', max(self.CHUNK, n)))
+            self.used = 0
+        c, off = len(self.chunks) - 1, self.used
+        np.frombuffer(self.chunks[c], dtype=np.uint8, count=n, offset=off)[:] = img.reshape(-1)
+        self.used += (n + 255) // 256 * 256
+        self.index[key] = (c, off, img.shape[0], img.shape[1])
+        self.records[key] = (name, sample)
+
+    def __len__(self):
+        return len(self.index)
+
+
+def _start_context():
+    """How the planning workers come to life.  Default `forkserver`: the training process asks a small server process --
+    started once with a fresh interpreter, this module preloaded, never a HIP call -- to fork the workers, so what a worker
+    costs does not depend on the training process: forking THAT copies the page tables of everything it has ever mapped
+    (6-8 ms in a fresh process with 7 GB of HBM mapped, SECONDS in one that has created and destroyed a hundred handles:
+    profiles/r03_b_fork_probe.txt -- round 3 ordered its test suite around this).  The recipe, the shared-memory slots and the
+    anchor table travel to the worker as pickled Process arguments.  SSD_FEEDER_START=fork restores the direct fork."""
+    method = os.environ.get('SSD_FEEDER_START', 'forkserver')
+    if method not in ('fork', 'forkserver', 'spawn'):
+        raise ValueError('SSD_FEEDER_START must be fork, forkserver or spawn, got %r' % (method,))
+    ctx = mp.get_context(method)
+    if method == 'forkserver':
+        try:
+            ctx.set_forkserver_preload(['ssd_tensorflow_amd.training_data', 'ssd_tensorflow_amd.transforms'])
+        except Exception:
+            pass
+    return ctx
+
+
+class _SampleAt:
+    """sample #i of a data set (picklable: it travels to the workers)."""
+
+    def __init__(self, td, which, salt):
+        self.td, self.which, self.salt = td, which, salt
+
+    def __call__(self, i):
+        td = self.td
+        samples = td.train_samples if self.which == 'train' else td.valid_samples
+        if td._real_dataset:
+            return samples[i]
+        return td._dataset_sample(i, self.salt)
+
+
 class _WorkerPool:
     def __init__(self, recipe, num_workers, slot_bytes):
-        ctx = mp.get_context('fork')
+        ctx = _start_context()
         self.num_workers, self.slot_bytes = num_workers, slot_bytes
         self.nslots = num_workers + 2
         self.tasks = ctx.Queue()
@@ -175,8 +264,9 @@ class _WorkerPool:
         self.generation = 0
         self.pinned = []
         self.workers = []
+        anchors_abs = prime_anchor_table(recipe.td.preset)      # (computed once per process, on the GPU unless a test installed one)
         for _ in range(num_workers):
-            w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results), daemon=True)
+            w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
             w.start()
             self.workers.append(w)
 
@@ -243,9 +333,8 @@ class TrainingData:
         self.epoch = 0
         self.device, self.device_tensors = device, bool(device_tensors)
         self.global_count = 0
-        self._dev = None                       # device-side slot ring, feeder stream (created on first use)
         self._upload_hook = None               # tests: replaces the GPU half of a batch
-        self._synthetic_cache = {}
+        self._synthetic_cache = _SharedImageCache(CACHE_SYNTHETIC_UP_TO)
         # where a prefetched epoch's time went (seconds, reset by every gen_batch call with workers): the consumer waiting
         # for a batch, the feeder thread waiting for the workers / for a free device slot / uploading
         self.feeder_stats = dict(consumer_wait=0.0, worker_wait=0.0, slot_wait=0.0, upload=0.0, batches=0)
@@ -253,6 +342,7 @@ class TrainingData:
         # 'shapes': the learnable synthetic set (textured rectangles, class = texture; _shapes_canvas) -- same plumbing as
         # 'synthetic', whose uniform-noise images carry nothing a detector could learn
         self._shapes = data_dir == 'shapes'
+        self._real_dataset = data_dir not in (None, '', 'synthetic', 'shapes')
         if data_dir not in (None, '', 'synthetic', 'shapes'):
             # ---- a real dataset directory (training_data.py:41-69 + process_dataset.py:199-252) ----
             try:
@@ -270,8 +360,8 @@ class TrainingData:
             self.valid_transforms = T.build_valid_transforms(self.preset, self.num_classes, images)
             self._max_image_bytes = max([s.imgsize.w * s.imgsize.h * 3 for s in self.train_samples + self.valid_samples] + [1])
             self._recipes = {
-                'train': _Recipe(self, 'train', self.num_train, 0, lambda i: self.train_samples[i], self.train_transforms),
-                'valid': _Recipe(self, 'valid', self.num_valid, 1 << 20, lambda i: self.valid_samples[i], self.valid_transforms)}
+                'train': _Recipe(self, 'train', self.num_train, 0, _SampleAt(self, 'train', 0), self.train_transforms),
+                'valid': _Recipe(self, 'valid', self.num_valid, 1 << 20, _SampleAt(self, 'valid', 1 << 20), self.valid_transforms)}
         else:
             self.num_classes = 20
             self.label_colors = {}
@@ -286,13 +376,23 @@ class TrainingData:
                 self.valid_samples = [self._dataset_sample(i, 1 << 20)[1] for i in range(num_valid)]
                 self._max_image_bytes = 640 * 640 * 3
                 self._recipes = {
-                    'train': _Recipe(self, 'train', num_train, 0, lambda i: self._dataset_sample(i, 0), self.train_transforms),
-                    'valid': _Recipe(self, 'valid', num_valid, 1 << 20, lambda i: self._dataset_sample(i, 1 << 20), self.valid_transforms)}
+                    'train': _Recipe(self, 'train', num_train, 0, _SampleAt(self, 'train', 0), self.train_transforms),
+                    'valid': _Recipe(self, 'valid', num_valid, 1 << 20, _SampleAt(self, 'valid', 1 << 20), self.valid_transforms)}
             else:
                 self.train_samples = self.valid_samples = None
                 self._recipes = {'train': _Recipe(self, 'train', num_train, 0), 'valid': _Recipe(self, 'valid', num_valid, 1 << 20)}
         self.train_generator = self._make_generator(self._recipes['train'])
         self.valid_generator = self._make_generator(self._recipes['valid'])
+
+    # ---- what travels to a worker process (forkserver / spawn start: _start_context) ------------------------------
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ('_upload_hook', 'train_generator', 'valid_generator'):
+            st[k] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
     # ---- lifetime of the worker processes ----------------------------------------------------------------------
     def close(self):
@@ -300,6 +400,7 @@ class TrainingData:
             if r.pool is not None:
                 r.pool.close()
                 r.pool = None
+            r.dev = None
 
     def __del__(self):
         try:
@@ -362,12 +463,10 @@ class TrainingData:
         rng = np.random.default_rng([self.seed, salt, index, 77])
         W, H = int(rng.integers(200, 640)), int(rng.integers(200, 640))
         if self._shapes:
-            W, H = int(rng.integers(280, 420)), int(rng.integers(280, 420))
             img, boxes = self._shapes_canvas(rng, W, H)
             name = 'shapes/%d/%d' % (salt, index)
             out = ({name: img}, Sample(name, boxes, Size(W, H)))
-            if len(self._synthetic_cache) < CACHE_SYNTHETIC_UP_TO:
-                self._synthetic_cache[key] = out
+            self._synthetic_cache.put(key, name, img, out[1])
             return out
         img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         n = int(rng.integers(1, 6))
@@ -378,8 +477,7 @@ class TrainingData:
                  for x, y, ww, hh, c in zip(cx, cy, w, h, cls)]
         name = 'synthetic/%d/%d' % (salt, index)
         out = ({name: img}, Sample(name, boxes, Size(W, H)))
-        if len(self._synthetic_cache) < CACHE_SYNTHETIC_UP_TO:
-            self._synthetic_cache[key] = out
+        self._synthetic_cache.put(key, name, img, out[1])
         return out
 
     # ---- preset-sized float32 synthetic images (no transform recipe) ------------------------------------------------
@@ -399,11 +497,14 @@ class TrainingData:
         return img, gt
 
     # ---- GPU half of a batch ------------------------------------------------------------------------------------------
-    def _device_ring(self, batch_size):
-        """Three device slots (images, labels, staging for the source bytes, tap-table workspace) + the feeder stream."""
+    def _device_ring(self, recipe, batch_size):
+        """Three device slots (images, labels, staging for the source bytes, tap-table workspace) + the feeder stream, PER DATA
+        SET: a training and a validation generator may be live at the same time (the reference's queues are independent,
+        training_data.py:147-195) and must not fill each other's slots.  Never replaced under a live generator (_prefetched
+        refuses a second generator of the same data set)."""
         import torch
         from ._lib import lib
-        d = self._dev
+        d = recipe.dev
         if d is not None and d['batch'] >= batch_size:
             return d
         dev = torch.device('cuda', self.device)
@@ -414,10 +515,10 @@ class TrainingData:
              'labels': [torch.empty((batch_size, A, nv), dtype=torch.float32, device=dev) for _ in range(DEVICE_SLOTS)],
              'packed': [None] * DEVICE_SLOTS, 'enc_ws': [None] * DEVICE_SLOTS,
              'ws': [torch.empty((lib.ssd_augment_ws_bytes(batch_size, W, H),), dtype=torch.uint8, device=dev) for _ in range(DEVICE_SLOTS)]}
-        self._dev = d
+        recipe.dev = d
         return d
 
-    def _upload(self, arrays, gts, slot=None):
+    def _upload(self, arrays, gts, slot=None, ring=None):
         """Source bytes up, augmentation + label kernels on torch's current stream -> (images, labels) of this batch.
         slot None: fresh tensors (the serial generator); else the device slot to fill."""
         if self._upload_hook is not None:
@@ -428,7 +529,7 @@ class TrainingData:
         b = len(gts)
         dev = torch.device('cuda', self.device)
         W, H = self.preset.image_size.w, self.preset.image_size.h
-        ring = self._dev if slot is not None else None
+        ring = ring if slot is not None else None
         if 'images' in arrays:
             src = torch.from_numpy(arrays['images'])
             if ring is not None:
@@ -455,7 +556,7 @@ class TrainingData:
         labels = self._labels(gts, out=ring['labels'][slot][:b] if ring is not None else None)
         return images, labels
 
-    def _upload_async(self, slot_arr, arrays, gts, dslot):
+    def _upload_async(self, ring, slot_arr, arrays, gts, dslot):
         """The prefetching feeder's upload: ONE host-to-device transfer of the slot's used prefix (source bytes, parameter
         records, boxes), then the augmentation and label kernels, all enqueued on torch's current stream; nothing is waited
         for.  `arrays` are views into slot_arr (pinned when the registration succeeded): the slot must stay untouched until
@@ -466,7 +567,6 @@ class TrainingData:
         b = len(gts)
         dev = torch.device('cuda', self.device)
         W, H = self.preset.image_size.w, self.preset.image_size.h
-        ring = self._dev
         stream = torch.cuda.current_stream(dev).cuda_stream
         base = slot_arr.ctypes.data
         offs = {k: v.ctypes.data - base for k, v in arrays.items()}
@@ -530,7 +630,7 @@ class TrainingData:
         use_gpu = self._upload_hook is None
         if use_gpu:
             pool.pin(self.device)
-            ring = self._device_ring(batch_size)
+            ring = self._device_ring(recipe, batch_size)
             fstream = ring['stream']
             dev = torch.device('cuda', self.device)
             # the device slots start out free: whatever the caller still has enqueued on batches of an earlier generator
@@ -599,9 +699,9 @@ class TrainingData:
                                 if released is not None:
                                     fstream.wait_event(released)
                                 if in_slot:      # enqueue and move on: the consumer's stream waits for the event, not this thread
-                                    images, labels = self._upload_async(slot_arr, arrays, gts, dslot)
+                                    images, labels = self._upload_async(ring, slot_arr, arrays, gts, dslot)
                                 else:            # a batch that did not fit its slot came through the pipe: the serial upload
-                                    images, labels = self._upload(arrays, gts, dslot)
+                                    images, labels = self._upload(arrays, gts, dslot, ring)
                                 ev = torch.cuda.Event()
                                 ev.record(fstream)
                             inflight.append((hslot, ev))

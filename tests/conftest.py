@@ -12,11 +12,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """-m gpu tests must not silently pass on a box without a GPU.  The feeder's GPU tests fork worker processes: in a
-    fresh process a fork takes 6-8 ms (profiles/r03_b_fork_probe.txt), at the end of this suite -- a hundred handles created
-    and destroyed, tens of GB mapped and unmapped -- it takes seconds (the same five tests: 17 s first, 230 s last), so
-    they run first."""
-    items.sort(key=lambda it: 0 if 'test_gpu_feeder' in it.nodeid else (1 if 'test_gpu_learning' in it.nodeid else 2))      # stable: everything else keeps its order
+    """-m gpu tests must not silently pass on a box without a GPU.  (Round 3 ran the feeder's tests first because forking
+    worker processes from a long-lived test process took seconds; the workers now come from a fork server --
+    training_data._start_context -- and the suite runs in its natural order.)"""
     try:
         import torch
         has_gpu = torch.cuda.is_available()

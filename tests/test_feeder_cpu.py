@@ -24,6 +24,18 @@ def _host_upload(arrays, gts, slot):
     return {k: np.array(v) for k, v in arrays.items()}, [[tuple(b) for b in g] for g in gts]
 
 
+class _Unreadable:
+    """a data set whose file #7 cannot be read (module level: it travels to the worker processes)"""
+
+    def __init__(self, orig):
+        self.orig = orig
+
+    def __call__(self, i):
+        if i == 7:
+            raise OSError('unreadable file %d' % i)
+        return self.orig(i)
+
+
 def _collect(td, gen, batch, workers):
     out = []
     for x, y, gt in gen(batch, workers):
@@ -131,7 +143,7 @@ def test_abandoned_epoch_and_failing_worker():
         recipe = td._recipes['train']
         recipe.pool.close(); recipe.pool = None
         orig = recipe.sample_at
-        recipe.sample_at = lambda i: (_ for _ in ()).throw(OSError('unreadable file %d' % i)) if i == 7 else orig(i)
+        recipe.sample_at = _Unreadable(orig)
         with pytest.raises(RuntimeError, match='unreadable file 7'):
             _collect(td, td.train_generator, 4, 2)
         recipe.pool.close(); recipe.pool = None
@@ -154,4 +166,37 @@ def test_batches_that_do_not_fit_a_slot_travel_through_the_pipe():
         _same(want, got)
         assert td._recipes['train'].pool.slot_bytes < sum(v.nbytes for v in want[0][0].values())
     finally:
+        td.close()
+
+
+@pytest.mark.parametrize('start', ['forkserver', 'fork'])
+def test_both_start_methods_and_a_killed_worker(start, monkeypatch):
+    """The workers come from the fork server (default) or from a direct fork: the same batches either way.  A worker that
+    is KILLED mid-epoch (out of memory, an operator's kill -9) cannot report anything: the consumer must get a RuntimeError within
+    seconds instead of waiting for its batch forever."""
+    import os
+    import signal
+    import time
+    monkeypatch.setenv('SSD_FEEDER_START', start)
+    _prime()
+    td = TrainingData(None, 'vgg300', num_train=64, num_valid=4, augment=True, device_tensors=False)
+    td._upload_hook = _host_upload
+    try:
+        want = _collect(td, td.train_generator, 4, 0)
+        _same(want, _collect(td, td.train_generator, 4, 2))
+        g = td.train_generator(4, 2)
+        next(g)
+        pool = td._recipes['train'].pool
+        assert len(pool.workers) == 2 and all(w.is_alive() for w in pool.workers)
+        for w in pool.workers:
+            os.kill(w.pid, signal.SIGKILL)
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match='a feeder worker process died'):
+            for _ in g:
+                pass
+        assert time.perf_counter() - t0 < 20.0
+    finally:
+        for r in td._recipes.values():      # (the pool's workers are dead: nothing to hand back)
+            if r.pool is not None:
+                r.pool.workers = []
         td.close()

@@ -54,6 +54,35 @@ def test_prefetched_batches_are_the_serial_batches(augment):
         td.close()
 
 
+def test_train_and_valid_generators_live_at_once():
+    """Validating in the middle of a training epoch (the reference's two queues are independent, training_data.py:147-195):
+    each data set has its own device slot ring and feeder stream, so interleaved generators hand out exactly the batches they
+    hand out one after the other -- and a second generator of the SAME data set is refused."""
+    td = TrainingData(None, 'vgg300', num_train=16, num_valid=12, augment=True)
+    try:
+        t_alone = _drain(td.train_generator, 4, 2)
+        v_alone = _drain(td.valid_generator, 4, 2)
+        gt_, gv_ = td.train_generator(4, 2), td.valid_generator(4, 2)
+        t_mixed, v_mixed = [], []
+        for k in range(4):
+            x, y, g = next(gt_)
+            torch.cuda.synchronize()
+            if k < 3:
+                xv, yv, gv = next(gv_)
+                v_mixed.append((xv.cpu().numpy().copy(), yv.cpu().numpy().copy(), gv))
+            t_mixed.append((x.cpu().numpy().copy(), y.cpu().numpy().copy(), g))      # read AFTER the other data set's upload
+            if k == 1:
+                with pytest.raises(RuntimeError, match='one train generator at a time'):
+                    next(td.train_generator(4, 2))
+        for a, b in ((t_alone, t_mixed), (v_alone, v_mixed)):
+            assert len(a) == len(b)
+            for (xa, ya, ga), (xb, yb, gb) in zip(a, b):
+                assert np.array_equal(xa, xb) and np.array_equal(ya, yb) and ga == gb
+        gt_.close(); gv_.close()
+    finally:
+        td.close()
+
+
 def test_slot_is_not_rewritten_under_the_consumer():
     """The consumer enqueues a long kernel sequence that READS the batch (a training step) and only then asks for the next
     batch: the feeder may refill that slot only behind those kernels.  The step's losses must equal the ones of the same
