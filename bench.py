@@ -72,7 +72,9 @@ KERNEL_SYMBOLS = {
     'conv_wgrad_bf16_64x128': _wbf(2, 2, 1, 2), 'conv_wgrad_bf16_128x64': _wbf(2, 2, 2, 1),
     'conv_wgrad_bf16_rows_64x64': ['conv_wgrad_bf16_rows_kernel<1'], 'conv_wgrad_bf16_rows_64x128': ['conv_wgrad_bf16_rows_kernel<2'],
     'conv_wgrad_bf16_rows8_128x128': ['conv_wgrad_bf16_rows8_kernel<'],
-    'conv_fwd_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<0, 2'], 'conv_dgrad_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2'],
+    'conv_fwd_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<0, 2, 2'], 'conv_dgrad_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2, 2'],
+    'conv_fwd_bf16_rows_128x64': ['conv_gather_bf16_rows_kernel<0, 2, 1'], 'conv_dgrad_bf16_rows_128x64': ['conv_gather_bf16_rows_kernel<1, 2, 1'],
+    'conv_fwd_bf16_64x64x6': _gbf(0, 2, 2, 1, 1), 'conv_dgrad_bf16_64x64x6': _gbf(1, 2, 2, 1, 1),
     'conv_fwd_bf16_c64': ['conv_gather_bf16_c64_kernel<0'], 'conv_dgrad_bf16_c64': ['conv_gather_bf16_c64_kernel<1'],
     'conv_fwd_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<0, 4'], 'conv_dgrad_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<1, 4'],
 }

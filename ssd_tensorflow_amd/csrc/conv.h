@@ -88,6 +88,8 @@ struct FilterCastPlan {
 };
 void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t* oi, hipStream_t s);
 
+// launches of the same shape the caller runs side by side on other streams (tile choice: conv_bf16.hip gather_rows_n64)
+extern thread_local int g_conv_lanes;
 // y: bf16 [B,Ho,Wo,Co], or fp32 when y_f32 (the multibox heads feed the fp32 loss)
 void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
                    hipStream_t s);

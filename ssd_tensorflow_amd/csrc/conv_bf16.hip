@@ -401,9 +401,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 // tile, so pieces per MFMA is the figure of merit: 17 per 48 MFMAs and wave with 128 rows, 20 per 96 with 256.  The
 // activation tile is then exactly 256 rows = 32 KB, i.e. a workgroup owns 256 - 2 dil - 1 output pixels (halo + the empty row), so that two workgroups still fit a CU (2 x 80 KB); the fp32 epilogue tile goes through
 // LDS in two halves.  Used where the tiles fill the chip at least twice (conv2_2, conv3_x).
-template <int MODE, int TM>
+// TN = 1: 128 x 64 tiles (45 KB of LDS: THREE workgroups per CU).  For the 19x19 maps at batch 32 (M = 11,552: conv5_x, mod_conv6,
+// the 19x19 head) the 128 x 128 tiling gives 364 workgroups for 512 slots -- 108 CUs carry two, 148 carry one, the launch lasts as
+// long as the doubly loaded ones (71 % fill, 800-850 TFLOP/s against 1,200 for conv4_x on the same kernel); 728 workgroups on 768
+// slots fill 95 %.  Costs 26 % more staged bytes per MFMA, which the rows kernels are insensitive to.
+template <int MODE, int TM, int TN = 2>
 __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH p, int dil) {
-    constexpr int WM = 2, WN = 2, TN = 2, BM = 64 * TM, BN = 128;
+    constexpr int WM = 2, WN = 2, BM = 64 * TM, BN = 32 * TN * WN;
+    static_assert(TN == 2 || (TN == 1 && TM == 2), "128-wide tiles, or 128 x 64");
     constexpr int AROWS = TM == 2 ? 160 : 256;         // 128 + 2 * dil rows in whole 32-row staging passes | 256 rows = 253 + 2 (dil = 1) + 1 empty
     constexpr int A_N = AROWS / 32, B_N = BN / 32;
     constexpr int ZROW = (AROWS - 1) * 128;            // a tile row that is always zero (past the halo)
@@ -1876,18 +1881,35 @@ static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, d
     HIP_OK(hipGetLastError());
 }
 
-template <int MODE, int TM>
+template <int MODE, int TM, int TN = 2>
 static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, double flops, double bytes, hipStream_t s) {
-    constexpr size_t unit = (TM == 2 ? 160 : 256) * 128 + 3 * 128 * 128, ctile = (size_t)128 * 132 * 4;
+    constexpr int BN = 64 * TN;
+    constexpr size_t unit = (TM == 2 ? 160 : 256) * 128 + 3 * BN * 128, ctile = (size_t)128 * (BN + 4) * 4;
     constexpr size_t lds = unit > ctile ? unit : ctile;
-    auto kern = conv_gather_bf16_rows_kernel<MODE, TM>;
+    auto kern = conv_gather_bf16_rows_kernel<MODE, TM, TN>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
-    a.NT = cdiv(a.DN, 128);
+    a.NT = cdiv(a.DN, BN);
     const int bmv = TM == 2 ? 128 : 256 - 2 * dil - 1;
     ProfScope prof(label, flops, bytes, s);
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, bmv) * a.NT), dim3(256), lds, s, a, dil);
     HIP_OK(hipGetLastError());
+}
+// 128 x 64 tiles (three workgroups per CU) where they fill the chip's slots better than 128 x 128 (two per CU) does: the
+// launch time follows the most loaded CU.  0.9 prices the narrower tile's extra staging.  SSD_GATHER_ROWS_N64_BF16: 0 off,
+// 1 by this rule (default), 2 everywhere (tests).
+// g_conv_lanes: how many launches of this shape run side by side (the executor's forward lanes): the slots are shared, so the
+// fill is that of all of them together -- judged alone, a half-batch conv4_x launch looks 71 % full and takes the narrow tile,
+// which made the step 1 % slower (profiles/r04_o_ab_rows_n64_bf16.txt).
+thread_local int g_conv_lanes = 1;
+static bool gather_rows_n64(int M, int N) {
+    static const int on = env_int("SSD_GATHER_ROWS_N64_BF16", 1);
+    if (on != 1) return on == 2;
+    M *= g_conv_lanes;
+    auto fill = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+    const double f128 = fill((long long)cdiv(M, 128) * cdiv(N, 128), 512), f64 = fill((long long)cdiv(M, 128) * cdiv(N, 64), 768);
+    const double waste128 = (double)N / (cdiv(N, 128) * 128), waste64 = (double)N / (cdiv(N, 64) * 64);      // useful columns (fused heads: N = 104 / 152)
+    return f64 * waste64 * 0.9 > f128 * waste128;
 }
 // 256-row tiles where they fill the chip (512 workgroup slots) at least twice; dil = 1 only (the tile owns 256 - 2 dil rows)
 static bool gather_rows256(const ConvDesc& d, int M, int N) {
@@ -1921,6 +1943,7 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
     static const int heads_rows_min_m = env_int("SSD_HEADS_ROWS_MIN_M", 4096);
     if (gather_rows_applicable(d, false) && d.Co >= 128 && !(y_f32 && a.M < heads_rows_min_m)) {
         if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
+        else if (gather_rows_n64(a.M, d.Co)) launch_gather_rows<MODE_FWD, 2, 1>(a, d.dil, "conv_fwd_bf16_rows_128x64", fl, by, s);
         else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
         return;
     }
@@ -1982,6 +2005,7 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
     }
     if (gather_rows_applicable(d, true) && d.Ci >= 128) {
         if (gather_rows256(d, a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 4>(a, d.dil, "conv_dgrad_bf16_rows_256x128", fl, by, s);
+        else if (gather_rows_n64(a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 2, 1>(a, d.dil, "conv_dgrad_bf16_rows_128x64", fl, by, s);
         else launch_gather_rows<MODE_DGRAD, 2>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
         return;
     }

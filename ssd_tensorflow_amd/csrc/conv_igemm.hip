@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 
 // STRIDED: data gradient of a stride-2^k convolution (conv8_2, conv9_2): source pixel = (oh + dh) / stride when that
 // division is exact; the validity of a (row, tap) pair is recomputed per iteration with shifts and masks.
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false>
+// NS: ring depth of the tile pipeline.  2 (every big layer): tile k + 1 streams in while tile k is multiplied -- the loop is
+// bound by the matrix pipe and a deeper ring only costs resident workgroups.  6 (round 4, the latency-bound small layers --
+// conv8_2 ... conv11_2 and the small maps' heads, a handful of workgroups with 36..144 dependent iterations each): up to four
+// tiles in flight, the iteration no longer waits for a whole DMA round trip.
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2>
 __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
@@ -550,14 +554,40 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
         }
     };
 
-    // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
-    if (nk > 0) issue(0, 0);
-    for (int k = 0; k < nk; ++k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
-        compute(k & 1);
+    if constexpr (NS == 2) {
+        // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
+        if (nk > 0) issue(0, 0);
+        for (int k = 0; k < nk; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
+            compute(k & 1);
+        }
+    } else {
+        // ring of NS stages: tiles k+1 .. k+NS-1 in flight while tile k is multiplied (vmcnt retires a lane's DMA in order:
+        // waiting until at most `ahead` tiles' worth of instructions are outstanding means tile k has landed)
+        constexpr int L = A_N + B_N;
+        static_assert(4 * L <= 63, "vmcnt field");
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < nk) issue(t, t);
+        int st_c = 0, st_i = NS - 1;
+        for (int k = 0; k < nk; ++k) {
+            const int later = nk - 1 - k;
+            const int ahead = later < NS - 2 ? later : NS - 2;
+            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * L) : "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L) : "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
+            compute(st_c);
+            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+            st_i = st_i + 1 == NS ? 0 : st_i + 1;
+        }
     }
 
 #pragma unroll
@@ -1093,11 +1123,11 @@ static void check_desc(const ConvDesc& d) {
                 "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2>
 static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY>;
+    constexpr size_t lds = NS * (size_t)(BM + BN) * 128;
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY, NS>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
@@ -1143,6 +1173,16 @@ static int pick_tile(long long M, int N, int mode) {
     return best;
 }
 
+// The small layers (at most one 64 x 64 workgroup per CU) on the deep-ring instantiation: SSD_SMALL_TILE_F32=1, default OFF.
+// Unlike their bf16 counterparts (conv_bf16.hip pick_tile_h: -25 % per launch) these launches are not waiting for their DMA:
+// a 32 x 32 x 2 fp32 MFMA retires two k per 64 cycles, so the serial k loop of a 3x3 x 256-channel layer is 1152 dependent
+// MFMAs = 31 us of matrix pipe per wave whatever the staging does -- per-layer times unchanged, step +0.2 ms from the
+// lost 128 x 64 tiles (profiles/r04_q_ab_small_tile_f32.txt).  What these layers need is k split over the waves of a workgroup.
+static bool small_deep_f32(long long M, int N) {
+    static const int on = env_int("SSD_SMALL_TILE_F32", 0), forced = env_int("SSD_TILE", -1);
+    return on && forced < 0 && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256;
+}
+
 static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, const float* bias, void* y, bool y_bf16, bool relu,
                          hipStream_t s) {
     check_desc(d);
@@ -1170,6 +1210,10 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
     if (smallc) {
         if (y_bf16) launch_gather<MODE_FWD, 4, 1, 1, 2, true, false, true>(a, "conv_fwd_smallc_128x64_bf16out", fl, by, s);
         else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
+        return;
+    }
+    if (use_dma() && small_deep_f32(a.M, a.DN)) {
+        launch_gather_dma<MODE_FWD, 2, 2, 1, 1, false, false, 6>(a, "conv_fwd_64x64x6", fl, by, s);
         return;
     }
     if (use_dma()) {
@@ -1262,6 +1306,8 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     } else if (d.stride > 1) {
         if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
+    } else if (use_dma() && small_deep_f32(a.M, a.DN)) {
+        launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1, false, false, 6>(a, "conv_dgrad_64x64x6", fl, by, s);
     } else if (use_dma()) {
         switch (cfg) {
         case 0: launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2>(a, "conv_dgrad_128x128", fl, by, s); break;

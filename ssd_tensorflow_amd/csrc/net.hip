@@ -670,6 +670,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     }
                 }
                 const ConvDesc d = conv_desc(op, run_nb);
+                struct LanesScope {      // (tile choice of the bf16 kernel-row gather: the lanes share the chip's workgroup slots)
+                    LanesScope(int n) { g_conv_lanes = n; }
+                    ~LanesScope() { g_conv_lanes = 1; }
+                } lanes_scope(run_nb == nb ? nl_cur : 1);
                 if (ln.cast_pending && !in.data_f32) {
                     HIP_OK(hipStreamWaitEvent(ln.s, ev_cast_, 0));
                     ln.cast_pending = false;

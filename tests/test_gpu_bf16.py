@@ -163,15 +163,19 @@ def test_conv_bf16_full_size_layer():
 
 
 
-def test_conv_bf16_large_layer_kernels_forced():
+@pytest.mark.parametrize('forced', [dict(SSD_GATHER_ROWS256_BF16='2', SSD_C64_BF16='2'), dict(SSD_GATHER_ROWS_N64_BF16='2'),
+                                    dict(SSD_GATHER_ROWS_N64_BF16='0', SSD_SMALL_TILE='0')], ids=['rows256+c64', 'rows128x64', 'no-n64-no-smalltile'])
+def test_conv_bf16_large_layer_kernels_forced(forced):
     """Two kernels are picked only at batch-32 sizes: the 256-row kernel-row gather (conv2_2 / conv3_x, where its tiles
     fill the chip twice) and the persistent 64 -> 64 kernel with the resident filter (conv1_2, >= 4 tiles per CU).
     SSD_GATHER_ROWS256_BF16=2 / SSD_C64_BF16=2 select them for every eligible layer.  The library reads the switches once
     per process: the conv cases (and the full-size conv1_2 image) run again in a child process with them set."""
     import os, subprocess, sys
-    if os.environ.get('SSD_GATHER_ROWS256_BF16') == '2':
+    if all(os.environ.get(k) == v for k, v in forced.items()):
         pytest.skip('already the forced configuration')
-    env = dict(os.environ, SSD_GATHER_ROWS256_BF16='2', SSD_C64_BF16='2')
+    # (round 4: the 128 x 64 kernel-row tiles of the 19x19 maps -- SSD_GATHER_ROWS_N64_BF16=2 takes them everywhere, =0 together
+    # with SSD_SMALL_TILE=0 restores round 3's choices, which stay reachable through the A/B switches)
+    env = dict(os.environ, **forced)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
                         'test_conv_bf16_fwd_dgrad_wgrad or test_conv_bf16_full_size_layer', '-p', 'no:cacheprovider'], env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
