@@ -341,7 +341,8 @@ def run_config(a, rank, world, local):
             return
         if a.mode == 'train':
             # N > 1: bucketed all-reduce (sum over ranks, RCCL over xGMI) overlapped with backward
-            parallel.train_step_dp(net, x, y, world, state['bucket'], force_collectives=getattr(a, 'force_collectives', False))
+            parallel.train_step_dp(net, x, y, world, state['bucket'], force_collectives=getattr(a, 'force_collectives', False),
+                                   allreduce_dtype=getattr(a, 'allreduce_dtype', 'f32'))
         elif a.mode == 'infer':
             net.infer_dev(x)
         else:
@@ -506,7 +507,8 @@ def run_config(a, rank, world, local):
             'config': {'workload': f'{a.preset} {what}, {b} images/GPU x {world} GPU, synthetic {H}x{W} BGR 0..255, '
                                    + ('GPU-encoded labels, Xavier-init weights' if a.mode != 'decode' else 'synthetic predictions (~300 detections/image at 0.5), outputs collected on the host')
                                    + (f' (BASELINE.json configs[{cfg_no}]' + (', per-GPU share' if cfg_no in (2, 3) and world == 1 else '') + ')' if cfg_no is not None else ' (not a BASELINE.json config)'),
-                       'global_batch': b * world, 'parallelism': f'dp{world}', 'allreduce': allreduce_mode,
+                       'global_batch': b * world, 'parallelism': f'dp{world}',
+                       'allreduce': allreduce_mode + (', bf16 messages' if allreduce_mode != 'none' and getattr(a, 'allreduce_dtype', 'f32') == 'bf16' else ''),
                        'replicas_agree': replicas_agree},
             'ms_per_image': round(dt / a.steps / (b * world) * 1e3, 5),
             'model_tflops': round(value * flops_img / 1e12, 2) if a.mode != 'decode' else None,
@@ -701,6 +703,8 @@ def main():
     ap.add_argument('--force-collectives', action='store_true', default=os.environ.get('SSD_BENCH_FORCE_COLLECTIVES', '0') == '1',
                     help='one GPU: run the data-parallel step (staged backward + bucketed all-reduce on a single-rank RCCL group) to price its plumbing')
     ap.add_argument('--bucket-mb', type=float, default=float(os.environ.get('SSD_BENCH_BUCKET_MB', 16)), help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    ap.add_argument('--allreduce-dtype', default=os.environ.get('SSD_BENCH_ALLREDUCE_DTYPE', 'f32'), choices=['f32', 'bf16'],
+                    help='N > 1 / --force-collectives: bf16 = filter gradients all-reduced as bf16 messages (half the bytes over xGMI)')
     ap.add_argument('--allow-fallback', action='store_true', help='N > 1: downgrade a failing bucketed all-reduce to a single one / report diverged replicas instead of aborting')
     ap.add_argument('--no-overlap', action='store_true', help='training: weight gradients on the main stream (one kernel at a time)')
     ap.add_argument('--per-layer', action='store_true', help='per-layer kernel table on stderr (events labelled kernel:layer)')

@@ -121,6 +121,8 @@ SIGNATURES = {
     'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),
     'ssd_op_maxpool_bwd': (i32, [vp, vp, vp, i32, i32] + [i32] * 10 + [vp]),
     'ssd_op_clock_monitor': (i32, [vp, i32, C.c_uint, vp]),
+    'ssd_grads_to_bf16': (i32, [i32, vp, vp, sz, vp]),
+    'ssd_grads_from_bf16': (i32, [i32, vp, vp, sz, vp]),
     'ssd_op_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, vp]),
     'ssd_op_l2norm_bwd_ws_floats': (sz, [i32, i32]),
     'ssd_op_l2norm_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),

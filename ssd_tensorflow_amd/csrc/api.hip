@@ -839,6 +839,18 @@ int ssd_op_maxpool_bwd(const float* x, const float* dy, float* dx, int accumulat
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));     // the scratch dies here
     API_END
 }
+int ssd_grads_to_bf16(int device, const float* grads_dev, void* msg_dev, size_t count, void* stream) {
+    API_BEGIN
+    DeviceGuard guard(device);
+    grads_to_bf16(grads_dev, msg_dev, count, (hipStream_t)stream);
+    API_END
+}
+int ssd_grads_from_bf16(int device, const void* msg_dev, float* grads_dev, size_t count, void* stream) {
+    API_BEGIN
+    DeviceGuard guard(device);
+    grads_from_bf16(msg_dev, grads_dev, count, (hipStream_t)stream);
+    API_END
+}
 int ssd_op_clock_monitor(unsigned* out_dev, int nsamples, unsigned period_ticks, void* stream) {
     API_BEGIN
     SSD_REQUIRE(out_dev && nsamples >= 1 && period_ticks >= 100, "bad arguments");

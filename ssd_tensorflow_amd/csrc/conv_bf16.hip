@@ -96,7 +96,9 @@ __device__ __forceinline__ void wait_tiles_and_sync(int ahead) {
 // last LDS read.
 // HALVES = 2: the C tile holds half of every wave's rows at a time (a 256-row tile through 66 KB of LDS);
 // rows_valid: tile rows that belong to this workgroup (the kernel-row 256-pixel tile owns 256 - 2 dil of its rows).
-template <int MODE, int WM, int WN, int TM, int TN, int HALVES = 1, bool PARITY = false>
+// ACC_IN_LDS: the C tile already holds the sums (the k-split instantiation of the per-tap kernel adds its wave groups'
+// accumulators there): no accumulator write, no barrier -- only the calling threads take part.
+template <int MODE, int WM, int WN, int TM, int TN, int HALVES = 1, bool PARITY = false, bool ACC_IN_LDS = false>
 __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned char* smem, const f32x16 (&acc)[TM][TN], int tid, int wm,
                                                 int wn, int li, int lh, int m0, int n0, int rows_valid = 32 * TM * WM,
                                                 const OutMap* om = nullptr) {
@@ -150,6 +152,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
             }
         }
     }
+    if constexpr (!ACC_IN_LDS) {
     if (h) __syncthreads();                   // the previous pass has been read out
 #pragma unroll
     for (int mi = 0; mi < TMH; ++mi)
@@ -163,6 +166,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                 *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
             }
     __syncthreads();
+    }
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
         const int ml = r0 + ps * RPP;
@@ -208,8 +212,13 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
   }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS, bool PARITY = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherArgsH pp) {
+// KSPLIT > 1 (round 4, the latency-bound small layers: conv8_2 ... conv11_2, the small maps' heads -- a handful of tiles, each
+// a serial loop of 18 ... 72 k iterations that is one DMA round trip after the other): KSPLIT groups of WM x WN waves share the
+// tile; group g multiplies the iterations g, g + KSPLIT, ... from its own ring of stages, so the loop is KSPLIT times shorter
+// with KSPLIT times the bytes in flight; the groups then add their accumulators in the fp32 C tile IN GROUP ORDER (a fixed
+// summation order: results do not depend on timing) and the first group writes the tile out.
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS, bool PARITY = false, int KSPLIT = 1>
+__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_gather_bf16_kernel(GatherArgsH pp) {
     // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
     const GatherArgsH& p = pp;
     int wg_first = 0, wg_count = gridDim.x;
@@ -227,8 +236,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
         P_tap_dh = pp.cls_dh[c]; P_tap_dw = pp.cls_dw[c]; P_tap_w = pp.cls_w[c];
         om = OutMap{P_M, P_DH, P_DW, pp.cls_ph[c], pp.cls_pw[c], pp.ODH, pp.ODW};
     }
-    constexpr int NTHR = 64 * WM * WN;                // 4 or 8 waves
-    constexpr int RPP_S = NTHR / 8;                   // tile rows one staging pass of the workgroup covers
+    constexpr int NTHR = 64 * WM * WN;                // 4 or 8 waves (per k-split group)
+    constexpr int RPP_S = NTHR / 8;                   // tile rows one staging pass of the group covers
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_N = BM / RPP_S, B_N = BN / RPP_S; // DMA instructions per thread and tile
     constexpr int STAGE = (BM + BN) * 128;            // bytes per pipeline stage
@@ -238,8 +247,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // scalar: LDS-DMA bases stay in SGPRs
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // scalar: LDS-DMA bases stay in SGPRs
+    const int grp = KSPLIT > 1 ? wave_all / (WM * WN) : 0;                              // k-split group of this wave
+    const int wave = KSPLIT > 1 ? wave_all - grp * (WM * WN) : wave_all, lane = threadIdx.x & 63;
+    const int tid = KSPLIT > 1 ? wave * 64 + lane : (int)threadIdx.x;                   // thread index inside the group
+    unsigned char* const gsm = smem + grp * (NS * STAGE);                               // the group's ring of stages
     const int wg = xcd_remap(blockIdx.x - wg_first, wg_count);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     auto issue = [&](int kiter, int stage) {
         const int cc = kiter / P_ntaps;
         const int tap = kiter - cc * P_ntaps;
-        unsigned char* As = smem + stage * STAGE + wave * 1024;       // wave-uniform: 8 rows x 128 B per DMA
+        unsigned char* As = gsm + stage * STAGE + wave * 1024;        // wave-uniform: 8 rows x 128 B per DMA
         unsigned char* Bs = As + BM * 128;
         const unsigned cmask = 0u - (unsigned)(cc * HBK + a_ck < p.SC);
         if constexpr (!STRIDED) {
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     const int b_row = BM * 128 + (wn * 32 * TN + li) * 128 + q0;
 
     auto compute = [&](int stage) {
-        const unsigned char* S = smem + stage * STAGE;
+        const unsigned char* S = gsm + stage * STAGE;
         // fragments of k-steps st+1 .. st+PF-1 are read while the MFMAs of step st run (PF register sets)
         constexpr int PF = GATHER_PF, KS = HBK / 16;
         bf16x8 a[PF][TM], b[PF][TN];
@@ -369,21 +381,66 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_bf16_kernel(GatherAr
     };
 
     // ---- main loop: NS stages; tiles k+1 .. k+NS-1 stream in while tile k is multiplied --------
+    if constexpr (KSPLIT == 1) {
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) issue(t, t);
-    int st_c = 0, st_i = NS - 1;
-    for (int k = 0; k < nk; ++k) {
-        const int later = nk - 1 - k;
-        wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
-        if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
-        compute(st_c);
-        st_c = st_c + 1 == NS ? 0 : st_c + 1;
-        st_i = st_i + 1 == NS ? 0 : st_i + 1;
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < nk) issue(t, t);
+        int st_c = 0, st_i = NS - 1;
+        for (int k = 0; k < nk; ++k) {
+            const int later = nk - 1 - k;
+            wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
+            if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
+            compute(st_c);
+            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+            st_i = st_i + 1 == NS ? 0 : st_i + 1;
+        }
+        __syncthreads();
+        gather_epilogue<MODE, WM, WN, TM, TN, 1, PARITY>(p, smem, acc, tid, wm, wn, li, lh, m0, n0, 32 * TM * WM, &om);
+    } else {
+        // group g owns the iterations g, g + KSPLIT, ...: local iteration j is global iteration grp + j KSPLIT.  Every group runs
+        // the same number of loop trips (the barrier is the workgroup's); a trip past a group's last iteration moves nothing.
+        const int nkg = (nk - grp + KSPLIT - 1) / KSPLIT;      // this group's iterations (may be 0)
+        const int trips = (nk + KSPLIT - 1) / KSPLIT;
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < nkg) issue(grp + t * KSPLIT, t);
+        int st_c = 0, st_i = NS - 1;
+        for (int j = 0; j < trips; ++j) {
+            const int later = nkg - 1 - j;
+            wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < 0 ? 0 : (later < NS - 2 ? later : NS - 2));
+            if (j + NS - 1 < nkg) issue(grp + (j + NS - 1) * KSPLIT, st_i);
+            if (j < nkg) compute(st_c);
+            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+            st_i = st_i + 1 == NS ? 0 : st_i + 1;
+        }
+        __syncthreads();
+        // the groups' accumulators meet in the fp32 C tile, in group order
+        float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+        for (int g = 0; g < KSPLIT; ++g) {
+            if (grp == g) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ml = wm * 32 * TM + mi * 32 + li;
+                            const int nl = wn * 32 * TN + ni * 32 + 8 * q + 4 * lh;
+                            f32x4* dst = reinterpret_cast<f32x4*>(Cs + ml * LDC + nl);
+                            f32x4 v = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                            if (g > 0) {
+                                const f32x4 o = *dst;
+                                v = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
+                            }
+                            *dst = v;
+                        }
+            }
+            __syncthreads();
+        }
+        if (grp == 0)
+            gather_epilogue<MODE, WM, WN, TM, TN, 1, PARITY, true>(p, smem, acc, tid, wm, wn, li, lh, m0, n0, 32 * TM * WM, &om);
     }
-    __syncthreads();
-
-    gather_epilogue<MODE, WM, WN, TM, TN, 1, PARITY>(p, smem, acc, tid, wm, wn, li, lh, m0, n0, 32 * TM * WM, &om);
 }
 
 // =================================================================================
@@ -1750,19 +1807,19 @@ void cast_filters(const FilterCastPlan& plan, const float* w, bf16_t* io, bf16_t
 // =================================================================================
 // host launchers
 // =================================================================================
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS = 2, bool PARITY = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED, int NS = 2, bool PARITY = false, int KSPLIT = 1>
 static void launch_gather_h(GatherArgsH& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t stages = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t stages = KSPLIT * NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = stages > ctile ? stages : ctile;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED, NS, PARITY>;
+    auto kern = conv_gather_bf16_kernel<MODE, WM, WN, TM, TN, STRIDED, NS, PARITY, KSPLIT>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(64 * WM * WN * KSPLIT), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -1777,15 +1834,15 @@ static void check_desc_h(const ConvDesc& d) {
 //   0: 128x128 x2 (2/CU)   1: 128x64 x2 (2/CU)   2: 64x128 x2 (2/CU)
 //   3: 256x128 x3 (1/CU)   4: 128x128 x4 (1/CU)  5: 128x64 x3 (2/CU)
 //   6: 256x128 x3, 8 waves (1/CU)   7: 256x128 x2, 8 waves (1/CU)   8: 256x64 x2, 8 waves (2/CU)
-//   9: 64x64 x6 (1/CU): the latency-bound small layers (see pick_tile_h)
-constexpr int NCFG_H = 10;
-static int pick_tile_h(long long M, int N, int mode) {
+//   9: 64x64 x6 (1/CU): the latency-bound small layers (see pick_tile_h)   10: 64x64 x2, k split over 4 wave groups (16 waves, 1/CU)
+constexpr int NCFG_H = 11;
+static int pick_tile_h(long long M, int N, int mode, int nk = 0) {
     static const int forced = env_int("SSD_TILE_BF16", -1);      // tuning override
     if (forced >= 0 && forced < NCFG_H) return forced;
-    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256, 64}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64, 64};
-    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2, 1};
+    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256, 64, 64}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
+    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2, 1, 1};
     // > 0: in the automatic choice.  256x64 (8 waves) serves the 64-channel layers: conv1_2 forward 427 -> 462, data gradient 423 -> 474 TF/s
-    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93, 0.0};
+    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93, 0.0, 0.0};
     int best = 0;
     double bc = 1e300;
     for (int c = 0; c < NCFG_H; ++c) {
@@ -1811,7 +1868,13 @@ static int pick_tile_h(long long M, int N, int mode) {
             // instead of 24 and a ring of SIX keeps four in flight; the launch also spreads over up to four times the
             // CUs.  Taken while it still fits one workgroup per CU.  SSD_SMALL_TILE=0 switches it off (A/B).
             static const int small_tile = env_int("SSD_SMALL_TILE", 1);
-            if (small_tile && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256) best = 9;
+            if (small_tile && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256) {
+                best = 9;
+                // ... and with at least 8 iterations to share, four wave groups split the k loop (conv_gather_bf16_kernel, KSPLIT):
+                // SSD_SMALL_KSPLIT=0 keeps the deep ring
+                static const int ksplit = env_int("SSD_SMALL_KSPLIT", 1);
+                if (ksplit && nk >= 8) best = 10;
+            }
         }
     }
     return best;
@@ -1821,10 +1884,11 @@ template <int MODE>
 static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hipStream_t s) {
     static const char* const names[2][NCFG_H] = {
         {"conv_fwd_bf16_128x128", "conv_fwd_bf16_128x64", "conv_fwd_bf16_64x128", "conv_fwd_bf16_256x128x3", "conv_fwd_bf16_128x128x4",
-         "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w", "conv_fwd_bf16_64x64x6"},
+         "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w", "conv_fwd_bf16_64x64x6",
+         "conv_fwd_bf16_64x64_k4"},
         {"conv_dgrad_bf16_128x128", "conv_dgrad_bf16_128x64", "conv_dgrad_bf16_64x128", "conv_dgrad_bf16_256x128x3",
          "conv_dgrad_bf16_128x128x4", "conv_dgrad_bf16_128x64x3", "conv_dgrad_bf16_256x128x3_8w", "conv_dgrad_bf16_256x128x2_8w",
-         "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6"}};
+         "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6", "conv_dgrad_bf16_64x64_k4"}};
     const char* label = names[MODE][cfg];
     switch (cfg) {
     case 0: launch_gather_h<MODE, 2, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
@@ -1836,7 +1900,8 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
     case 6: launch_gather_h<MODE, 4, 2, 2, 2, false, 3>(a, label, fl, by, s); break;
     case 7: launch_gather_h<MODE, 4, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
     case 8: launch_gather_h<MODE, 8, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
-    default: launch_gather_h<MODE, 2, 2, 1, 1, false, 6>(a, label, fl, by, s); break;
+    case 9: launch_gather_h<MODE, 2, 2, 1, 1, false, 6>(a, label, fl, by, s); break;
+    default: launch_gather_h<MODE, 2, 2, 1, 1, false, 2, false, 4>(a, label, fl, by, s); break;
     }
 }
 
@@ -1947,7 +2012,7 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
         else launch_gather_rows<MODE_FWD, 2>(a, d.dil, "conv_fwd_bf16_rows_128x128", fl, by, s);
         return;
     }
-    launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD), a, fl, by, s);
+    launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD, cdiv(a.SC, HBK) * a.ntaps), a, fl, by, s);
 }
 
 void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
@@ -1969,7 +2034,16 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
     if (d.stride == 2 && parity) {       // conv8_2, conv9_2, vgg512 conv10_2: parity classes, one launch (see conv_igemm.hip)
         GatherArgsH c = a;
         c.div = 1; c.mul = 1; c.wtaps = a.ntaps; c.ODH = d.Hi; c.ODW = d.Wi;
-        const int NT = cdiv(a.DN, 128);
+        // a handful of tiles (conv9_2 at batch 32: four classes of 800 pixels): 64 x 64 tiles with the k loop split over four
+        // wave groups, like the unstrided small layers (pick_tile_h)
+        static const int small_k = env_int("SSD_SMALL_KSPLIT", 1) && env_int("SSD_SMALL_TILE", 1) && env_int("SSD_TILE_BF16", -1) < 0;
+        long long tiles64 = 0;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw)
+                tiles64 += (long long)cdiv((long long)d.B * ((d.Hi - ph + 1) / 2) * ((d.Wi - pw + 1) / 2), 64) * cdiv(a.DN, 64);
+        const bool small = small_k && tiles64 <= 256;
+        const int bm = small ? 64 : 128;
+        const int NT = cdiv(a.DN, bm);
         c.nclass = 0;
         c.cls_wg0[0] = 0;
         for (int ph = 0; ph < 2; ++ph)
@@ -1988,11 +2062,12 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
                         ++nt;
                     }
                 c.cls_ntaps[k] = nt;
-                c.cls_wg0[k + 1] = c.cls_wg0[k] + cdiv(c.cls_M[k], 128) * NT;
+                c.cls_wg0[k + 1] = c.cls_wg0[k] + cdiv(c.cls_M[k], bm) * NT;
                 ++c.nclass;
             }
         c.M = c.cls_M[0]; c.DH = c.cls_DH[0]; c.DW = c.cls_DW[0]; c.ntaps = c.cls_ntaps[0];
-        launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false, 2, true>(c, "conv_dgrad_bf16_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
+        if (small) launch_gather_h<MODE_DGRAD, 2, 2, 1, 1, false, 2, true, 4>(c, "conv_dgrad_bf16_parity_64x64_k4", fl, by, s, c.cls_wg0[c.nclass]);
+        else launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false, 2, true>(c, "conv_dgrad_bf16_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
         return;
     }
     if (d.stride > 1) {       // the all-taps strided kernel (other strides, SSD_DGRAD_PARITY=0)
@@ -2009,7 +2084,7 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
         else launch_gather_rows<MODE_DGRAD, 2>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
         return;
     }
-    launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD), a, fl, by, s);
+    launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD, cdiv(a.SC, HBK) * a.ntaps), a, fl, by, s);
 }
 
 // ---- wgrad planning -------------------------------------------------------------------
@@ -2111,7 +2186,11 @@ static RowsPlan plan_rows8(const ConvDesc& d) {
     p.NT = cdiv(d.Co, 128);
     p.nslots = (long long)d.B * d.Ho * (d.Wo + 2);
     const int jobs = 3 * p.CT * p.NT;
-    int want = jobs >= 256 ? 1 : 256 / jobs;
+    // SSD_WGRAD_ROWS8_WGS: workgroup target (A/B switch).  256 = one per CU.  Fewer = fewer pixel splits = proportionally less
+    // fp32 slab traffic (every workgroup leaves 196 KB), at the price of CUs the launch does not use -- which, in the step, the
+    // data gradient on the other stream does.
+    static const int wgs_target = env_int("SSD_WGRAD_ROWS8_WGS", 256);
+    int want = jobs >= wgs_target ? 1 : wgs_target / jobs;
     const int maxs = (int)std::max<long long>(1, p.nslots / (64 * 8));
     p.nsplit = want > maxs ? maxs : want;
     p.schunk = cdiv(cdiv(p.nslots, p.nsplit), 64) * 64;

@@ -91,6 +91,9 @@ void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, f
 
 // gradients of a step without samples (a data-parallel rank whose shard of a short last batch is empty)
 void null_gradients(const float* w, float* g, size_t nfilters, size_t n, float wd, hipStream_t s);
+// fp32 gradient range <-> bf16 message buffer of the data-parallel all-reduce (halves the bytes that cross xGMI)
+void grads_to_bf16(const float* g, void* out, size_t n, hipStream_t s);
+void grads_from_bf16(const void* in, float* g, size_t n, hipStream_t s);
 
 void clock_monitor(unsigned* out, int nsamples, unsigned period, hipStream_t s);
 void fill_zero(void* p, size_t bytes, hipStream_t s);

@@ -1368,6 +1368,38 @@ void momentum_update(float* w, float* acc, const float* g, size_t n, float lr, f
     HIP_OK(hipGetLastError());
 }
 
+// Gradient range <-> bf16 message buffer of the data-parallel all-reduce (parallel.py, allreduce_dtype = 'bf16'): the payload
+// that crosses xGMI is halved; masters, momentum and the local gradient arena stay fp32.  Round-to-nearest-even like every other
+// bf16 store of the library; n need not be a multiple of anything.
+__global__ __launch_bounds__(256) void grads_to_bf16_kernel(const float* __restrict__ g, unsigned short* __restrict__ out, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = ld4(g + i * 4);
+        *reinterpret_cast<u32x2*>(out + i * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) out[n4 * 4 + threadIdx.x] = f2bf(g[n4 * 4 + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void grads_from_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ g, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(in + i * 4);
+        st4(g + i * 4, f32x4{lo2f(w[0]), hi2f(w[0]), lo2f(w[1]), hi2f(w[1])});
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) g[n4 * 4 + threadIdx.x] = lo2f((unsigned)in[n4 * 4 + threadIdx.x]);
+}
+void grads_to_bf16(const float* g, void* out, size_t n, hipStream_t s) {
+    SSD_REQUIRE(((uintptr_t)g % 16 == 0) && ((uintptr_t)out % 8 == 0), "gradient range / message buffer must be 16- / 8-byte aligned");
+    if (n == 0) return;
+    hipLaunchKernelGGL(grads_to_bf16_kernel, dim3(grid_for(n / 4 + 1, 256, 256 * 16)), dim3(256), 0, s, g, (unsigned short*)out, n);
+    HIP_OK(hipGetLastError());
+}
+void grads_from_bf16(const void* in, float* g, size_t n, hipStream_t s) {
+    SSD_REQUIRE(((uintptr_t)g % 16 == 0) && ((uintptr_t)in % 8 == 0), "gradient range / message buffer must be 16- / 8-byte aligned");
+    if (n == 0) return;
+    hipLaunchKernelGGL(grads_from_bf16_kernel, dim3(grid_for(n / 4 + 1, 256, 256 * 16)), dim3(256), 0, s, (const unsigned short*)in, g, n);
+    HIP_OK(hipGetLastError());
+}
+
 // gradient arena of a step without samples: d(l2_loss)/dw = wd * w on the filters, zero elsewhere
 __global__ __launch_bounds__(256) void null_grads_kernel(const float* __restrict__ w, float* __restrict__ g, size_t nf4, size_t n4,
                                                          float wd) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training driver: the counterpart of the reference's train.py loop (train.py:247-343) over
 the HIP library.  Same flags (train.py:55-80) plus --preset / --synthetic-train / --synthetic-valid /
---augment / --dtype / --allreduce-bucket-mb.  Scalar summaries go to <tensorboard-dir>/<name>/scalars.jsonl
+--augment / --dtype / --allreduce-bucket-mb / --allreduce-dtype.  Scalar summaries go to <tensorboard-dir>/<name>/scalars.jsonl
 (summaries.py); image summaries and TensorBoard event files are out of scope.
 
     python -m ssd_tensorflow_amd.train --name run1 --epochs 2 --batch-size 8
@@ -42,10 +42,11 @@ class StepLoop:
     collected after step k + 1's decode has been launched, and with num_workers > 0 batch k + 1 is already in HBM
     (training_data.py)."""
 
-    def __init__(self, net, sess, td, batch_size, num_workers=0, world=1, rank=0, bucket=0):
+    def __init__(self, net, sess, td, batch_size, num_workers=0, world=1, rank=0, bucket=0, allreduce_dtype='f32'):
         self.net, self.sess, self.td = net, sess, td
         self.batch_size, self.num_workers = batch_size, num_workers
         self.world, self.rank, self.bucket = world, rank, bucket
+        self.allreduce_dtype = allreduce_dtype
         self.steps = 0
 
     def booked(self, loss_batch, count):
@@ -81,7 +82,7 @@ class StepLoop:
             count = td.global_count if world > 1 else n
             ran = True
             if train and world > 1:
-                parallel.train_step_dp(net, x, y, world, self.bucket, td.global_count)       # an empty shard still steps
+                parallel.train_step_dp(net, x, y, world, self.bucket, td.global_count, allreduce_dtype=self.allreduce_dtype)       # an empty shard still steps
             elif n == 0:
                 ran = False
             elif train:
@@ -130,6 +131,7 @@ def main(argv=None):
     parser.add_argument('--synthetic-train', type=int, default=64, help='synthetic training samples per epoch')
     parser.add_argument('--synthetic-valid', type=int, default=16)
     parser.add_argument('--augment', type=str2bool, default='False', help="run the reference's train augmentation recipe (process_dataset.py) on the GPU over a uint8 synthetic dataset")
+    parser.add_argument('--allreduce-dtype', default='f32', choices=['f32', 'bf16'], help='data parallel: bf16 = the filter gradients cross the links as bf16 messages of half the bytes (fp32 masters, momentum and arenas untouched)')
     parser.add_argument('--allreduce-bucket-mb', type=float, default=16, help='data parallel: all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     args = parser.parse_args(argv)
 
@@ -219,7 +221,7 @@ def main(argv=None):
         training_loss = LossSummary(writer, 'training', td.num_train)
         validation_loss = LossSummary(writer, 'validation', td.num_valid)
 
-        loop = StepLoop(net, sess, td, args.batch_size, args.num_workers, world, rank, bucket)
+        loop = StepLoop(net, sess, td, args.batch_size, args.num_workers, world, rank, bucket, args.allreduce_dtype)
 
         def gathered_aps(calc):
             """{label: AP} over the WHOLE sample (train.py:317-323): data parallel, every rank's detections and ground

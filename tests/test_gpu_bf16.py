@@ -164,7 +164,8 @@ def test_conv_bf16_full_size_layer():
 
 
 @pytest.mark.parametrize('forced', [dict(SSD_GATHER_ROWS256_BF16='2', SSD_C64_BF16='2'), dict(SSD_GATHER_ROWS_N64_BF16='2'),
-                                    dict(SSD_GATHER_ROWS_N64_BF16='0', SSD_SMALL_TILE='0')], ids=['rows256+c64', 'rows128x64', 'no-n64-no-smalltile'])
+                                    dict(SSD_GATHER_ROWS_N64_BF16='0', SSD_SMALL_TILE='0'), dict(SSD_SMALL_KSPLIT='0')],
+                         ids=['rows256+c64', 'rows128x64', 'no-n64-no-smalltile', 'deep-ring-instead-of-ksplit'])
 def test_conv_bf16_large_layer_kernels_forced(forced):
     """Two kernels are picked only at batch-32 sizes: the 256-row kernel-row gather (conv2_2 / conv3_x, where its tiles
     fill the chip twice) and the persistent 64 -> 64 kernel with the resident filter (conv1_2, >= 4 tiles per CU).
