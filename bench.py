@@ -62,7 +62,7 @@ KERNEL_SYMBOLS = {
     'conv_dgrad_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_64x64': _gather(1, 2, 2, 1, 1),
     'conv_wgrad_128x128': _wgrad(2, 2, 2, 2), 'conv_wgrad_64x64': _wgrad(2, 2, 1, 1),
     'conv_wgrad_64x128': _wgrad(2, 2, 1, 2), 'conv_wgrad_128x64': _wgrad(2, 2, 2, 1),
-    'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'],
+    'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'], 'detect_fused': ['detect_fused_kernel'],
     'multibox_loss': ['heads_kernel<true>'], 'multibox_loss_grad': ['loss_grad_kernel<'], 'heads_result': ['heads_kernel<false>'],
     'conv_fwd_bf16_128x128': _gbf(0, 2, 2, 2, 2), 'conv_fwd_bf16_128x64': _gbf(0, 4, 1, 1, 2),
     'conv_fwd_bf16_64x128': _gbf(0, 2, 2, 1, 2), 'conv_fwd_bf16_256x64_8w': _gbf(0, 8, 1, 1, 2),

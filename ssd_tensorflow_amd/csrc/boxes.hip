@@ -259,13 +259,14 @@ constexpr int SCAN_ROWS = 256;
 constexpr int SCAN_MAXV = 32;                       // nv <= 32
 constexpr int SCAN_LOADS = SCAN_ROWS * SCAN_MAXV / 4 / 256;   // float4 per thread, worst case
 
-__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
-                                                          u64* __restrict__ dense, int* __restrict__ bcount) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];
-    __shared__ int s_cnt[2][4];
+// One scan block = SCAN_ROWS rows, worked by the 256 threads t = 0..255 of a (half) workgroup; `rows` and `s_cnt` are that
+// half's LDS.  blk past the last block: nothing to do, but every barrier is still passed.
+__device__ __forceinline__ void detect_scan_block(const int blk, const int t, float* __restrict__ rows, int (*s_cnt)[4], int A, int nv,
+                                                  int B, const float* __restrict__ pred, float thr, u64* __restrict__ dense,
+                                                  int* __restrict__ bcount) {
     const int total_rows = B * A;
-    const int r0 = blockIdx.x * SCAN_ROWS;
-    const int nrows = min(SCAN_ROWS, total_rows - r0);
+    const int r0 = blk * SCAN_ROWS;
+    const int nrows = max(0, min(SCAN_ROWS, total_rows - r0));
     const int nfl = nrows * nv;
     const float* src = pred + (size_t)r0 * nv;           // r0*nv*4 bytes: 256*nv*4*block -> 16-byte aligned
     const int n4 = nfl >> 2;
@@ -273,30 +274,30 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, 
     float4 v[SCAN_LOADS];
 #pragma unroll
     for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
+        const int i = t + 256 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) v[j] = *reinterpret_cast<const float4*>(src + (size_t)i * 4);
     }
 #pragma unroll
     for (int j = 0; j < SCAN_LOADS; ++j) {
-        const int i = threadIdx.x + 256 * j;
+        const int i = t + 256 * j;
         if (i < n4) *reinterpret_cast<float4*>(rows + (size_t)i * 4) = v[j];
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    for (int i = (n4 << 2) + t; i < nfl; i += 256) rows[i] = src[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = t & 63, wv = t >> 6;
     const int img_first = r0 / A;
     const int boundary = (img_first + 1) * A;            // first row of the next image (may lie beyond this workgroup)
     u64 key = 0ull;
     int half = 0;
-    if ((int)threadIdx.x < nrows) {
-        const float* r = rows + (size_t)threadIdx.x * nv;
+    if ((int)t < nrows) {
+        const float* r = rows + (size_t)t * nv;
         const int nfg = nv - 5;                  // argmax excludes the background class
         int best = 0;
         float conf = r[0];
         for (int c = 1; c < nfg; ++c)
             if (r[c] > conf) { conf = r[c]; best = c; }     // first maximum wins (np.argmax)
-        const int row = r0 + threadIdx.x;
+        const int row = r0 + t;
         half = row >= boundary ? 1 : 0;
         const int a = row - (img_first + half) * A;
         if (!(conf < thr))                        // the reference breaks at the first conf < thr
@@ -311,12 +312,28 @@ __global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, 
         if (w < wv) base += s_cnt[half][w];
         tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
     }
+    // The candidates and their counts are handed to ANOTHER workgroup inside the same launch (detect_fused_kernel): stored
+    // write-through at agent scope (`sc1`) and read the same way, the form MI355X_MICROARCH.md lists for small payloads -- a
+    // release fence per scan workgroup writes back the XCD's whole L2 each time (measured: the pass at 188 us instead of 50).
     if (key != 0ull) {
         const u64 bal = half ? bal1 : bal0;
-        dense[(size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        __hip_atomic_store(dense + (size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull)), key, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) { bcount[blockIdx.x * 2] = tot0; bcount[blockIdx.x * 2 + 1] = tot1; }
+    if (t == 0 && nrows > 0) {
+        __hip_atomic_store(bcount + blk * 2, tot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bcount + blk * 2 + 1, tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's stores have left before the workgroup's barrier
 }
+
+__global__ __launch_bounds__(256) void detect_scan_kernel(int A, int nv, int B, const float* __restrict__ pred, float thr,
+                                                          u64* __restrict__ dense, int* __restrict__ bcount) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    __shared__ int s_cnt[2][4];
+    detect_scan_block(blockIdx.x, threadIdx.x, rows, s_cnt, A, nv, B, pred, thr, dense, bcount);
+}
+
 
 // descending bitonic sort of n2 (power of two) keys by one workgroup; keys may live in LDS or global
 __device__ void bitonic_desc(u64* keys, int n2) {
@@ -476,7 +493,7 @@ struct DetectArgs {
 };
 #define DET_STAMP(k)                                                                  \
     do {                                                                              \
-        if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                        \
+        if (p.stamps && b == 0 && threadIdx.x == 0) {                                 \
             p.stamps[2 * (k)] = __builtin_readcyclecounter();                         \
             p.stamps[2 * (k) + 1] = wall_clock64();                                   \
         }                                                                             \
@@ -519,13 +536,15 @@ __device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, c
     if (tid == 0) p.out.count[b] = p.max_out >= 0 ? min(total, p.max_out) : total;
 }
 
-__global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[DET_SMEM];
+// The per-image phase: rank, decode, NMS and ordered emit of image b by one workgroup of DET_THREADS threads; `smem` = DET_SMEM
+// bytes of the caller's LDS.  Called by detect_image_kernel (one workgroup per image) or, by default, by the scan workgroup
+// that delivers an image's last candidate segment (detect_fused_kernel).
+__device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int b, unsigned char* smem) {
     __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
     __shared__ int s_npresent, s_wtot[DET_WAVES];
     __shared__ u64 cmax[32];
     __shared__ int bstart[32];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     u64* g1 = p.keys1 + (size_t)b * p.A2;
     DET_STAMP(0);
@@ -538,7 +557,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
         const int blk = first_blk + tid;
         const bool tail_of_prev = blk * SCAN_ROWS < row_lo;      // the workgroup started in the previous image
         seg_base[tid] = tail_of_prev ? row_lo : blk * SCAN_ROWS;
-        seg_off[tid + 1] = p.bcount[blk * 2 + (tail_of_prev ? 1 : 0)];
+        seg_off[tid + 1] = __hip_atomic_load(p.bcount + blk * 2 + (tail_of_prev ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (nseg <= 64) {                       // inclusive scan of the segment counts by one wave
@@ -566,7 +585,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
             const int mid = (lo + hi + 1) >> 1;
             if (seg_off[mid] <= f) lo = mid; else hi = mid - 1;
         }
-        return p.dense[(size_t)seg_base[lo] + (f - seg_off[lo])];
+        return __hip_atomic_load(p.dense + (size_t)seg_base[lo] + (f - seg_off[lo]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     if (n <= DET_FAST) {
@@ -848,16 +867,72 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     detect_emit(p, b, m, alive, [&](int q) { return g1[(int)((~k2[q]) & 0xFFFFFFFFull)]; }, [&](int q) { return box[q]; }, s_wtot);
 }
 
+__global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DET_SMEM];
+    detect_image_body(p, blockIdx.x, smem);
+}
+
+// ONE launch for the whole pass (round 4; measured slower than the two launches and therefore NOT the default: see detect()).
+// A workgroup of 512 threads scans two blocks of 256 rows (its two halves), then the
+// thread that closes a block takes a ticket on every image the block touched; the workgroup that draws an image's LAST
+// ticket owns all of that image's candidate segments and runs the per-image phase at once, while the other workgroups are
+// still scanning.  What this removes: the second launch, its ramp over 128 workgroups on 256 CUs, and the wait of every
+// image for the slowest scan workgroup of the batch -- the per-image phases spread under the scan (HBM-bound, 6.4 TB/s).
+// Cross-workgroup hand-off in the write-through form of MI355X_MICROARCH.md: `sc1` stores of the payload, every lane's vmcnt
+// drained, barrier, one relaxed agent-scope atomic per touched image; the last arriver reads the payload with `sc1` loads.  No
+// fence anywhere.  The tickets reset themselves (the last arriver stores 0): zero again when the launch has finished.
+constexpr int FUSED_SMEM = 2 * SCAN_ROWS * SCAN_MAXV * 4 > DET_SMEM ? 2 * SCAN_ROWS * SCAN_MAXV * 4 : DET_SMEM;
+static_assert(DET_THREADS == 2 * SCAN_ROWS, "two scan blocks per workgroup");
+
+// (4 waves per SIMD = two of these workgroups per CU: left alone the compiler spends 246 registers on the inlined per-image phase
+// and ONE workgroup per CU scans at a third of the HBM rate)
+__global__ __launch_bounds__(DET_THREADS, 4) void detect_fused_kernel(DetectArgs p, float thr, u64* __restrict__ dense, int* __restrict__ bcount,
+                                                                   int* __restrict__ tickets, int nblocks, int run_body) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FUSED_SMEM];
+    __shared__ int s_cnt[2][2][4];
+    __shared__ int s_todo[4], s_ntodo;
+    const int h = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int blk = blockIdx.x * 2 + h;
+    if (threadIdx.x == 0) s_ntodo = 0;
+    detect_scan_block(blk < nblocks ? blk : nblocks + 1, t, reinterpret_cast<float*>(smem) + h * (SCAN_ROWS * p.nv), s_cnt[h], p.A, p.nv, p.B,
+                      p.pred, thr, dense, bcount);
+    __syncthreads();                                   // every store of the workgroup's two blocks has been issued
+    if (t == 0 && blk < nblocks) {
+        const int r0 = blk * SCAN_ROWS;
+        const int last_row = min(r0 + SCAN_ROWS, p.B * p.A) - 1;
+        for (int img = r0 / p.A; img <= last_row / p.A; ++img) {
+            const int nseg = ((img + 1) * p.A - 1) / SCAN_ROWS - (img * p.A) / SCAN_ROWS + 1;
+            const int old = __hip_atomic_fetch_add(tickets + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == nseg - 1) {                     // this block was the image's last segment
+                __hip_atomic_store(tickets + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_todo[atomicAdd(&s_ntodo, 1)] = img;
+            }
+        }
+    }
+    __syncthreads();
+    const int ntodo = s_ntodo;
+    if (ntodo == 0 || !run_body) return;
+    for (int k = 0; k < ntodo; ++k) {
+        detect_image_body(p, s_todo[k], smem);
+        __syncthreads();
+    }
+}
+
 static int pow2_ge(int n) {
     int p = 1;
     while (p < n) p <<= 1;
     return p;
 }
 
-static size_t det_head_bytes(int B, int A) {      // bcount [scan workgroups][2]
+static size_t det_bcount_bytes(int B, int A) {      // bcount [scan workgroups][2]
     const size_t blocks = ((size_t)B * A + SCAN_ROWS - 1) / SCAN_ROWS;
     return (blocks * 8 + 255) / 256 * 256 + 256;
 }
+// The fused launch's per-image tickets sit at the START of the workspace in a region of fixed size, whatever the batch of the
+// pass: a workspace shared by passes of different batch sizes keeps them where they are (and at zero).
+constexpr int DET_MAX_BATCH = 4096;
+size_t detect_ticket_bytes() { return (size_t)DET_MAX_BATCH * 4; }
+static size_t det_head_bytes(int B, int A) { return detect_ticket_bytes() + det_bcount_bytes(B, A); }
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
@@ -865,7 +940,7 @@ size_t detect_ws_bytes(int B, int A) {
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
-            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s) {
+            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s, bool tickets_zeroed) {
     SSD_REQUIRE(A <= 32767 && A <= DET_MAX_ALIVE, "detect: at most 32767 anchors (got %d)", A);
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
     SSD_REQUIRE(A >= SCAN_ROWS, "detect: at least %d anchors", SCAN_ROWS);
@@ -873,8 +948,10 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     SSD_REQUIRE((long long)B * A < (1LL << 31), "detect: batch * anchors must stay below 2^31");
     const int nv = num_classes + 5;
     const int A2 = pow2_ge(A);
+    SSD_REQUIRE(B <= DET_MAX_BATCH, "detect: at most %d images per pass (got %d)", DET_MAX_BATCH, B);
     char* base = (char*)ws;
-    int* bcount = (int*)base; base += det_head_bytes(B, A);
+    int* tickets = (int*)base;
+    int* bcount = (int*)(base + detect_ticket_bytes()); base += det_head_bytes(B, A);
     u64* dense = (u64*)base; base += ((size_t)B * A * 8 + 255) / 256 * 256;
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
@@ -882,10 +959,17 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     int* nbox = (int*)base;
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
-    {
+    // SSD_DETECT_FUSED=1: the single-launch form (detect_fused_kernel) -- A/B switch, default OFF: measured SLOWER
+    // (profiles/r04_y_detect_fused_probe.txt, batch 128): 92 us against 17.6 + 26.6 us for the two launches.  Its scan half alone
+    // takes 34 us (two 512-thread workgroups of 76 KB per CU instead of six small ones), and a per-image phase that runs BESIDE
+    // the scan -- a chain of dependent loads -- pays the loaded memory system's latency at every link: 58 us instead of 26.
+    static const bool fused = [] { const char* v = getenv("SSD_DETECT_FUSED"); return v && v[0] == '1'; }();
+    if (!fused) {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
                            conf_thr, dense, bcount);
+    } else if (!tickets_zeroed) {      // a caller-owned workspace of unknown content (the handle zeroes its own once)
+        HIP_OK(hipMemsetAsync(tickets, 0, (size_t)B * 4, s));
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
@@ -898,7 +982,11 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
         HIP_OK(hipMemset(stamps_dev, 0, 16 * 2 * sizeof(unsigned long long)));
     }
     a.stamps = stamps_on ? stamps_dev : nullptr;
-    {
+    if (fused) {
+        ProfScope prof("detect_fused", 0.0, (double)rows * nv * 4.0, s);
+        static const int run_body = [] { const char* v = getenv("SSD_DETECT_FUSED_NOBODY"); return (v && v[0] == '1') ? 0 : 1; }();      // measurement aid
+        hipLaunchKernelGGL(detect_fused_kernel, dim3((blocks + 1) / 2), dim3(DET_THREADS), 0, s, a, conf_thr, dense, bcount, tickets, blocks, run_body);
+    } else {
         ProfScope prof("detect_image", 0.0, 0.0, s);
         hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
     }

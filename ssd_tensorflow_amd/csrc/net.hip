@@ -1283,7 +1283,10 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
     SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
     const int A = preset_->num_anchors;
-    if (!detect_ws_) detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
+    if (!detect_ws_) {
+        detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
+        HIP_OK(hipMemset(detect_ws_, 0, detect_ws_bytes(Bmax_, A)));      // (the fused pass' per-image tickets start at zero and return to it)
+    }
     det_cur_ ^= 1;
     DetectSlot& sl = det_slot_[det_cur_];
     if (!sl.ready) {
@@ -1321,7 +1324,7 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     prof_.layer = "detect";
     DetectOut d;
     detect_slot_carve(sl, d, sl.dev);
-    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
+    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_, true);
     if (!sl.mapped) HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipEventRecord(sl.ready, stream_));
     if (dev_out) *dev_out = d;
