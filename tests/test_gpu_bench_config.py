@@ -217,7 +217,11 @@ def test_step_lane_settings_agree(dtype):
         line = [l for l in r.stdout.splitlines() if l.startswith('LANES ')][-1]
         got[(fwd, bwd)] = json.loads(line[6:])
     base = got[(1, 1)]
-    tol = 1e-5 if dtype == 'f32' else 2e-3      # half batches may pick another tile / kernel variant: summation order, bf16 roundings
+    # half batches may pick another tile / kernel variant: summation order, bf16 roundings.  (Round 4 added variants whose choice
+    # depends on the launch's pixel count -- 64 x 64 deep-ring / k-split tiles, 128 x 64 kernel-row tiles -- and with them the worst
+    # bf16 deviation after two steps went from below 2e-3 to 2.4e-3, on a bias of 2.6e-3; fp32, which walks the same schedule
+    # code, stays at 1e-5.)
+    tol = 1e-5 if dtype == 'f32' else 5e-3
     for key, g in got.items():
         for a, c in zip(np.ravel(base['losses']), np.ravel(g['losses'])):
             assert abs(a - c) <= tol * abs(a), (key, base['losses'], g['losses'])
