@@ -238,6 +238,36 @@ def _start_context():
     return ctx
 
 
+class _NoMainReimport:
+    """While the workers start: keep multiprocessing from re-importing the launching script in them.  A worker that comes from
+    the fork server (or from spawn) is told the parent's `__main__` -- by path or by module name -- and runs it again as
+    `__mp_main__` before its target; everything a worker needs (`_worker_main`, the recipe's classes) is importable from this
+    package, while a training script WITHOUT an `if __name__ == '__main__':` guard would run a second time in every worker (and
+    die at its own first worker start: BrokenPipeError in the parent).  Nothing defined in `__main__` can therefore travel to a
+    worker: a data source or transform belongs in a module."""
+
+    def __enter__(self):
+        import sys
+        self.main = sys.modules.get('__main__')
+        self.saved = {}
+        for k in ('__spec__', '__file__'):
+            if self.main is not None and hasattr(self.main, k):
+                self.saved[k] = getattr(self.main, k)
+                try:
+                    if k == '__spec__':
+                        setattr(self.main, k, None)
+                    else:
+                        delattr(self.main, k)
+                except Exception:
+                    self.saved.pop(k)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            setattr(self.main, k, v)
+        return False
+
+
 class _SampleAt:
     """sample #i of a data set (picklable: it travels to the workers)."""
 
@@ -265,10 +295,11 @@ class _WorkerPool:
         self.pinned = []
         self.workers = []
         anchors_abs = prime_anchor_table(recipe.td.preset)      # (computed once per process, on the GPU unless a test installed one)
-        for _ in range(num_workers):
-            w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
-            w.start()
-            self.workers.append(w)
+        with _NoMainReimport():
+            for _ in range(num_workers):
+                w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
+                w.start()
+                self.workers.append(w)
 
     def pin(self, device):
         """Page-lock the slots so the uploads are asynchronous DMA transfers (a refusal is harmless: the copies are

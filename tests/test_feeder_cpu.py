@@ -200,3 +200,51 @@ def test_both_start_methods_and_a_killed_worker(start, monkeypatch):
             if r.pool is not None:
                 r.pool.workers = []
         td.close()
+
+
+_KILL_DRIVER = r'''
+import os, signal, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ['SSD_TEST_ROOT']); sys.path.insert(0, os.path.join(os.environ['SSD_TEST_ROOT'], 'tests'))
+from oracle import boxes as ob
+from ssd_tensorflow_amd import parallel, ssdutils
+from ssd_tensorflow_amd.training_data import TrainingData
+rank, local, world = parallel.init('gloo')
+preset = ssdutils.get_preset_by_name('vgg300')
+ssdutils.prime_anchor_table(preset, ob.anchors_abs(ob.anchors(ob.PRESETS['vgg300'])))
+td = TrainingData(None, 'vgg300', num_train=96, num_valid=4, augment=True, device_tensors=False, rank=rank, world=world)
+td._upload_hook = lambda arrays, gts, slot: ({k: np.array(v) for k, v in arrays.items()}, [len(g) for g in gts])
+for k, (x, y, gt) in enumerate(td.train_generator(4, 2)):
+    t = torch.ones(4)
+    dist.all_reduce(t)                       # the step's collective: every rank must arrive
+    if rank == 1 and k == 2:
+        for w in td._recipes['train'].pool.workers:
+            os.kill(w.pid, signal.SIGKILL)
+print('rank %d finished the epoch' % rank, flush=True)
+'''
+
+
+def test_killed_worker_ends_a_two_rank_job(tmp_path):
+    """Two ranks over gloo, a collective per step; rank 1's feeder workers are killed mid-epoch.  Rank 1 must fail with the feeder's
+    RuntimeError (not hang waiting for a batch), and the launcher then takes rank 0 -- blocked in the next collective -- down with
+    it: the job ends, non-zero, in seconds."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'kill_driver.py'
+    script.write_text(_KILL_DRIVER)
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], env=dict(os.environ, SSD_TEST_ROOT=root, OMP_NUM_THREADS='1'),
+                       capture_output=True, text=True, timeout=240, cwd=root)
+    took = time.perf_counter() - t0
+    assert r.returncode != 0, r.stdout[-1500:]
+    assert 'a feeder worker process died' in r.stderr, r.stderr[-3000:]
+    assert 'rank 1 finished the epoch' not in r.stdout
+    assert took < 120, took

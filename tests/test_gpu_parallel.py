@@ -106,3 +106,39 @@ def test_loss_normalizer_and_null_gradients(nccl_group):
         wd = 0.0005 * p0; wd[nf:] = 0
         assert torch.allclose(net.momentum_flat, 0.9 * m0 + wd, rtol=1e-6, atol=1e-12)
     sess.close()
+
+
+def test_bf16_message_allreduce_on_one_rank(nccl_group):
+    """allreduce_dtype='bf16' (parallel.Bf16Message; HIP pack / unpack kernels around the collective): on a single rank the
+    all-reduce is the identity, so after the step the FILTER gradients are exactly their bf16 roundings (round to nearest even, as
+    torch rounds), the bias / scale tail is untouched fp32 -- with and without buckets, for odd range sizes too."""
+    from ssd_tensorflow_amd._lib import lib, check
+    g = torch.randn(1_000_003, device='cuda') * 3.0
+    msg = torch.empty(g.numel(), dtype=torch.bfloat16, device='cuda')
+    back = torch.empty_like(g)
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib.ssd_grads_to_bf16(0, g.data_ptr(), msg.data_ptr(), g.numel(), s))
+    check(lib.ssd_grads_from_bf16(0, msg.data_ptr(), back.data_ptr(), g.numel(), s))
+    torch.cuda.synchronize()
+    assert torch.equal(msg, g.bfloat16()) and torch.equal(back, g.bfloat16().float())
+    b = 2
+    preset = ob.get_preset('vgg300')
+    w = ref.init_params(preset, 20, seed=5, alive=True)
+    rng = np.random.default_rng(19)
+    x, y, _ = ref.synth_batch(rng, b, preset)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    sess1, plain = _net(b, w)
+    plain.forward_backward_dev(xt, yt)
+    torch.cuda.synchronize()
+    want = plain.grads_flat.clone()
+    nf = plain.filter_floats
+    want[:nf] = want[:nf].bfloat16().float()
+    for bucket in (0, 4_000_000):
+        sess2, dp = _net(b, w)
+        p0 = dp.params_flat.clone()
+        parallel.train_step_dp(dp, xt, yt, 1, bucket_floats=bucket, force_collectives=True, allreduce_dtype='bf16')
+        torch.cuda.synchronize()
+        assert torch.equal(dp.grads_flat, want), bucket
+        assert torch.equal(dp.momentum_flat, want) and torch.equal(dp.params_flat, p0 - 0.001 * want)      # first step: momentum = gradient
+        sess2.close()
+    sess1.close()
