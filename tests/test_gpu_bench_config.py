@@ -217,14 +217,18 @@ def test_step_lane_settings_agree(dtype):
         line = [l for l in r.stdout.splitlines() if l.startswith('LANES ')][-1]
         got[(fwd, bwd)] = json.loads(line[6:])
     base = got[(1, 1)]
-    # half batches may pick another tile / kernel variant: summation order, bf16 roundings.  (Round 4 added variants whose choice
-    # depends on the launch's pixel count -- 64 x 64 deep-ring / k-split tiles, 128 x 64 kernel-row tiles -- and with them the worst
-    # bf16 deviation after two steps went from below 2e-3 to 2.4e-3, on a bias of 2.6e-3; fp32, which walks the same schedule
-    # code, stays at 1e-5.)
-    tol = 1e-5 if dtype == 'f32' else 5e-3
+    # fp32: the four settings agree to 1e-5 on everything (same schedule code, summation order of another tile at worst).
+    # bf16: half batches may pick another tile / kernel variant (round 4 added several whose choice depends on the launch's pixel
+    # count), i.e. other summation orders in front of a bf16 rounding.  After the first update the trunks therefore differ in
+    # the last bf16 bit here and there, and the SECOND step's hard-negative mining (ssdvgg.py:450-470: a top-k) picks a slightly
+    # different set of anchors -- a discrete change: the heads' biases, which start at zero and are nothing but two gradient
+    # steps, move by up to 2 % in L1 norm (measured 2.2 % on classifier1_0), the filters (dominated by their initial values)
+    # by < 1e-4, the losses by < 2e-3.
+    tol = 1e-5 if dtype == 'f32' else 2e-3
     for key, g in got.items():
         for a, c in zip(np.ravel(base['losses']), np.ravel(g['losses'])):
             assert abs(a - c) <= tol * abs(a), (key, base['losses'], g['losses'])
         for k in base['w']:
-            assert abs(base['w'][k] - g['w'][k]) <= tol * max(abs(base['w'][k]), 1e-6), (key, k, base['w'][k], g['w'][k])
+            wtol = tol if dtype == 'f32' else (5e-2 if k.endswith('biases') else 1e-4)
+            assert abs(base['w'][k] - g['w'][k]) <= wtol * max(abs(base['w'][k]), 1e-6), (key, k, base['w'][k], g['w'][k])
         print(f'    lanes fwd={key[0]} bwd={key[1]}: losses {g["losses"][1]}', 'identical' if g == base else 'within tolerance')
