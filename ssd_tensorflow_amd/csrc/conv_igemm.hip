@@ -376,8 +376,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 // bound by the matrix pipe and a deeper ring only costs resident workgroups.  6 (round 4, the latency-bound small layers --
 // conv8_2 ... conv11_2 and the small maps' heads, a handful of workgroups with 36..144 dependent iterations each): up to four
 // tiles in flight, the iteration no longer waits for a whole DMA round trip.
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2>
-__global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
+// KSPLIT > 1 (round 4, the small layers): KSPLIT groups of four waves share the tile; group g multiplies the k iterations g,
+// g + KSPLIT, ... from its own stages and the groups' accumulators are added through LDS in group order (a fixed order) before
+// group 0 writes the tile out.  What this buys in fp32 is matrix-pipe time: a 3x3 x 256-channel layer with a handful of
+// tiles is 1152 dependent 32x32x2 MFMAs = 31 us per wave however its tiles are staged (profiles/r04_q_ab_small_tile_f32.txt).
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2, int KSPLIT = 1>
+__global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArgs pp) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
     const GatherArgs& p = pp;
@@ -404,10 +408,11 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
     static_assert(BK % B_RPP == 0, "filter tile vs staging pass");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int grp = KSPLIT > 1 ? wave_all >> 2 : 0;                                      // k-split group of this wave
+    const int wave = KSPLIT > 1 ? (wave_all & 3) : wave_all, lane = threadIdx.x & 63;
+    const int tid = KSPLIT > 1 ? wave * 64 + lane : (int)threadIdx.x;                    // thread index inside the group
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem) + grp * (NS * STAGE);      // the group's stages
     const int wg = xcd_remap(blockIdx.x - wg_first, wg_count);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -554,7 +559,43 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
         }
     };
 
-    if constexpr (NS == 2) {
+    if constexpr (KSPLIT > 1) {
+        const int nkg = nk > grp ? (nk - grp + KSPLIT - 1) / KSPLIT : 0;      // this group's iterations
+        const int trips = (nk + KSPLIT - 1) / KSPLIT;                         // every group passes the same barriers
+        static_assert(NS == 2, "the k-split instantiation runs two stages per group");
+        if (nkg > 0) issue(grp, 0);
+        for (int j = 0; j < trips; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j + 1 < nkg) issue(grp + (j + 1) * KSPLIT, (j + 1) & 1);
+            if (j < nkg) compute(j & 1);
+        }
+        __syncthreads();
+        // groups 1 .. KSPLIT - 1 park their accumulators in LDS (a private 16-float slot per thread and block), group 0 adds them
+        // in group order: thread t of every group holds the same elements of the tile
+        float* park = smem;
+        if (grp > 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        park[(((grp - 1) * TM * TN + mi * TN + ni) * 16 + r) * 256 + tid] = acc[mi][ni][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll 1
+        for (int g = 1; g < KSPLIT; ++g)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mi][ni][r] += park[(((g - 1) * TM * TN + mi * TN + ni) * 16 + r) * 256 + tid];
+    } else if constexpr (NS == 2) {
         // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
         if (nk > 0) issue(0, 0);
         for (int k = 0; k < nk; ++k) {
@@ -1123,17 +1164,19 @@ static void check_desc(const ConvDesc& d) {
                 "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2, int KSPLIT = 1>
 static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t lds = NS * (size_t)(BM + BN) * 128;
-    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY, NS>;
+    constexpr size_t stages = KSPLIT * NS * (size_t)(BM + BN) * 128, park = (size_t)(KSPLIT - 1) * TM * TN * 16 * 256 * 4;
+    constexpr size_t lds = stages > park ? stages : park;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY, NS, KSPLIT>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256 * KSPLIT), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -1178,6 +1221,15 @@ static int pick_tile(long long M, int N, int mode) {
 // a 32 x 32 x 2 fp32 MFMA retires two k per 64 cycles, so the serial k loop of a 3x3 x 256-channel layer is 1152 dependent
 // MFMAs = 31 us of matrix pipe per wave whatever the staging does -- per-layer times unchanged, step +0.2 ms from the
 // lost 128 x 64 tiles (profiles/r04_q_ab_small_tile_f32.txt).  What these layers need is k split over the waves of a workgroup.
+// SSD_SMALL_KSPLIT_F32=1 (default OFF): small layers (at most one 64 x 64 workgroup per CU, at least 16 k iterations) on the k-split
+// instantiation, four wave groups per tile.  Measured (profiles/r04_ac_ab_ksplit_f32.txt): conv11_2 forward 37 -> 32 us, the
+// small heads 63 -> 52 us, step 50.42 -> 50.65 ms.  A quarter of the MFMAs per wave bought 5-11 us: with two stages per group
+// every trip of the loop is still one whole DMA round trip from HBM (a handful of workgroups keeps 16 KB in flight per
+// group), and the 1024-thread workgroups start ~8 us apart.  The remedy for these layers is k split ACROSS CUs.
+static bool small_ksplit_f32(long long M, int N, int nk) {
+    static const int on = env_int("SSD_SMALL_KSPLIT_F32", 0), forced = env_int("SSD_TILE", -1);
+    return on && forced < 0 && nk >= 16 && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256;
+}
 static bool small_deep_f32(long long M, int N) {
     static const int on = env_int("SSD_SMALL_TILE_F32", 0), forced = env_int("SSD_TILE", -1);
     return on && forced < 0 && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256;
@@ -1210,6 +1262,10 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
     if (smallc) {
         if (y_bf16) launch_gather<MODE_FWD, 4, 1, 1, 2, true, false, true>(a, "conv_fwd_smallc_128x64_bf16out", fl, by, s);
         else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
+        return;
+    }
+    if (use_dma() && small_ksplit_f32(a.M, a.DN, cdiv(a.SC, 32) * a.ntaps)) {
+        launch_gather_dma<MODE_FWD, 2, 2, 1, 1, false, false, 2, 4>(a, "conv_fwd_64x64_k4", fl, by, s);
         return;
     }
     if (use_dma() && small_deep_f32(a.M, a.DN)) {
@@ -1306,6 +1362,8 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     } else if (d.stride > 1) {
         if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
+    } else if (use_dma() && small_ksplit_f32(a.M, a.DN, cdiv(a.SC, 32) * a.ntaps)) {
+        launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1, false, false, 2, 4>(a, "conv_dgrad_64x64_k4", fl, by, s);
     } else if (use_dma() && small_deep_f32(a.M, a.DN)) {
         launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1, false, false, 6>(a, "conv_dgrad_64x64x6", fl, by, s);
     } else if (use_dma()) {

@@ -129,6 +129,8 @@ FP32_VARIANTS = [
     dict(SSD_GLDS='0', SSD_TILE='1', SSD_WGRAD_CFG='1'),
     dict(SSD_GLDS='0', SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_FIRST_F32='0', SSD_FIRST_WGRAD_F32='0'),
     dict(SSD_GLDS='0', SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_DGRAD_PARITY='0', SSD_WGRAD_ROUNDS='0'),
+    dict(SSD_SMALL_TILE_F32='1'),                                                      # round 4: the small layers' deep ring ...
+    dict(SSD_SMALL_KSPLIT_F32='1'),                                                    # ... and their k split over four wave groups (both off by default)
 ]
 
 
