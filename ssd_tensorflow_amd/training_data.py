@@ -295,9 +295,27 @@ class _WorkerPool:
         self.pinned = []
         self.workers = []
         anchors_abs = prime_anchor_table(recipe.td.preset)      # (computed once per process, on the GPU unless a test installed one)
-        with _NoMainReimport():
+        try:
+            with _NoMainReimport():
+                for _ in range(num_workers):
+                    w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
+                    w.start()
+                    self.workers.append(w)
+        except Exception as e:      # no fork server to be had (e.g. nothing picklable about a custom source): the direct fork still works
+            if ctx.get_start_method() == 'fork':
+                raise
+            import warnings
+            warnings.warn('feeder workers could not be started through %s (%s: %s); forking them directly' %
+                          (ctx.get_start_method(), type(e).__name__, e), RuntimeWarning)
+            for w in self.workers:
+                try:
+                    w.terminate()
+                except Exception:
+                    pass
+            self.workers = []
+            fork = mp.get_context('fork')
             for _ in range(num_workers):
-                w = ctx.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
+                w = fork.Process(target=_worker_main, args=(recipe, self.tasks, self.results, anchors_abs), daemon=True)
                 w.start()
                 self.workers.append(w)
 

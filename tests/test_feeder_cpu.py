@@ -248,3 +248,24 @@ def test_killed_worker_ends_a_two_rank_job(tmp_path):
     assert 'a feeder worker process died' in r.stderr, r.stderr[-3000:]
     assert 'rank 1 finished the epoch' not in r.stdout
     assert took < 120, took
+
+
+def test_unpicklable_recipe_falls_back_to_a_direct_fork():
+    """Something in the recipe that cannot travel to a fork-server worker (here: a lambda as the sample accessor) must not break
+    the feeder: it warns and forks the workers directly, as round 3 did."""
+    import warnings
+    _prime()
+    td = TrainingData(None, 'vgg300', num_train=12, num_valid=4, augment=True, device_tensors=False)
+    td._upload_hook = _host_upload
+    try:
+        want = _collect(td, td.train_generator, 4, 0)
+        recipe = td._recipes['train']
+        orig = recipe.sample_at
+        recipe.sample_at = lambda i: orig(i)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            got = _collect(td, td.train_generator, 4, 2)
+        _same(want, got)
+        assert any('forking them directly' in str(w.message) for w in caught)
+    finally:
+        td.close()
