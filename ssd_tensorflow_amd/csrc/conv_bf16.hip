@@ -1960,20 +1960,23 @@ static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, doubl
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, bmv) * a.NT), dim3(256), lds, s, a, dil);
     HIP_OK(hipGetLastError());
 }
-// 128 x 64 tiles (three workgroups per CU) where they fill the chip's slots better than 128 x 128 (two per CU) does: the
-// launch time follows the most loaded CU.  0.9 prices the narrower tile's extra staging.  SSD_GATHER_ROWS_N64_BF16: 0 off,
-// 1 by this rule (default), 2 everywhere (tests).
-// g_conv_lanes: how many launches of this shape run side by side (the executor's forward lanes): the slots are shared, so the
-// fill is that of all of them together -- judged alone, a half-batch conv4_x launch looks 71 % full and takes the narrow tile,
-// which made the step 1 % slower (profiles/r04_o_ab_rows_n64_bf16.txt).
+// 128 x 64 tiles (three workgroups per CU) -- where they cut PADDED COLUMNS: the fused 19x19 head (N = 152: three 64-wide tiles carry
+// 79 % useful columns, two 128-wide ones 59 %; 361 -> 520 TFLOP/s sustained, not power-limited: 2.39 GHz either way).
+// NOT where they merely fill the chip's workgroup slots better (conv5_x, mod_conv6: 364 workgroups on 512 slots against 728 on
+// 768).  A single launch does run faster that way (67 -> 58 us) -- but back to back, as in a training step, the better-filled
+// tile draws more power and the chip clocks down: conv5_2 forward 996 TFLOP/s at 2.22 GHz on 128 x 128 tiles against 949 TFLOP/s
+// at 1.89 GHz on 128 x 64 (tools/power_probe.py conv5_2, profiles/r04_ae_power_clock_19x19_bf16.txt).  Idle CUs are not waste under
+// a power limit; the staged bytes per MFMA are.  SSD_GATHER_ROWS_N64_BF16: 0 off, 1 by the padded-columns rule (default), 2
+// everywhere (tests), 3 round 4's first rule (also by slot fill; the lanes' launches counted together: g_conv_lanes).
 thread_local int g_conv_lanes = 1;
 static bool gather_rows_n64(int M, int N) {
     static const int on = env_int("SSD_GATHER_ROWS_N64_BF16", 1);
-    if (on != 1) return on == 2;
+    if (on == 0 || on == 2) return on == 2;
+    const double waste128 = (double)N / (cdiv(N, 128) * 128), waste64 = (double)N / (cdiv(N, 64) * 64);      // useful columns
+    if (on == 1) return waste64 > waste128 * 1.1;
     M *= g_conv_lanes;
     auto fill = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
     const double f128 = fill((long long)cdiv(M, 128) * cdiv(N, 128), 512), f64 = fill((long long)cdiv(M, 128) * cdiv(N, 64), 768);
-    const double waste128 = (double)N / (cdiv(N, 128) * 128), waste64 = (double)N / (cdiv(N, 64) * 64);      // useful columns (fused heads: N = 104 / 152)
     return f64 * waste64 * 0.9 > f128 * waste128;
 }
 // 256-row tiles where they fill the chip (512 workgroup slots) at least twice; dil = 1 only (the tile owns 256 - 2 dil rows)

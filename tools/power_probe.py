@@ -147,6 +147,11 @@ def conv_fns(hw, ci, co, k, bf16, zero=False, B=32):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in ('conv5_2', 'head1'):      # round 4: a 19x19 layer under whatever tile the environment selects
+        fl, keep, fns = conv_fns(19, 512, 512, 3, True) if sys.argv[1] == 'conv5_2' else conv_fns(19, 1024, 152, 3, True)
+        for tag in (('fwd', 'dgrad', 'wgrad') if sys.argv[1] == 'conv5_2' else ('fwd',)):
+            phase(f'{sys.argv[1]} b32 bf16 (post-relu operands) {tag} [N64={os.environ.get("SSD_GATHER_ROWS_N64_BF16", "rule")}]', fns[tag], fl, 2.0)
+        return
     print('sensors:', (CARD + ' + ' + HWMON) if CARD else 'rocm-smi --showclocks --showpower --json', '| first reading', read_sensors())
     phase('idle (monitor wave only)', lambda: time.sleep(0.001), 0.0, 1.5)
     for label, bf16, zero in (('fp32', False, False), ('bf16 (post-relu operands)', True, False), ('bf16 all-zero operands', True, True)):
