@@ -147,6 +147,16 @@ def conv_fns(hw, ci, co, k, bf16, zero=False, B=32):
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == 'sustained':      # round 4: any layer back to back under the environment's kernel choice
+        table = {'conv2_2': (150, 128, 128), 'conv3_2': (75, 256, 256), 'conv4_2': (38, 512, 512), 'conv5_2': (19, 512, 512),
+                 'conv2_1': (150, 64, 128), 'conv3_1': (75, 128, 256), 'conv4_1': (38, 256, 512), 'conv1_2': (300, 64, 64)}
+        hw, ci, co = table[sys.argv[2]]
+        bf16 = not (len(sys.argv) > 3 and sys.argv[3] == 'f32')
+        fl, keep, fns = conv_fns(hw, ci, co, 3, bf16)
+        env = ' '.join(f'{k[4:]}={v}' for k, v in sorted(os.environ.items()) if k.startswith('SSD_') and k not in ('SSD_BENCH_RELU',))
+        for tag in ('fwd', 'dgrad', 'wgrad'):
+            phase(f'{sys.argv[2]} {"bf16" if bf16 else "f32"} {tag} [{env or "default"}]', fns[tag], fl, 1.6)
+        return
     if len(sys.argv) > 1 and sys.argv[1] in ('conv5_2', 'head1'):      # round 4: a 19x19 layer under whatever tile the environment selects
         fl, keep, fns = conv_fns(19, 512, 512, 3, True) if sys.argv[1] == 'conv5_2' else conv_fns(19, 1024, 152, 3, True)
         for tag in (('fwd', 'dgrad', 'wgrad') if sys.argv[1] == 'conv5_2' else ('fwd',)):
