@@ -1979,10 +1979,18 @@ static bool gather_rows_n64(int M, int N) {
     const double f128 = fill((long long)cdiv(M, 128) * cdiv(N, 128), 512), f64 = fill((long long)cdiv(M, 128) * cdiv(N, 64), 768);
     return f64 * waste64 * 0.9 > f128 * waste128;
 }
-// 256-row tiles where they fill the chip (512 workgroup slots) at least twice; dil = 1 only (the tile owns 256 - 2 dil rows)
+// 256-row tiles where they fill the chip's 512 workgroup slots often enough; dil = 1 only (the tile owns 256 - 2 dil rows).
+// Round 4: the count is taken over the launches that run side by side (the forward lanes: g_conv_lanes) and the bar is 700
+// instead of 1024 workgroups -- under sustained load (profiles/r04_ag_sustained_tile_sweep_bf16.txt) the 256-row tile is ahead
+// wherever it was tried: conv2_2 forward 957 vs 883 TFLOP/s, conv3_2 1122 vs 1077, conv4_2 1161 vs 1135 (732 workgroups); the
+// half-batch launches of conv3_x in the forward lanes (712 each) had been on 128-row tiles.  SSD_GATHER_ROWS256_BF16: 0 off,
+// 1 this rule, 2 every eligible layer (tests), 3 round 3's rule (1024 workgroups, per launch).
 static bool gather_rows256(const ConvDesc& d, int M, int N) {
-    static const int on = env_int("SSD_GATHER_ROWS256_BF16", 1);      // A/B switch; 2 = every eligible layer (tests)
-    return on && d.dil == 1 && (on == 2 || cdiv(M, 253) * cdiv(N, 128) >= 1024);
+    static const int on = env_int("SSD_GATHER_ROWS256_BF16", 1);
+    if (!on || d.dil != 1) return false;
+    if (on == 2) return true;
+    if (on == 3) return cdiv(M, 253) * cdiv(N, 128) >= 1024;
+    return (long long)cdiv((long long)M * g_conv_lanes, 253) * cdiv(N, 128) >= 700;
 }
 
 void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, void* y, bool y_f32, bool relu,
