@@ -1273,7 +1273,10 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
         return;
     }
     if (use_dma()) {
-        switch (pick_tile(a.M, a.DN, MODE_FWD)) {
+        // (the cost model counts rounds of workgroups on the chip: the launches that run side by side -- the executor's forward
+        // lanes, g_conv_lanes -- share it.  SSD_TILE_LANES=0: per launch, as before round 4.)
+        static const int lane_aware = env_int("SSD_TILE_LANES", 1);
+        switch (pick_tile((long long)a.M * (lane_aware ? g_conv_lanes : 1), a.DN, MODE_FWD)) {
         case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2>(a, "conv_fwd_128x128", fl, by, s); break;
         case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2>(a, "conv_fwd_128x64", fl, by, s); break;
         case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2>(a, "conv_fwd_64x128", fl, by, s); break;
