@@ -213,13 +213,15 @@ static int env_i(const char* name, int dflt) {
 //    all of them sat behind conv11_2, and because the heads of a lane share one in-order side stream whose first entry
 //    (head 0) needs the l2-norm, the six heads ran back to back AFTER the trunk on a nearly empty chip: 340 us of a
 //    7.47 ms bf16 step with fewer than 256 workgroups in flight (profiles/r04_a_timeline_bf16.txt; fp32: 0.6 ms).
-//  * Backward: the latency-bound chain (small heads' data gradients -> conv11_2 ... conv8_2) is what the first big data
-//    gradient (conv8_1 -> mod_conv7 -> mod_conv6) waits for, and its launches queue for LDS behind whatever fills the CUs
-//    beside them (gaps of 35-40 us between two chain kernels in the same trace).  So: the chain first; head 1's data
-//    gradient (main stream) gated behind a point of the chain (SSD_BW_HEAD1_POS chain ops, default: its end); head 0's data
-//    gradient and the l2-norm backward deferred to the side stream beside mod_conv6's data gradient (1.4 rounds of
-//    workgroups, idle CUs in its tail) -- they are needed by pool4's backward only.
-// SSD_FWD_ORDER=0 / SSD_BW_ORDER=0 restore graph order (A/B switches).
+//  * Backward: REVERSE GRAPH ORDER by default.  SSD_BW_ORDER=1 selects the alternative built here -- the latency-bound chain
+//    (small heads' data gradients -> conv11_2 ... conv8_2, what the first big data gradient waits for, and whose launches queue
+//    for LDS behind whatever fills the CUs beside them: gaps of 35-40 us between two chain kernels in the same trace) first;
+//    head 1's data gradient (main stream) gated behind a point of the chain (SSD_BW_HEAD1_POS chain ops, default: its end);
+//    head 0's data gradient and the l2-norm backward deferred to the side stream beside mod_conv6's data gradient.  Measured:
+//    the chain shrinks from 450 to 264 us and the STEP grows from 7.22 to 7.37 ms (profiles/r04_g_ab_schedule_bf16.txt): what
+//    ran beside the chain on an otherwise empty chip now runs beside the big data gradients on a full one.  Kept as a switch;
+//    the bookkeeping below (bw_need / bw_sync / bw_final_lo) serves any valid order.
+// SSD_FWD_ORDER=0 restores graph order in forward (A/B switch).
 void Net::build_orders() {
     const int n = (int)ops_.size();
     fwd_order_.clear();
