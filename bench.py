@@ -38,8 +38,7 @@ PEAK_HBM = 8000.0           # GB/s spec
 # template arguments that select the tile are spelled out, so a kernel that gains a trailing template parameter
 # still matches (r01's table carried the full argument list and went stale).
 def _gather(mode, wm, wn, tm, tn):
-    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn),     # default (LDS-DMA staging)
-            'conv_gather_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn)]         # SSD_GLDS=0
+    return ['conv_gather_dma_kernel<%d, %d, %d, %d, %d,' % (mode, wm, wn, tm, tn)]      # (LDS-DMA staging)
 
 
 def _wgrad(wm, wn, tm, tn):
@@ -62,7 +61,16 @@ KERNEL_SYMBOLS = {
     'conv_dgrad_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_64x64': _gather(1, 2, 2, 1, 1),
     'conv_wgrad_128x128': _wgrad(2, 2, 2, 2), 'conv_wgrad_64x64': _wgrad(2, 2, 1, 1),
     'conv_wgrad_64x128': _wgrad(2, 2, 1, 2), 'conv_wgrad_128x64': _wgrad(2, 2, 2, 1),
-    'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'], 'detect_fused': ['detect_fused_kernel'],
+    # round 5: the same kernels with the 2x2 pool fused (forward: a POOL instantiation; data gradient: the same instantiation, the
+    # un-pool is a run-time branch of its epilogue)
+    'conv_fwd_pool_128x128': _gather(0, 2, 2, 2, 2), 'conv_fwd_pool_128x64': _gather(0, 4, 1, 1, 2),
+    'conv_fwd_pool_64x128': _gather(0, 2, 2, 1, 2), 'conv_fwd_pool_64x64': _gather(0, 2, 2, 1, 1),
+    'conv_dgrad_unpool_128x128': _gather(1, 2, 2, 2, 2), 'conv_dgrad_unpool_128x64': _gather(1, 4, 1, 1, 2),
+    'conv_dgrad_unpool_64x128': _gather(1, 2, 2, 1, 2), 'conv_dgrad_unpool_64x64': _gather(1, 2, 2, 1, 1),
+    'conv_fwd_pool_bf16_c64': ['conv_fwd_pool_bf16_c64_kernel'], 'conv_fwd_pool_bf16_rows_256x128': ['conv_fwd_pool_bf16_rows_kernel'],
+    'conv_dgrad_unpool_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<1, 4'], 'conv_dgrad_unpool_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2, 2'],
+    'conv_dgrad_unpool_bf16_256x64_8w': _gbf(1, 8, 1, 1, 2), 'conv_dgrad_unpool_bf16_128x64': _gbf(1, 4, 1, 1, 2),
+    'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'],
     'multibox_loss': ['heads_kernel<true>'], 'multibox_loss_grad': ['loss_grad_kernel<'], 'heads_result': ['heads_kernel<false>'],
     'conv_fwd_bf16_128x128': _gbf(0, 2, 2, 2, 2), 'conv_fwd_bf16_128x64': _gbf(0, 4, 1, 1, 2),
     'conv_fwd_bf16_64x128': _gbf(0, 2, 2, 1, 2), 'conv_fwd_bf16_256x64_8w': _gbf(0, 8, 1, 1, 2),

@@ -118,6 +118,14 @@ SIGNATURES = {
     'ssd_op_conv2d_first_fwd_bf16': (i32, [vp, vp, vp, vp] + [i32] * 14 + [vp]),
     'ssd_op_conv2d_first_wgrad_bf16_ws_floats': (sz, [i32] * 13),
     'ssd_op_conv2d_first_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
+    'ssd_op_maxpool_rec_fwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'ssd_op_maxpool_rec_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'ssd_op_conv2d_fwd_pool': (i32, [vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_fwd_pool_bf16': (i32, [vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_dgrad_unpool': (i32, [vp, vp, vp, vp, i32, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_dgrad_unpool_bf16': (i32, [vp, vp, vp, vp, i32, i32] + [i32] * 13 + [vp]),
+    'ssd_pool_fusion': (i32, [handle, p_i32, i32, p_i32]),
+    'ssd_debug_set_ablate': (i32, [cstr]),
     'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),
     'ssd_op_maxpool_bwd': (i32, [vp, vp, vp, i32, i32] + [i32] * 10 + [vp]),
     'ssd_op_clock_monitor': (i32, [vp, i32, C.c_uint, vp]),

@@ -839,6 +839,70 @@ int ssd_op_maxpool_bwd(const float* x, const float* dy, float* dx, int accumulat
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));     // the scratch dies here
     API_END
 }
+// 2x2 stride-2 pooling with the forward-written record (ops.h), fp32 (bf16 = 0) or bf16 storage: the unfused form of the
+// fused-pool entry points below (tests compare the two bit for bit)
+int ssd_op_maxpool_rec_fwd(const void* x, void* y, void* rec, int bf16, int b, int hi, int wi, int c, void* stream) {
+    API_BEGIN
+    PoolDesc d{b, hi, wi, c, (hi + 1) / 2, (wi + 1) / 2, 2, 2, 0, 0};
+    if (bf16) maxpool_fwd_rec(d, (const bf16_t*)x, (bf16_t*)y, rec, (hipStream_t)stream);
+    else maxpool_fwd_rec(d, (const float*)x, (float*)y, rec, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_maxpool_rec_bwd(const void* rec, const void* dy, void* dx, int relu_mask, int bf16, int b, int hi, int wi, int c,
+                           void* stream) {
+    API_BEGIN
+    PoolDesc d{b, hi, wi, c, (hi + 1) / 2, (wi + 1) / 2, 2, 2, 0, 0};
+    if (bf16) maxpool_bwd_rec(d, rec, (const bf16_t*)dy, (bf16_t*)dx, relu_mask != 0, (hipStream_t)stream);
+    else maxpool_bwd_rec(d, rec, (const float*)dy, (float*)dx, relu_mask != 0, (hipStream_t)stream);
+    API_END
+}
+// conv (3x3 stride 1 SAME) + bias + relu + 2x2 stride-2 max-pool in ONE kernel: y_pool [b][(ho+1)/2][(wo+1)/2][co], rec = the
+// pool's record or NULL; the convolution's own output is not written (conv.h conv_fwd_pool)
+int ssd_op_conv2d_fwd_pool(const float* x, const float* w, const float* bias, float* y_pool, void* rec, int b, int hi, int wi,
+                           int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    conv_fwd_pool(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), x, w, bias, y_pool, rec, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_fwd_pool_bf16(const void* x, const void* w_oi, const float* bias, void* y_pool, void* rec, int b, int hi, int wi,
+                                int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w,
+                                void* stream) {
+    API_BEGIN
+    conv_fwd_pool_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), (const bf16_t*)x, (const bf16_t*)w_oi, bias,
+                       (bf16_t*)y_pool, rec, (hipStream_t)stream);
+    API_END
+}
+// data gradient of a conv whose input is a pooled tensor, routed through the pool's record into the pool's input gradient
+// [b][uh][uw][ci] (relu mask of that tensor's producer from the record's sign bit); the geometry is the convolution's
+int ssd_op_conv2d_dgrad_unpool(const float* dy, const float* w, float* dx_unpooled, const void* rec, int uh, int uw, int b, int hi,
+                               int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w,
+                               void* stream) {
+    API_BEGIN
+    conv_dgrad_unpool(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), dy, w, dx_unpooled, rec, uh, uw,
+                      (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_dgrad_unpool_bf16(const void* dy, const void* w_io, void* dx_unpooled, const void* rec, int uh, int uw, int b,
+                                    int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h,
+                                    int pad_w, void* stream) {
+    API_BEGIN
+    conv_dgrad_unpool_bf16(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w), (const bf16_t*)dy, (const bf16_t*)w_io,
+                           (bf16_t*)dx_unpooled, rec, uh, uw, (hipStream_t)stream);
+    API_END
+}
+// which of its 2x2 pools the handle runs fused: bit 0 of out[i] = forward (producer's epilogue), bit 1 = backward (consumer's
+// data gradient); i counts the 2x2 stride-2 pools in graph order; *count = their number
+int ssd_pool_fusion(ssd_handle h, int* out, int cap, int* count) {
+    API_BEGIN_NET(h)
+    n.pool_fusion(out, cap, count);
+    API_END
+}
+// measurement aid (tools/step_time.py): drop groups of launches from every handle's step ("" / NULL = none); results are WRONG
+int ssd_debug_set_ablate(const char* tokens) {
+    API_BEGIN
+    set_ablate(tokens);
+    API_END
+}
 int ssd_grads_to_bf16(int device, const float* grads_dev, void* msg_dev, size_t count, void* stream) {
     API_BEGIN
     DeviceGuard guard(device);

@@ -50,11 +50,8 @@ struct DetectOut {
 };
 size_t detect_ws_bytes(int B, int A);
 // nms = false: decode_boxes only (confidence order, nothing suppressed)
-// tickets_zeroed: the caller has zeroed the first detect_ticket_bytes() of ws once and nothing but detect() writes there (the
-// fused launch leaves its tickets at zero); false: detect() zeroes them in stream order before every pass.
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap,
-            int max_out, int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s, bool tickets_zeroed = false);
-size_t detect_ticket_bytes();
+            int max_out, int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s);
 
 // non_maximum_suppression / suppress_overlaps on an arbitrary list: boxes [n][4] i32 (xmin,xmax,ymin,ymax),
 // conf [n], group [n] (0..ngroups-1); keep [n+1]: keep[0] = count, then the selected input indices in output order.

@@ -312,9 +312,6 @@ __device__ __forceinline__ void detect_scan_block(const int blk, const int t, fl
         if (w < wv) base += s_cnt[half][w];
         tot0 += s_cnt[0][w]; tot1 += s_cnt[1][w];
     }
-    // The candidates and their counts are handed to ANOTHER workgroup inside the same launch (detect_fused_kernel): stored
-    // write-through at agent scope (`sc1`) and read the same way, the form MI355X_MICROARCH.md lists for small payloads -- a
-    // release fence per scan workgroup writes back the XCD's whole L2 each time (measured: the pass at 188 us instead of 50).
     if (key != 0ull) {
         const u64 bal = half ? bal1 : bal0;
         __hip_atomic_store(dense + (size_t)(half ? boundary : r0) + base + __popcll(bal & ((1ull << lane) - 1ull)), key, __ATOMIC_RELAXED,
@@ -418,7 +415,7 @@ __device__ __forceinline__ bool overlaps45(int x0, int x1, int y0, int y1, int a
 __device__ __forceinline__ void nms_segment(const int4* nbox, unsigned char* al_plain, int s0, int len, int lane) {
     // The segment bounds come out of LDS, i.e. in vector registers: left there, the compiler treats the pivot loop as
     // divergent (exec-mask bookkeeping, 64-bit vector shifts for the survivor mask, a v_readfirstlane per v_readlane) --
-    // ~420 cycles per pivot, 7.8 us of the 23 us this kernel took at batch 128 (SSD_DETECT_STAMPS=1).  They are wave
+    // ~420 cycles per pivot, 7.8 us of the 23 us this kernel took at batch 128 (phase clocks of workgroup 0, a measurement aid of round 3).  They are wave
     // uniform, so say so: the loop counter, the survivor mask and the pivot's coordinates then live in scalar registers.
     s0 = __builtin_amdgcn_readfirstlane(s0);
     len = __builtin_amdgcn_readfirstlane(len);
@@ -489,16 +486,7 @@ struct DetectArgs {
     int* box;       // [B][A][4]
     int* nbox;      // [B][A][4]
     DetectOut out;
-    unsigned long long* stamps;   // measurement aid (SSD_DETECT_STAMPS=1): workgroup 0's clock at each phase boundary
 };
-#define DET_STAMP(k)                                                                  \
-    do {                                                                              \
-        if (p.stamps && b == 0 && threadIdx.x == 0) {                                 \
-            p.stamps[2 * (k)] = __builtin_readcyclecounter();                         \
-            p.stamps[2 * (k) + 1] = wall_clock64();                                   \
-        }                                                                             \
-    } while (0)
-
 // survivors in order -> the caller's arrays, clipped to [:max_out] / out_cap
 template <typename KeyAt, typename BoxAt>
 __device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, const unsigned char* alive, KeyAt key_at,
@@ -537,8 +525,7 @@ __device__ __forceinline__ void detect_emit(const DetectArgs& p, int b, int m, c
 }
 
 // The per-image phase: rank, decode, NMS and ordered emit of image b by one workgroup of DET_THREADS threads; `smem` = DET_SMEM
-// bytes of the caller's LDS.  Called by detect_image_kernel (one workgroup per image) or, by default, by the scan workgroup
-// that delivers an image's last candidate segment (detect_fused_kernel).
+// bytes of the caller's LDS.  Called by detect_image_kernel (one workgroup per image).
 __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int b, unsigned char* smem) {
     __shared__ int firstpos[32], crank[32], ccount[32], segstart[33], order_cls[32];
     __shared__ int s_npresent, s_wtot[DET_WAVES];
@@ -547,7 +534,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     u64* g1 = p.keys1 + (size_t)b * p.A2;
-    DET_STAMP(0);
     // ---- the image's candidate segments (one per scan workgroup that touched the image) ----------------
     __shared__ int seg_off[DET_MAX_SEGS + 1], seg_base[DET_MAX_SEGS];
     __shared__ int s_pos[DET_FAST], s_cpos[DET_FAST];
@@ -578,7 +564,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
     }
     __syncthreads();
     const int n = seg_off[nseg];
-    DET_STAMP(1);
     auto candidate = [&](int f) {            // f-th candidate of the image (any order: the keys are unique and get sorted)
         int lo = 0, hi = nseg - 1;
         while (lo < hi) {
@@ -624,7 +609,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
         }
         if (tid < 32) { firstpos[tid] = INT_MAX; ccount[tid] = 0; }
         __syncthreads();
-        DET_STAMP(2);      // candidates, offsets and anchors loaded
         const int m = p.cap >= 0 ? min(n, p.cap) : n;          // detections_cap (ssdutils.py:207-210)
         // The output order is: class groups in first-appearance order of the confidence-sorted list (defaultdict,
         // ssdutils.py:311-314) = classes by their best key, and inside a group by key.  When no cap bites (m == n, the
@@ -675,7 +659,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
                 }
             }
             __syncthreads();
-            DET_STAMP(3);      // ranking
             if (tid < 64) {         // one lane per class: its rank among the present classes and where its segment starts
                 const bool present = tid < 32 && ccount[tid & 31] > 0;
                 const u64 mine = present ? cmax[tid & 31] : 0ull;
@@ -720,7 +703,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
             }
         }
         __syncthreads();
-        DET_STAMP(3);      // ranking sweep
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             const int i = tid + DET_THREADS * r;
@@ -755,7 +737,6 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
         }
         }
         __syncthreads();
-        DET_STAMP(4);      // class groups
         // place, decode
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
@@ -774,12 +755,9 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
             }
         }
         __syncthreads();
-        DET_STAMP(5);      // decode
         for (int r = wave; r < s_npresent; r += DET_WAVES) nms_segment(nbox, alive, segstart[r], segstart[r + 1] - segstart[r], lane);
         __syncthreads();
-        DET_STAMP(6);      // NMS
         detect_emit(p, b, m, alive, [&](int q) { return okey[q]; }, [&](int q) { return box[q]; }, s_wtot);
-        DET_STAMP(7);      // emit
         return;
     }
 
@@ -872,51 +850,10 @@ __global__ __launch_bounds__(DET_THREADS) void detect_image_kernel(DetectArgs p)
     detect_image_body(p, blockIdx.x, smem);
 }
 
-// ONE launch for the whole pass (round 4; measured slower than the two launches and therefore NOT the default: see detect()).
-// A workgroup of 512 threads scans two blocks of 256 rows (its two halves), then the
-// thread that closes a block takes a ticket on every image the block touched; the workgroup that draws an image's LAST
-// ticket owns all of that image's candidate segments and runs the per-image phase at once, while the other workgroups are
-// still scanning.  What this removes: the second launch, its ramp over 128 workgroups on 256 CUs, and the wait of every
-// image for the slowest scan workgroup of the batch -- the per-image phases spread under the scan (HBM-bound, 6.4 TB/s).
-// Cross-workgroup hand-off in the write-through form of MI355X_MICROARCH.md: `sc1` stores of the payload, every lane's vmcnt
-// drained, barrier, one relaxed agent-scope atomic per touched image; the last arriver reads the payload with `sc1` loads.  No
-// fence anywhere.  The tickets reset themselves (the last arriver stores 0): zero again when the launch has finished.
-constexpr int FUSED_SMEM = 2 * SCAN_ROWS * SCAN_MAXV * 4 > DET_SMEM ? 2 * SCAN_ROWS * SCAN_MAXV * 4 : DET_SMEM;
-static_assert(DET_THREADS == 2 * SCAN_ROWS, "two scan blocks per workgroup");
-
-// (4 waves per SIMD = two of these workgroups per CU: left alone the compiler spends 246 registers on the inlined per-image phase
-// and ONE workgroup per CU scans at a third of the HBM rate)
-__global__ __launch_bounds__(DET_THREADS, 4) void detect_fused_kernel(DetectArgs p, float thr, u64* __restrict__ dense, int* __restrict__ bcount,
-                                                                   int* __restrict__ tickets, int nblocks, int run_body) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FUSED_SMEM];
-    __shared__ int s_cnt[2][2][4];
-    __shared__ int s_todo[4], s_ntodo;
-    const int h = threadIdx.x >> 8, t = threadIdx.x & 255;
-    const int blk = blockIdx.x * 2 + h;
-    if (threadIdx.x == 0) s_ntodo = 0;
-    detect_scan_block(blk < nblocks ? blk : nblocks + 1, t, reinterpret_cast<float*>(smem) + h * (SCAN_ROWS * p.nv), s_cnt[h], p.A, p.nv, p.B,
-                      p.pred, thr, dense, bcount);
-    __syncthreads();                                   // every store of the workgroup's two blocks has been issued
-    if (t == 0 && blk < nblocks) {
-        const int r0 = blk * SCAN_ROWS;
-        const int last_row = min(r0 + SCAN_ROWS, p.B * p.A) - 1;
-        for (int img = r0 / p.A; img <= last_row / p.A; ++img) {
-            const int nseg = ((img + 1) * p.A - 1) / SCAN_ROWS - (img * p.A) / SCAN_ROWS + 1;
-            const int old = __hip_atomic_fetch_add(tickets + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == nseg - 1) {                     // this block was the image's last segment
-                __hip_atomic_store(tickets + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_todo[atomicAdd(&s_ntodo, 1)] = img;
-            }
-        }
-    }
-    __syncthreads();
-    const int ntodo = s_ntodo;
-    if (ntodo == 0 || !run_body) return;
-    for (int k = 0; k < ntodo; ++k) {
-        detect_image_body(p, s_todo[k], smem);
-        __syncthreads();
-    }
-}
+// (Round 4 also built the pass as ONE launch -- scan workgroups taking a ticket per image, the last arriver running that image's
+// per-image phase beside the scan: bit-identical and slower, 92 us against 17.6 + 26.6 us (profiles/r04_y_detect_fused_probe.txt:
+// the scan half alone took 34 us in that form, and a chain of dependent loads beside an HBM-bound scan pays the loaded memory
+// system's latency at every link).  Removed in round 5.)
 
 static int pow2_ge(int n) {
     int p = 1;
@@ -928,11 +865,8 @@ static size_t det_bcount_bytes(int B, int A) {      // bcount [scan workgroups][
     const size_t blocks = ((size_t)B * A + SCAN_ROWS - 1) / SCAN_ROWS;
     return (blocks * 8 + 255) / 256 * 256 + 256;
 }
-// The fused launch's per-image tickets sit at the START of the workspace in a region of fixed size, whatever the batch of the
-// pass: a workspace shared by passes of different batch sizes keeps them where they are (and at zero).
 constexpr int DET_MAX_BATCH = 4096;
-size_t detect_ticket_bytes() { return (size_t)DET_MAX_BATCH * 4; }
-static size_t det_head_bytes(int B, int A) { return detect_ticket_bytes() + det_bcount_bytes(B, A); }
+static size_t det_head_bytes(int B, int A) { return det_bcount_bytes(B, A); }
 
 size_t detect_ws_bytes(int B, int A) {
     const size_t A2 = pow2_ge(A);
@@ -940,7 +874,7 @@ size_t detect_ws_bytes(int B, int A) {
 }
 
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
-            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s, bool tickets_zeroed) {
+            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s) {
     SSD_REQUIRE(A <= 32767 && A <= DET_MAX_ALIVE, "detect: at most 32767 anchors (got %d)", A);
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
     SSD_REQUIRE(A >= SCAN_ROWS, "detect: at least %d anchors", SCAN_ROWS);
@@ -950,8 +884,7 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     const int A2 = pow2_ge(A);
     SSD_REQUIRE(B <= DET_MAX_BATCH, "detect: at most %d images per pass (got %d)", DET_MAX_BATCH, B);
     char* base = (char*)ws;
-    int* tickets = (int*)base;
-    int* bcount = (int*)(base + detect_ticket_bytes()); base += det_head_bytes(B, A);
+    int* bcount = (int*)base; base += det_head_bytes(B, A);
     u64* dense = (u64*)base; base += ((size_t)B * A * 8 + 255) / 256 * 256;
     u64* keys1 = (u64*)base; base += (size_t)B * A2 * 8;
     u64* keys2 = (u64*)base; base += (size_t)B * A2 * 8;
@@ -959,51 +892,20 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     int* nbox = (int*)base;
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
-    // SSD_DETECT_FUSED=1: the single-launch form (detect_fused_kernel) -- A/B switch, default OFF: measured SLOWER
-    // (profiles/r04_y_detect_fused_probe.txt, batch 128): 92 us against 17.6 + 26.6 us for the two launches.  Its scan half alone
-    // takes 34 us (two 512-thread workgroups of 76 KB per CU instead of six small ones), and a per-image phase that runs BESIDE
-    // the scan -- a chain of dependent loads -- pays the loaded memory system's latency at every link: 58 us instead of 26.
-    static const bool fused = [] { const char* v = getenv("SSD_DETECT_FUSED"); return v && v[0] == '1'; }();
-    if (!fused) {
+    {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
                            conf_thr, dense, bcount);
-    } else if (!tickets_zeroed) {      // a caller-owned workspace of unknown content (the handle zeroes its own once)
-        HIP_OK(hipMemsetAsync(tickets, 0, (size_t)B * 4, s));
     }
     DetectArgs a{};
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
     a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;
-    static const bool stamps_on = [] { const char* v = getenv("SSD_DETECT_STAMPS"); return v && v[0] == '1'; }();
-    static unsigned long long* stamps_dev = nullptr;
-    if (stamps_on && !stamps_dev) {
-        HIP_OK(hipMalloc((void**)&stamps_dev, 16 * 2 * sizeof(unsigned long long)));
-        HIP_OK(hipMemset(stamps_dev, 0, 16 * 2 * sizeof(unsigned long long)));
-    }
-    a.stamps = stamps_on ? stamps_dev : nullptr;
-    if (fused) {
-        ProfScope prof("detect_fused", 0.0, (double)rows * nv * 4.0, s);
-        static const int run_body = [] { const char* v = getenv("SSD_DETECT_FUSED_NOBODY"); return (v && v[0] == '1') ? 0 : 1; }();      // measurement aid
-        hipLaunchKernelGGL(detect_fused_kernel, dim3((blocks + 1) / 2), dim3(DET_THREADS), 0, s, a, conf_thr, dense, bcount, tickets, blocks, run_body);
-    } else {
+    {
         ProfScope prof("detect_image", 0.0, 0.0, s);
         hipLaunchKernelGGL(detect_image_kernel, dim3(B), dim3(DET_THREADS), 0, s, a);
     }
     HIP_OK(hipGetLastError());
-    if (stamps_on) {      // measurement aid: workgroup 0's shader cycles / 100 MHz ticks per phase of the LDS path
-        static int calls = 0;
-        if (++calls % 64 == 0) {
-            unsigned long long h[16];
-            HIP_OK(hipStreamSynchronize(s));
-            HIP_OK(hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost));
-            static const char* const names[7] = {"segments", "loads", "rank", "classes", "decode", "nms", "emit"};
-            fprintf(stderr, "[detect stamps]");
-            for (int k = 1; k < 8; ++k)
-                fprintf(stderr, " %s %llu cyc %.2f us;", names[k - 1], h[2 * k] - h[2 * k - 2], (double)(h[2 * k + 1] - h[2 * k - 1]) / 100.0);
-            fprintf(stderr, " total %.2f us\n", (double)(h[15] - h[1]) / 100.0);
-        }
-    }
 }
 
 // =================================================================================

@@ -90,6 +90,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Measurement aid (net.hip): groups of launches dropped from the step, set through ssd_debug_set_ablate only
+void set_ablate(const char* tokens);
+bool ablated(const char* token);
+
 // TF SAME padding: pad_total = max((ceil(in/s)-1)*s + k_eff - in, 0); before = total/2.
 inline void tf_same(int in, int k, int s, int d, int* before, int* out) {
     int keff = (k - 1) * d + 1;

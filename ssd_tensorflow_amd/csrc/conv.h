@@ -30,6 +30,19 @@ size_t conv_wgrad_ws_floats(const ConvDesc& d);
 void conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias,
                 const float* w, float weight_decay, float* ws, hipStream_t s);
 
+// ---- 2x2 stride-2 max-pool fused into its neighbours (round 5; ops.h maxpool_*_rec is the unfused form) ----
+// Forward: y_pool[b][oh/2][ow/2][c] = max over the window of relu(conv + bias), first maximum in scan order wins, cells outside
+// the image never (TF SAME, no leading padding); rec (may be nullptr) = the pool's 12-bit record per (window, 4 channels).  The
+// convolution's own output is NOT written.  3x3 / stride 1 / SAME convolutions.  Bit-identical to conv_fwd + maxpool_fwd_rec.
+bool conv_fwd_pool_supported(const ConvDesc& d);
+void conv_fwd_pool(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y_pool, void* rec, hipStream_t s);
+// Backward: the data gradient of a conv whose INPUT is the pooled tensor, scattered through the pool's record into the
+// [B, UH, UW, Ci] gradient of the pool's input: cell = the recorded first maximum and (relu of the producer) the maximum was
+// positive ? dx : 0; every cell of dx_unpooled is written.  Bit-identical to conv_dgrad + maxpool_bwd_rec(relu_mask = true).
+bool conv_dgrad_unpool_supported(const ConvDesc& d);
+void conv_dgrad_unpool(const ConvDesc& d, const float* dy, const float* w, float* dx_unpooled, const void* rec, int UH, int UW,
+                       hipStream_t s);
+
 // dedicated fp32 first-layer forward (conv_first.hip): Ci*taps <= 32, Co == 64
 bool conv_first_fwd_f32_applicable(const ConvDesc& d);
 void conv_first_fwd_f32(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y, bool relu, hipStream_t s);
@@ -54,27 +67,6 @@ size_t conv_first_wgrad_bf16_ws_floats(const ConvDesc& d);
 void conv_first_wgrad_bf16(const ConvDesc& d, const float* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                            float weight_decay, float* ws, hipStream_t s);
 
-// Deferred reduce of the split-M weight-gradient slabs.  Every weight-gradient pass ends in a small reduce launch
-// (slabs -> dw + weight decay, bias sums): ~35 launches of 6..40 us per step.  While a ReduceBatch is installed
-// (thread local, by the step executor) those launches are queued instead and wgrad_reduce_flush() runs the whole
-// backward stage's reduces as ONE grouped launch.  Each queued layer's slab workspace must stay untouched until
-// the flush (the executor gives every layer its own).
-struct ReduceItem {
-    const float* ws;
-    const float* w;
-    float* dw;
-    float* db;
-    unsigned long long wcount;
-    int nsplit, Co;
-    float wd;
-    int lanes;          // threads sharing one float4 element (4, 16 or 64: many slabs x few elements -> more lanes)
-};
-struct ReduceBatch {
-    std::vector<ReduceItem> items;
-};
-extern thread_local ReduceBatch* g_reduce_batch;
-void wgrad_reduce_flush(ReduceBatch& batch, hipStream_t s);
-
 // One launch mirrors every layer's fp32 filter [tap][Ci][Co] as bf16 in the same order (io, the data
 // gradient's operand) and transposed [tap][Co][Ci] (oi, the forward operand), at the same offsets.
 struct FilterCastPlan {
@@ -95,6 +87,12 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
                    hipStream_t s);
 void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
                      hipStream_t s);
+// the bf16 forms of the fused pool (above); forward: est. fraction of the tile rows that carry pixels is part of "supported"
+bool conv_fwd_pool_bf16_supported(const ConvDesc& d);
+void conv_fwd_pool_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, bf16_t* y_pool, void* rec, hipStream_t s);
+bool conv_dgrad_unpool_bf16_supported(const ConvDesc& d);
+void conv_dgrad_unpool_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx_unpooled, const void* rec, int UH, int UW,
+                            hipStream_t s);
 size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d);
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s);

@@ -56,6 +56,15 @@ struct GatherArgsH {
     int wtaps, nclass, ODH, ODW;
     int cls_wg0[5], cls_M[4], cls_DH[4], cls_DW[4], cls_ntaps[4], cls_ph[4], cls_pw[4];
     int cls_dh[4][9], cls_dw[4][9], cls_w[4][9];
+    // Round 5, the 2x2 pools fused into their neighbours (conv.h).  Data gradient: unpool_rec != nullptr routes every pooled
+    // pixel's dx through the pool's record into the four cells of the pool's input gradient [.][UH][UW][DN] (gather_epilogue).
+    // Forward (conv_fwd_pool_bf16_*_kernel): 2-D tiles of R image rows x TW columns (+ a one-column halo either side) of ONE
+    // image, NSEG column segments x NBAND row bands per image; pooled tensor [PB][PH][PW][DN] + record.
+    const unsigned short* unpool_rec;
+    int UH, UW;
+    bf16_t* pool_dst;
+    unsigned short* pool_rec;
+    int PB, PH, PW, TW, NSEG, NBAND;
 };
 struct OutMap { int M, DH, DW, ph, pw, ODH, ODW; };      // parity class: virtual pixel (b, a, c) -> real pixel (b, 2 a + ph, 2 c + pw)
 
@@ -134,6 +143,17 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
     // through LDS (two barriers), all of them at once: fetched row by row inside the write-out loop, every row waited for
     // its own round trip (8 per tile: as long as the main loop of a 64- or 128-channel layer)
     u32x4 pre_mask[NPS], pre_old[NPS];
+    unsigned pre_rec[NPS];
+    if constexpr (MODE != MODE_FWD && !PARITY) {
+        if (p.unpool_rec) {      // the pool's record of this thread's 8 channels: two 12-bit entries
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                bool ok;
+                const size_t o = row_offset(h, r0 + ps * RPP, ok);      // = pooled pixel * DN + n (0 when there is nothing to write)
+                pre_rec[ps] = *reinterpret_cast<const unsigned*>(p.unpool_rec + (o >> 2));
+            }
+        }
+    }
     if constexpr (MODE != MODE_FWD) {
         if (p.mask) {
 #pragma unroll
@@ -198,6 +218,31 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                     v[2 * e] = lo2f(y[e]) > 0.f ? v[2 * e] : 0.f;
                     v[2 * e + 1] = hi2f(y[e]) > 0.f ? v[2 * e + 1] : 0.f;
                 }
+            }
+        }
+        if constexpr (MODE != MODE_FWD && !PARITY) {
+            if (p.unpool_rec) {
+                // pooled pixel m = (b, oh, ow) -> cells (2 oh + (q >> 1), 2 ow + (q & 1)) of the [UH][UW] image: the recorded first
+                // maximum gets dx if that maximum was positive (relu of the pooled tensor's producer), every other cell zero
+                const int m = (int)(o / (size_t)p.DN);
+                const int ow = m % p.DW, t2 = m / p.DW;
+                const int oh = t2 % p.DH, b = t2 / p.DH;
+                const bool okq[4] = {true, 2 * ow + 1 < p.UW, 2 * oh + 1 < p.UH, 2 * ow + 1 < p.UW && 2 * oh + 1 < p.UH};
+                const unsigned rw = pre_rec[ps];
+                bf16_t* d0 = reinterpret_cast<bf16_t*>(p.dst) + ((size_t)(b * p.UH + 2 * oh) * p.UW + 2 * ow) * p.DN + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!okq[q]) continue;
+                    float g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned re = (rw >> (16 * (e / 4) + 3 * (e & 3))) & 7u;
+                        g[e] = ((re & 3u) == (unsigned)q && (re & 4u)) ? v[e] : 0.f;
+                    }
+                    *reinterpret_cast<u32x4*>(d0 + ((size_t)(q >> 1) * p.UW + (q & 1)) * p.DN) =
+                        u32x4{pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7])};
+                }
+                continue;
             }
         }
         if (p.out_f32) {
@@ -619,7 +664,7 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 // Wave w owns pixel rows 32 w .. 32 w + 31 of the tile x all 64 channels (2 accumulator tiles); the results leave
 // straight from the accumulators (4 consecutive channels of one pixel per register quad = one 8-byte store).
 // =================================================================================
-template <int MODE, bool EPI>
+template <int MODE>
 __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks) {
     constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
     constexpr int ZROW = (AROWS - 1) * 128;
@@ -711,7 +756,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 
         // data gradient: the relu mask / the values to accumulate onto are fetched while the last kernel row multiplies
         // (one workgroup per CU: nothing else would hide that round trip)
-        u32x2 pre_mask[2][4], pre_old[2][4];
+        u32x2 pre_old[2][4];
         u32x4 row_mask[4];
 #pragma unroll
         for (int kr = 0; kr < 3; ++kr, ++gunit) {
@@ -722,11 +767,10 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const size_t o = (size_t)m * 64 + ni * 32 + 8 * g + 4 * lh;
-                        if (!EPI && p.mask) pre_mask[ni][g] = *reinterpret_cast<const u32x2*>(p.mask + o);
                         if (p.accum) pre_old[ni][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.dst) + o);
                     }
             }
-            if (EPI && MODE == MODE_DGRAD && kr == 2 && p.mask) {      // the mask in the write-out layout: whole 128-byte rows
+            if (MODE == MODE_DGRAD && kr == 2 && p.mask) {      // the mask in the write-out layout: whole 128-byte rows
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r2 = wave * 32 + i * 8 + (lane >> 3), m2 = m0 + r2;
@@ -759,7 +803,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             }
         }
         // ---- results: pixel m, channels 32 ni + 8 g + 4 lh + (0..3)
-        if constexpr (EPI) {
+        {
             // Through LDS, so that rows leave (and the mask arrives) as whole 128-byte lines: written straight from the
             // accumulators every 128-byte line is touched by 8 different 16-byte requests (and as many for the mask).  The
             // staging area is this wave's 32 rows of the activation buffer the last unit has just consumed; 16-byte chunk c
@@ -800,33 +844,353 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                 }
                 if (r2 < BMV && m2 < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m2 * 64 + ch * 8) = v;
             }
-        } else
-        if (rr < BMV && m < p.M) {
+        }
+    }
+}
+
+// =================================================================================
+// Round 5: the forward kernels with the 2x2 stride-2 max-pool FUSED into their epilogue (conv.h conv_fwd_pool_bf16).
+// pool1-3 are pure HBM traffic between two convolutions: the producer writes its output, the pool reads it back to write a
+// quarter of it -- and nothing else ever reads the unpooled tensor, not even backward (the pool's record carries the argmax
+// and the relu sign).  Pooling in the producer's epilogue needs whole 2x2 windows in one tile, i.e. tiles of IMAGE ROWS
+// instead of the raster runs of the kernels above:
+//   the 256-row activation tile of a kernel row is [R image rows][CW slots] (R x CW = 256), slot cc of row j = input pixel
+//   (oh0 + j + kh - 1, c0 - 1 + cc): TW = up to CW - 2 output columns plus a one-column halo either side, every slot's zero
+//   padding decided by the DMA (a slot outside the image is an out-of-range offset), so there is no tap mask and no empty row.
+//   GEMM row m = j * CW + c is output pixel (oh0 + j, c0 + c) and reads tile row m + kw under tap kw -- exactly the
+//   fragment addressing of the raster kernels, the compute loops are theirs unchanged.  Rows with c >= TW are dead
+//   (R x TW of 256 rows do work: 93.75 % for conv1_2 at 300 / conv2_2 at 150; the executor fuses where >= 88 % do).
+// Epilogue: bias + relu + ONE rounding to bf16, then the window's first maximum in scan order over the cells inside the
+// image (ops.hip maxpool2x2_fwd_rec_kernel: bit-identical results and records), pooled rows leave as 16-byte pieces of
+// whole 128-byte lines.
+// =================================================================================
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }      // the value the unfused path stores and re-reads
+__device__ __forceinline__ void lds_barrier() {      // LDS hand-off between waves WITHOUT draining the DMA in flight (vmcnt untouched)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// one pooled pixel x 8 channels: cells v[q][e] (already rounded to bf16 values), validity ok[q] (cell 0 always inside)
+__device__ __forceinline__ void pool_window8(const float (&v)[4][8], const bool (&ok)[4], u32x4& out, unsigned& rec) {
+    float m[8];
+    unsigned r[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        unsigned a = 0;
+        float mm = v[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (ok[q] && v[q][e] > mm) { mm = v[q][e]; a = q; }      // strict: the first maximum wins
+        m[e] = mm;
+        r[e / 4] |= (a | (mm > 0.f ? 4u : 0u)) << (3 * (e & 3));
+    }
+    out = u32x4{pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7])};
+    rec = r[0] | (r[1] << 16);
+}
+
+// ---- kernel-row gather, 256-row tiles as [8 image rows][32 slots] (TW <= 30), 128 output channels per workgroup ----------
+__global__ __launch_bounds__(256) void conv_fwd_pool_bf16_rows_kernel(GatherArgsH p) {
+    constexpr int TM = 4, TN = 2, WN = 2, BN = 128, AROWS = 256, A_N = 8, B_N = 4, CW = 32, R = 8;
+    constexpr int A_BYTES = AROWS * 128, LDC = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = wg / p.NT, nt = wg - mt * p.NT;
+    const int sg = mt % p.NSEG, t2 = mt / p.NSEG;
+    const int rb = t2 % p.NBAND, b = t2 / p.NBAND;
+    const int oh0 = rb * R, c0 = sg * p.TW, n0 = nt * BN;
+    const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+
+    const int total = p.PB * p.SH * p.SW;
+    const int bias_px = 1 + p.SW;                        // the first tile's halo reaches one row and one column before the tensor
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.src) - (size_t)bias_px * p.SC, 0, (unsigned)(((size_t)total + bias_px) * p.SC * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.wgt), 0, (unsigned)((size_t)9 * p.DN * p.SC * 2u), 0x00020000);
+    // staging: DMA piece i of a thread fills tile row 32 i + (tid >> 3) = (image row i, slot tid >> 3): the slot -- and with it
+    // the column's validity -- is a per-thread constant, the row's a per-piece scalar
+    const int cc = tid >> 3;
+    const bool colok = cc < p.TW + 2 && (unsigned)(c0 - 1 + cc) < (unsigned)p.SW;
+    unsigned a_vo[A_N], b_vo[B_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) a_vo[i] = colok ? (unsigned)(((i * p.SW + cc) * p.SC + a_ck) * 2) : OOBH;
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        b_vo[i] = n < p.DN ? (unsigned)((n * p.SC + a_ck) * 2) : OOBH;
+    }
+    const int nunits = (p.SC / HBK) * 3;
+
+    auto issue = [&](int unit) {
+        const int cch = unit / 3, kr = unit - cch * 3;
+        unsigned char* As = smem + wave * 1024;
+        unsigned char* Bs = smem + A_BYTES + wave * 1024;
+        const int row0 = oh0 + kr - 1;                   // image row of tile row block 0 under this kernel row
+        const int a_so = (int)(((unsigned)((b * p.SH + row0) * p.SW + c0 - 1 + bias_px) * (unsigned)p.SC + (unsigned)(cch * HBK)) * 2u);
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const unsigned vo = (unsigned)(row0 + i) < (unsigned)p.SH ? a_vo[i] : OOBH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 4096), 16, (int)vo, a_so, 0, 0);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const int b_so = (int)(((unsigned)((kr * 3 + kc) * p.DN) * (unsigned)p.SC + (unsigned)(cch * HBK)) * 2u);
+#pragma unroll
+            for (int i = 0; i < B_N; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(Bs + kc * (BN * 128) + i * 4096), 16, (int)b_vo[i], b_so, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int bb = 0; bb < TN; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    int a_addr[3][TM];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int Rr = wm * 32 * TM + mi * 32 + li + kc;      // GEMM row m reads tile row m + kw (dead rows run into the next block / the filter tile: discarded)
+            a_addr[kc][mi] = Rr * 128 + ((lh ^ ((Rr >> 1) & 7)) * 16);
+        }
+    const int q0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int b_row = A_BYTES + (wn * 32 * TN + li) * 128 + q0;
+
+    for (int unit = 0; unit < nunits; ++unit) {
+        __syncthreads();                                  // every wave is done with the previous unit's tiles
+        issue(unit);
+        wait_tiles_and_sync<1>(0);
+        constexpr int PF = GATHER_PF, KS = 3 * (HBK / 16);
+        bf16x8 a[PF][TM], bfr[PF][TN];
+        auto frags = [&](int ks) {
+            const int kc = ks >> 2, st = ks & 3;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[ks % PF][mi] = *reinterpret_cast<const bf16x8*>(smem + (a_addr[kc][mi] ^ (st * 32)));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                bfr[ks % PF][ni] = *reinterpret_cast<const bf16x8*>(smem + kc * (BN * 128) + ((b_row + ni * 4096) ^ (st * 32)));
+        };
+#pragma unroll
+        for (int ks = 0; ks < PF - 1; ++ks) frags(ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF - 1 < KS) frags(ks + PF - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks % PF][ni], a[ks % PF][mi], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue through an fp32 C tile [128][132], half of every wave's rows at a time.  Half h of wave row block wm holds
+    // tile rows wm 128 + h 64 + x = image rows j = 4 wm + 2 h + (x >> 5), columns x & 31: one complete ROW PAIR per (wm, h).
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int cg = tid & 15, n = n0 + cg * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n < p.DN) ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ml = wm * 64 + mi * 32 + li;
+                    const int nl = wn * 32 * TN + ni * 32 + 8 * g + 4 * lh;
+                    const f32x16& c = acc[2 * h + mi][ni];
+                    *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + 256 * it;              // (wave row block, window, channel group)
+            const int wq = (item >> 4) & 15, wmr = item >> 8;
+            const int oh = oh0 + 4 * wmr + 2 * h, ow = c0 + 2 * wq;
+            if (!(2 * wq < p.TW && ow < p.DW && oh < p.DH && n < p.DN)) continue;
+            const bool ok[4] = {true, ow + 1 < p.DW, oh + 1 < p.DH, ow + 1 < p.DW && oh + 1 < p.DH};
+            float v[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* cr = Cs + (wmr * 64 + (q >> 1) * 32 + 2 * wq + (q & 1)) * LDC + cg * 8;
+                const f32x4 c0v = *reinterpret_cast<const f32x4*>(cr), c1v = *reinterpret_cast<const f32x4*>(cr + 4);
+                const float t[8] = {c0v[0], c0v[1], c0v[2], c0v[3], c1v[0], c1v[1], c1v[2], c1v[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = t[e] + bv[e];
+                    v[q][e] = rbf(x > 0.f ? x : 0.f);
+                }
+            }
+            u32x4 out;
+            unsigned rec;
+            pool_window8(v, ok, out, rec);
+            const size_t pix = ((size_t)b * p.PH + (oh >> 1)) * p.PW + (ow >> 1);
+            *reinterpret_cast<u32x4*>(p.pool_dst + pix * p.DN + n) = out;
+            if (p.pool_rec) *reinterpret_cast<unsigned*>(p.pool_rec + pix * (p.DN >> 2) + (n >> 2)) = rec;
+        }
+    }
+}
+
+// ---- 64 -> 64 channels, persistent, filter resident (conv_gather_bf16_c64_kernel): tiles as [4 image rows][64 slots] (TW <= 62) --
+__global__ __launch_bounds__(512) void conv_fwd_pool_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks) {
+    constexpr int AROWS = 256, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP, R = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+
+    const int total = p.PB * p.SH * p.SW;
+    const int bias_px = 1 + p.SW;
+    const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.src) - (size_t)bias_px * 64, 0, (unsigned)(((size_t)total + bias_px) * 64 * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.wgt), 0, (unsigned)(9u * 64u * 64u * 2u), 0x00020000);
+    {
+        const unsigned vo = (unsigned)(((tid >> 3) * 64 + a_ck) * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rsrc, LDS_PTR(smem + t * B_TAP + wave * 1024), 16, (int)vo, t * (64 * 64 * 2), 0, 0);
+    }
+    // staging: DMA piece i of a thread fills tile row 64 i + (tid >> 3) = (image row i, slot tid >> 3)
+    const int cc = tid >> 3;
+    const bool cc_in = cc < p.TW + 2;
+    unsigned a_vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_vo[i] = (unsigned)(((i * p.SW + cc) * 64 + a_ck) * 2);
+    struct Tile { int b, oh0, c0; };
+    auto decode = [&](int tile) {
+        Tile t;
+        const int sg = tile % p.NSEG, t2 = tile / p.NSEG;
+        t.c0 = sg * p.TW; t.oh0 = (t2 % p.NBAND) * R; t.b = t2 / p.NBAND;
+        return t;
+    };
+    auto issue = [&](const Tile& t, int kr, int buf) {
+        unsigned char* As = smem + A_BASE + buf * A_BYTES + wave * 1024;
+        const int row0 = t.oh0 + kr - 1;
+        const bool colok = cc_in && (unsigned)(t.c0 - 1 + cc) < (unsigned)p.SW;
+        const int a_so = (int)((unsigned)((t.b * p.SH + row0) * p.SW + t.c0 - 1 + bias_px) * 128u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vo = (colok && (unsigned)(row0 + i) < (unsigned)p.SH) ? a_vo[i] : OOBH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, LDS_PTR(As + i * 8192), 16, (int)vo, a_so, 0, 0);
+        }
+    };
+
+    int a_addr[3], b_addr[2];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+        const int Rr = wave * 32 + li + kc;               // GEMM row m reads tile row m + kw
+        a_addr[kc] = Rr * 128 + ((lh ^ ((Rr >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int nn = ni * 32 + li;
+        b_addr[ni] = nn * 128 + ((lh ^ ((nn >> 1) & 7)) * 16);
+    }
+    float bv[2][4][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[ni][g][e] = p.bias ? p.bias[ni * 32 + 8 * g + 4 * lh + e] : 0.f;
+
+    int tile = blockIdx.x, tstep = gridDim.x, tend = ntiles, gunit = 0;
+    if (xcd_chunks) {      // the tile range in 8 contiguous chunks, one per XCD: neighbouring bands (shared halo rows) meet in one L2
+        const int chunk = (ntiles + 7) >> 3, x = blockIdx.x & 7;
+        tile = x * chunk + (blockIdx.x >> 3);
+        tstep = gridDim.x >> 3;
+        tend = min(ntiles, (x + 1) * chunk);
+    }
+    Tile cur = decode(tile < tend ? tile : 0), nxt = cur;
+    if (tile < tend) issue(cur, 0, 0);
+    for (; tile < tend; tile += tstep, cur = nxt) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#pragma unroll
+        for (int kr = 0; kr < 3; ++kr, ++gunit) {
+            wait_tiles_and_sync<1>(0);                    // this unit's tile (and, the first time, the filter) has landed
+            if (kr < 2) issue(cur, kr + 1, (gunit + 1) & 1);
+            else if (tile + tstep < tend) {
+                nxt = decode(tile + tstep);
+                issue(nxt, 0, (gunit + 1) & 1);
+            }
+            const unsigned char* A = smem + A_BASE + (gunit & 1) * A_BYTES;
+            bf16x8 a[2], bfr[2][2];
+            auto frags = [&](int ks) {                   // k-step ks: tap column ks >> 2, 16-channel slice ks & 3
+                const int kc = ks >> 2, st = ks & 3;
+                a[ks & 1] = *reinterpret_cast<const bf16x8*>(A + (a_addr[kc] ^ (st * 32)));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    bfr[ks & 1][ni] = *reinterpret_cast<const bf16x8*>(smem + (kr * 3 + kc) * B_TAP + (b_addr[ni] ^ (st * 32)));
+            };
+            frags(0);
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                if (ks + 1 < 12) frags(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][ni], a[ks & 1], acc[ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- results: the whole tile (bias + relu, rounded to bf16) parked in the activation buffer the last unit has just
+        // consumed -- row = tile row, 16-byte chunk c at chunk c ^ sw(row & 31) --, then one pooled pixel x 8 channels per thread
+        lds_barrier();                                    // every wave has read its fragments of that buffer
+        unsigned char* S = smem + A_BASE + ((gunit - 1) & 1) * A_BYTES;
+        {
+            const int swl = (li ^ (li >> 3)) & 7;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4] = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
-                    const size_t o = (size_t)m * 64 + ni * 32 + 8 * g + 4 * lh;
-                    if constexpr (MODE == MODE_FWD) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] += bv[ni][g][e];
-                            if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                        }
-                    } else {
-                        if (p.accum) {
-                            const u32x2 old = pre_old[ni][g];
-                            v[0] += lo2f(old[0]); v[1] += hi2f(old[0]); v[2] += lo2f(old[1]); v[3] += hi2f(old[1]);
-                        }
-                        if (p.mask) {
-                            const u32x2 y = pre_mask[ni][g];
-                            v[0] = lo2f(y[0]) > 0.f ? v[0] : 0.f; v[1] = hi2f(y[0]) > 0.f ? v[1] : 0.f;
-                            v[2] = lo2f(y[1]) > 0.f ? v[2] : 0.f; v[3] = hi2f(y[1]) > 0.f ? v[3] : 0.f;
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += bv[ni][g][e];
+                        v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.dst) + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(S + (wave * 32 + li) * 128 + (((4 * ni + g) ^ swl) * 16) + lh * 8) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
                 }
+        }
+        lds_barrier();
+        {
+            const int ch = tid & 7, wq = (tid >> 3) & 31, pr = tid >> 8;      // channel chunk, window, pooled row of the tile
+            const int oh = cur.oh0 + 2 * pr, ow = cur.c0 + 2 * wq;
+            if (2 * wq < p.TW && ow < p.DW && oh < p.DH) {
+                const bool ok[4] = {true, ow + 1 < p.DW, oh + 1 < p.DH, ow + 1 < p.DW && oh + 1 < p.DH};
+                float v[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = (2 * pr + (q >> 1)) * 64 + 2 * wq + (q & 1), rl = row & 31;
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(S + row * 128 + ((ch ^ ((rl ^ (rl >> 3)) & 7)) * 16));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[q][2 * e] = lo2f(w[e]); v[q][2 * e + 1] = hi2f(w[e]); }
+                }
+                u32x4 out;
+                unsigned rec;
+                pool_window8(v, ok, out, rec);
+                const size_t pix = ((size_t)cur.b * p.PH + (oh >> 1)) * p.PW + (ow >> 1);
+                *reinterpret_cast<u32x4*>(p.pool_dst + pix * 64 + ch * 8) = out;
+                if (p.pool_rec) *reinterpret_cast<unsigned*>(p.pool_rec + pix * 16 + ch * 2) = rec;
+            }
         }
     }
 }
@@ -1274,7 +1638,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_rows_kernel(WgradRowsArgs
 
     // NS = 2 (default): one tile in flight while one is multiplied -- a stage is 12..24 MFMAs per wave (400..800 cycles)
     // against a DMA round trip of 1300..2500, so a workgroup idles most of the time and the CU's other resident
-    // workgroups fill in.  NS = 3 / 4 (SSD_WGRAD_ROWS_NS): a ring with two / three tiles in flight per workgroup -- measured
+    // workgroups fill in.  NS = 3 / 4 (a switch until round 5): a ring with two / three tiles in flight per workgroup -- measured
     // SLOWER (profiles/r03_o_rows_wgrad_ring_sweep_bf16.txt: conv1_2 0.374 -> 0.42..0.46 -> 0.52 ms, conv2_1 0.206 -> 0.208 ->
     // 0.283): the deeper ring costs resident workgroups (4 -> 3 -> 2 per CU), and four independent two-stage pipelines hide
     // more than two four-stage ones -- the same answer the gather kernels gave in round 1.
@@ -1336,7 +1700,6 @@ struct WgradColArgs {
     int B, H, W, Ci, Co;
     int NT;                 // output-channel tiles of 64
     int nstrips, rpu, RC;   // 64-column strips per image row, image rows per unit, units per (image, strip)
-    int ablate;             // measurement aid (SSD_WGRAD_COL_ABLATE): 1 no multiply, 2 no staging after the first tiles -- WRONG results
 };
 
 // (two waves per SIMD = two workgroups per CU: left alone the scheduler hoists all 36 fragment reads of a step -- 316 registers)
@@ -1484,8 +1847,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (y + 2 < r1 && !(p.ablate & 2)) { issue_x(y + 3); issue_y(y + 2); }
-        if (!(p.ablate & 1)) compute(y);
+        if (y + 2 < r1) { issue_x(y + 3); issue_y(y + 2); }
+        compute(y);
     }
 
     const size_t wcount = (size_t)9 * p.Ci * p.Co;
@@ -1856,11 +2219,10 @@ static int pick_tile_h(long long M, int N, int mode, int nk = 0) {
     // conv8_1 ... conv11_2 and the small maps' heads: matrix-pipe duty 0.17); the same tile with 3 / 4 pipeline stages
     // keeps two or three tiles in flight -- LDS is no constraint when a CU holds a single workgroup.  Measured on one
     // box, two interleaved repetitions (profiles/r03_a_ab_small_deep_bf16.txt): step 7.591 / 7.561 -> 7.499 / 7.512 ms
-    // (+0.9 %); up to two workgroups per CU (value 2): 7.580 / 7.600, no gain.  SSD_SMALL_DEEP=0 switches it off.
-    static const int small_deep = env_int("SSD_SMALL_DEEP", 1);
-    if (small_deep) {
+    // (+0.9 %); up to two workgroups per CU: 7.580 / 7.600, no gain.
+    {
         const long long wgs = (long long)cdiv(M, bm[best]) * cdiv(N, bn[best]);
-        if (wgs <= 256 * small_deep) {
+        if (wgs <= 256) {
             if (best == 0) best = 4;           // 128x128 x4
             else if (best == 1) best = 5;      // 128x64 x3
             // Round 4: such a launch's time IS its serial k loop (conv9_2: 18 iterations, the 10x10 map's head: 72) at
@@ -1881,7 +2243,7 @@ static int pick_tile_h(long long M, int N, int mode, int nk = 0) {
 }
 
 template <int MODE>
-static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hipStream_t s) {
+static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hipStream_t s, bool unpool = false) {
     static const char* const names[2][NCFG_H] = {
         {"conv_fwd_bf16_128x128", "conv_fwd_bf16_128x64", "conv_fwd_bf16_64x128", "conv_fwd_bf16_256x128x3", "conv_fwd_bf16_128x128x4",
          "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w", "conv_fwd_bf16_64x64x6",
@@ -1889,7 +2251,11 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
         {"conv_dgrad_bf16_128x128", "conv_dgrad_bf16_128x64", "conv_dgrad_bf16_64x128", "conv_dgrad_bf16_256x128x3",
          "conv_dgrad_bf16_128x128x4", "conv_dgrad_bf16_128x64x3", "conv_dgrad_bf16_256x128x3_8w", "conv_dgrad_bf16_256x128x2_8w",
          "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6", "conv_dgrad_bf16_64x64_k4"}};
-    const char* label = names[MODE][cfg];
+    static const char* const unpool_names[NCFG_H] = {
+        "conv_dgrad_unpool_bf16_128x128", "conv_dgrad_unpool_bf16_128x64", "conv_dgrad_unpool_bf16_64x128", "conv_dgrad_unpool_bf16_256x128x3",
+        "conv_dgrad_unpool_bf16_128x128x4", "conv_dgrad_unpool_bf16_128x64x3", "conv_dgrad_unpool_bf16_256x128x3_8w", "conv_dgrad_unpool_bf16_256x128x2_8w",
+        "conv_dgrad_unpool_bf16_256x64_8w", "conv_dgrad_unpool_bf16_64x64x6", "conv_dgrad_unpool_bf16_64x64_k4"};
+    const char* label = unpool ? unpool_names[cfg] : names[MODE][cfg];
     switch (cfg) {
     case 0: launch_gather_h<MODE, 2, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
     case 1: launch_gather_h<MODE, 4, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
@@ -1927,22 +2293,15 @@ static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, d
     // (Measured and not kept, gpurun r02_s: a 7-wave variant with THREE 28-KB activation buffers, two units in flight.
     // Same time to +-2 % -- the kernel is not waiting for its DMA; like the other bf16 gather kernels its time moves with
     // the DATA: 0.33 ms on random operands, 0.25 ms on the step's post-relu activations, i.e. with power and clock.)
-    static const int xcd_on = env_int("SSD_C64_XCD", 1);      // A/B switch: XCD-contiguous tile chunks (forward +2..7 %, step +0.3 %)
+    // (XCD-contiguous tile chunks: forward +2..7 %, step +0.3 %, profiles/r02_r; results leave through LDS as whole 128-byte
+    // rows: +0.9 % on the step, profiles/r02_ai -- both were A/B switches until round 5)
     constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128;
-    static const int epi = env_int("SSD_C64_EPI", 1);         // A/B switch: results leave through LDS as whole 128-byte rows
     const int ntiles = cdiv(a.M, 253);
     ProfScope prof(label, flops, bytes, s);
-    if (epi) {
-        auto kern = conv_gather_bf16_c64_kernel<MODE, true>;
-        static bool once = (set_lds(kern, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
-    } else {
-        auto kern = conv_gather_bf16_c64_kernel<MODE, false>;
-        static bool once = (set_lds(kern, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, (xcd_on && ntiles >= 2048) ? 1 : 0);
-    }
+    auto kern = conv_gather_bf16_c64_kernel<MODE>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0);
     HIP_OK(hipGetLastError());
 }
 
@@ -1967,17 +2326,14 @@ static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, doubl
 // tile draws more power and the chip clocks down: conv5_2 forward 996 TFLOP/s at 2.22 GHz on 128 x 128 tiles against 949 TFLOP/s
 // at 1.89 GHz on 128 x 64 (tools/power_probe.py conv5_2, profiles/r04_ae_power_clock_19x19_bf16.txt).  Idle CUs are not waste under
 // a power limit; the staged bytes per MFMA are.  SSD_GATHER_ROWS_N64_BF16: 0 off, 1 by the padded-columns rule (default), 2
-// everywhere (tests), 3 round 4's first rule (also by slot fill; the lanes' launches counted together: g_conv_lanes).
+// everywhere (tests).
 thread_local int g_conv_lanes = 1;
 static bool gather_rows_n64(int M, int N) {
     static const int on = env_int("SSD_GATHER_ROWS_N64_BF16", 1);
     if (on == 0 || on == 2) return on == 2;
     const double waste128 = (double)N / (cdiv(N, 128) * 128), waste64 = (double)N / (cdiv(N, 64) * 64);      // useful columns
-    if (on == 1) return waste64 > waste128 * 1.1;
-    M *= g_conv_lanes;
-    auto fill = [](long long wgs, long long slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
-    const double f128 = fill((long long)cdiv(M, 128) * cdiv(N, 128), 512), f64 = fill((long long)cdiv(M, 128) * cdiv(N, 64), 768);
-    return f64 * waste64 * 0.9 > f128 * waste128;
+    (void)M;
+    return waste64 > waste128 * 1.1;
 }
 // 256-row tiles where they fill the chip's 512 workgroup slots often enough; dil = 1 only (the tile owns 256 - 2 dil rows).
 // Round 4: the count is taken over the launches that run side by side (the forward lanes: g_conv_lanes) and the bar is 700
@@ -2016,7 +2372,7 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
     // head of the 10x10 map 45 -> 36 us, gpurun r02_b heads_tiles_bf16)
     // A/B switch: the fp32-out layers (multibox heads) below this many pixels take the per-tap kernel; 4096 keeps the
     // 19x19 map's head (M = 11552, N = 152: 182 kernel-row workgroups, 281 TFLOP/s) on the kernel-row gather
-    static const int heads_rows_min_m = env_int("SSD_HEADS_ROWS_MIN_M", 4096);
+    constexpr int heads_rows_min_m = 4096;
     if (gather_rows_applicable(d, false) && d.Co >= 128 && !(y_f32 && a.M < heads_rows_min_m)) {
         if (gather_rows256(d, a.M, d.Co)) launch_gather_rows<MODE_FWD, 4>(a, d.dil, "conv_fwd_bf16_rows_256x128", fl, by, s);
         else if (gather_rows_n64(a.M, d.Co)) launch_gather_rows<MODE_FWD, 2, 1>(a, d.dil, "conv_fwd_bf16_rows_128x64", fl, by, s);
@@ -2026,11 +2382,14 @@ void conv_fwd_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const
     launch_gather_cfg<MODE_FWD>(pick_tile_h(a.M, a.DN, MODE_FWD, cdiv(a.SC, HBK) * a.ntaps), a, fl, by, s);
 }
 
-void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
-                     hipStream_t s) {
+static void conv_dgrad_bf16_any(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
+                                hipStream_t s, const void* unpool_rec, int UH, int UW) {
     check_desc_h(d);
+    const bool unpool = unpool_rec != nullptr;
+    SSD_REQUIRE(!unpool || d.stride == 1, "conv_dgrad_bf16: the fused un-pool is for stride-1 convolutions");
     GatherArgsH a{};
     a.src = dy; a.wgt = w_io; a.bias = nullptr; a.mask = mask; a.dst = dx;
+    a.unpool_rec = static_cast<const unsigned short*>(unpool_rec); a.UH = UH; a.UW = UW;
     a.M = d.B * d.Hi * d.Wi; a.DH = d.Hi; a.DW = d.Wi; a.DN = d.Ci;
     a.SH = d.Ho; a.SW = d.Wo; a.SC = d.Co;
     a.ntaps = d.KH * d.KW; a.mul = 1; a.div = d.stride;
@@ -2085,17 +2444,87 @@ void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf
         launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, true, 2>(a, "conv_dgrad_bf16_strided_128x128", fl, by, s);
         return;
     }
-    if (gather_c64_applicable(d, false)) {
+    if (!unpool && gather_c64_applicable(d, false)) {      // (the persistent 64 -> 64 kernel has its own write-out: no un-pool there)
         launch_gather_c64<MODE_DGRAD>(a, "conv_dgrad_bf16_c64", fl, by, s);
         return;
     }
     if (gather_rows_applicable(d, true) && d.Ci >= 128) {
-        if (gather_rows256(d, a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 4>(a, d.dil, "conv_dgrad_bf16_rows_256x128", fl, by, s);
-        else if (gather_rows_n64(a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 2, 1>(a, d.dil, "conv_dgrad_bf16_rows_128x64", fl, by, s);
-        else launch_gather_rows<MODE_DGRAD, 2>(a, d.dil, "conv_dgrad_bf16_rows_128x128", fl, by, s);
+        if (gather_rows256(d, a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 4>(a, d.dil, unpool ? "conv_dgrad_unpool_bf16_rows_256x128" : "conv_dgrad_bf16_rows_256x128", fl, by, s);
+        else if (gather_rows_n64(a.M, d.Ci)) launch_gather_rows<MODE_DGRAD, 2, 1>(a, d.dil, unpool ? "conv_dgrad_unpool_bf16_rows_128x64" : "conv_dgrad_bf16_rows_128x64", fl, by, s);
+        else launch_gather_rows<MODE_DGRAD, 2>(a, d.dil, unpool ? "conv_dgrad_unpool_bf16_rows_128x128" : "conv_dgrad_bf16_rows_128x128", fl, by, s);
         return;
     }
-    launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD, cdiv(a.SC, HBK) * a.ntaps), a, fl, by, s);
+    launch_gather_cfg<MODE_DGRAD>(pick_tile_h(a.M, a.DN, MODE_DGRAD, cdiv(a.SC, HBK) * a.ntaps), a, fl, by, s, unpool);
+}
+
+void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
+                     hipStream_t s) {
+    conv_dgrad_bf16_any(d, dy, w_io, dx, mask, accumulate, s, nullptr, 0, 0);
+}
+
+bool conv_dgrad_unpool_bf16_supported(const ConvDesc& d) { return d.stride == 1 && d.Ci % 8 == 0 && d.Co % 8 == 0; }
+void conv_dgrad_unpool_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx_unpooled, const void* rec, int UH, int UW,
+                            hipStream_t s) {
+    SSD_REQUIRE(conv_dgrad_unpool_bf16_supported(d), "conv_dgrad_unpool_bf16: unsupported shape");
+    SSD_REQUIRE(rec != nullptr && (UH + 1) / 2 == d.Hi && (UW + 1) / 2 == d.Wi, "conv_dgrad_unpool_bf16: record / pooled size mismatch");
+    conv_dgrad_bf16_any(d, dy, w_io, dx_unpooled, nullptr, false, s, rec, UH, UW);
+}
+
+// ---- forward with the fused 2x2 pool (conv_fwd_pool_bf16_*_kernel) ------------------------------------------------------
+struct PoolTiling { int cw, rows, tw, nseg, nband; double util; };
+static PoolTiling pool_tiling(const ConvDesc& d, int cw) {      // cw = 64: [4][64] tiles (64 -> 64 kernel), 32: [8][32] (kernel-row gather)
+    PoolTiling t{};
+    t.cw = cw; t.rows = 256 / cw;
+    const int twmax = cw - 2;
+    t.nseg = cdiv(d.Wo, twmax);
+    t.tw = (cdiv(d.Wo, t.nseg) + 1) & ~1;                        // even: a window never straddles two segments
+    t.nband = cdiv(d.Ho, t.rows);
+    t.util = (double)d.Ho * d.Wo / ((double)t.nseg * t.nband * 256.0);
+    return t;
+}
+static bool pool_fwd_shape_bf16(const ConvDesc& d) {
+    const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo;
+    return shape && d.Ci % 64 == 0 && d.Co % 8 == 0 && ((d.Ci == 64 && d.Co == 64) || d.Co >= 128);
+}
+// the executor's rule: fuse where at least 88 % of the 2-D tile rows carry pixels (conv1_2 / conv2_2 of both presets; conv3_3's
+// 75- / 128-wide rows fill [8][32] tiles to 73 / 80 %: a matrix-bound layer loses more there than the pool costs)
+bool conv_fwd_pool_bf16_supported(const ConvDesc& d) {
+    return pool_fwd_shape_bf16(d) && pool_tiling(d, (d.Ci == 64 && d.Co == 64) ? 64 : 32).util >= 0.88;
+}
+void conv_fwd_pool_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, const float* bias, bf16_t* y_pool, void* rec, hipStream_t s) {
+    check_desc_h(d);
+    SSD_REQUIRE(pool_fwd_shape_bf16(d), "conv_fwd_pool_bf16: 3x3 stride-1 SAME, Ci a multiple of 64, 64 -> 64 or Co >= 128");
+    SSD_REQUIRE(y_pool != nullptr, "conv_fwd_pool_bf16: null output");
+    const bool c64 = d.Ci == 64 && d.Co == 64;
+    const PoolTiling t = pool_tiling(d, c64 ? 64 : 32);
+    GatherArgsH a{};
+    a.src = x; a.wgt = w_oi; a.bias = bias; a.dst = nullptr;
+    a.M = d.B * d.Ho * d.Wo; a.DH = d.Ho; a.DW = d.Wo; a.DN = d.Co;
+    a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
+    a.ntaps = 9; a.mul = 1; a.div = 1; a.relu = 1;
+    a.pool_dst = y_pool; a.pool_rec = static_cast<unsigned short*>(rec);
+    a.PB = d.B; a.PH = (d.Ho + 1) / 2; a.PW = (d.Wo + 1) / 2;
+    a.TW = t.tw; a.NSEG = t.nseg; a.NBAND = t.nband;
+    const int ntiles = d.B * t.nseg * t.nband;
+    const double fl = conv_flops(d), by = 2.0 * ((double)d.B * d.Hi * d.Wi * d.Ci + (double)d.B * a.PH * a.PW * d.Co * 1.25 + 9.0 * d.Ci * d.Co);
+    if (c64) {
+        constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128 + 512;      // (+ the two rows a dead GEMM row's last tap reads past the tile)
+        auto kern = conv_fwd_pool_bf16_c64_kernel;
+        static bool once = (set_lds(kern, lds), true);
+        (void)once;
+        ProfScope prof("conv_fwd_pool_bf16_c64", fl, by, s);
+        hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0);
+        HIP_OK(hipGetLastError());
+        return;
+    }
+    constexpr size_t lds = 256 * 128 + 3 * 128 * 128;      // one unit; the fp32 C tile of the epilogue ([128][132]) fits inside
+    auto kern = conv_fwd_pool_bf16_rows_kernel;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    a.NT = cdiv(d.Co, 128);
+    ProfScope prof("conv_fwd_pool_bf16_rows_256x128", fl, by, s);
+    hipLaunchKernelGGL(kern, dim3(ntiles * a.NT), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
 }
 
 // ---- wgrad planning -------------------------------------------------------------------
@@ -2120,7 +2549,7 @@ static WgradPlanH plan_wgrad_h(const ConvDesc& d) {
     p.CT = cdiv(d.Ci, p.bkt);
     p.NT = cdiv(d.Co, p.bnt);
     p.tiles = d.KH * d.KW * p.CT * p.NT;
-    static const int target_wgs = env_int("SSD_WGRAD_WGS_BF16", 1536);      // tuning override
+    constexpr int target_wgs = 1536;
     int want = cdiv(target_wgs, p.tiles);
     if (want > 256) want = 256;          // the reduce pass reads every slab: keep it short
     int maxs = cdiv(M, 512);
@@ -2169,7 +2598,7 @@ static RowsPlan plan_rows(const ConvDesc& d) {
     // tuning override.  Re-measured on the round-2 kernels incl. the slab reduce (gpurun r02_m): conv1_2 0.515 / 0.424 / 0.374 /
     // 0.383 / 0.399 / 0.381 ms and conv2_1 0.207 / 0.203 / 0.202 / 0.217 / 0.240 / 0.247 ms at 512 / 768 / 1024 / 1536 / 2048 /
     // 3072 workgroups (beyond ~1024 the slabs' write + reduce traffic outgrows the layer's own); step 1024 vs 2048: +0.4 %
-    static const int target = env_int("SSD_WGRAD_ROWS_WGS_BF16", 1024);
+    constexpr int target = 1024;
     int want = cdiv(target, 3 * p.CT * p.NT);
     if (want > 1024) want = 1024;
     const int maxs = cdiv(p.nslots, 64 * 16);
@@ -2200,7 +2629,7 @@ static RowsPlan plan_rows8(const ConvDesc& d) {
     // SSD_WGRAD_ROWS8_WGS: workgroup target (A/B switch).  256 = one per CU.  Fewer = fewer pixel splits = proportionally less
     // fp32 slab traffic (every workgroup leaves 196 KB), at the price of CUs the launch does not use -- which, in the step, the
     // data gradient on the other stream does.
-    static const int wgs_target = env_int("SSD_WGRAD_ROWS8_WGS", 256);
+    constexpr int wgs_target = 256;      // (192 ties, 128 loses 9 %: profiles/r04_t_ab_rows8_wgs_bf16.txt)
     int want = jobs >= wgs_target ? 1 : wgs_target / jobs;
     const int maxs = (int)std::max<long long>(1, p.nslots / (64 * 8));
     p.nsplit = want > maxs ? maxs : want;
@@ -2231,10 +2660,7 @@ static void launch_wgrad_rows_ns(WgradRowsArgs& a, const char* label, double flo
 }
 template <int TM, int TN>
 static void launch_wgrad_rows(WgradRowsArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
-    static const int ns = env_int("SSD_WGRAD_ROWS_NS", 2);      // A/B switch: ring depth of the 4-wave kernel-row weight gradient
-    if (ns == 3) launch_wgrad_rows_ns<TM, TN, 3>(a, label, flops, bytes, s);
-    else if (ns >= 4) launch_wgrad_rows_ns<TM, TN, 4>(a, label, flops, bytes, s);
-    else launch_wgrad_rows_ns<TM, TN, 2>(a, label, flops, bytes, s);
+    launch_wgrad_rows_ns<TM, TN, 2>(a, label, flops, bytes, s);      // (rings of 3 / 4 stages measured slower: see the kernel)
 }
 
 // ---- column-walk variant (3x3, stride 1, SAME, <= 64 input channels): SSD_WGRAD_COL_BF16 = 0 off, 1 on (default), 2 also small
@@ -2259,7 +2685,7 @@ static ColPlan plan_col(const ConvDesc& d) {
     p.nstrips = cdiv(d.Wo, 64);
     // two workgroups per CU (nine accumulator tiles per wave: ~220 registers) = 512 slots; a unit of fewer than 8 rows would
     // spend more than a quarter of its loads on the two halo rows
-    static const int target = env_int("SSD_WGRAD_COL_WGS_BF16", 512);
+    constexpr int target = 512;
     const int per_row_chunk = d.B * p.nstrips * p.NT;
     int rc = target / (per_row_chunk > 0 ? per_row_chunk : 1);
     if (rc < 1) rc = 1;
@@ -2289,8 +2715,6 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
         c.x = x; c.dy = dy; c.ws = ws;
         c.B = d.B; c.H = d.Ho; c.W = d.Wo; c.Ci = d.Ci; c.Co = d.Co;
         c.NT = cp.NT; c.nstrips = cp.nstrips; c.rpu = cp.rpu; c.RC = cp.RC;
-        static const int ablate = env_int("SSD_WGRAD_COL_ABLATE", 0);
-        c.ablate = ablate;
         constexpr size_t lds = 5 * 72 * 128 + 3 * 64 * 128;
         static bool once = (set_lds(conv_wgrad_bf16_col_kernel, lds), true);
         (void)once;
@@ -2310,12 +2734,9 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
         r.CT = rp.CT; r.NT = rp.NT; r.nslots = rp.nslots; r.schunk = rp.schunk; r.nsplit = rp.nsplit;
         const double fl = conv_flops(d), by = 2.0 * conv_elems(d);
         const char* label = "conv_wgrad_bf16_rows8_128x128";
-        static const int stagger = env_int("SSD_WGRAD_ROWS8_STAGGER", 1);      // A/B switch
         if (rows8_mode() == 2) launch_wgrad_rows8<2>(r, label, fl, by, s);
-        else if (rows8_mode() == 4 && stagger) launch_wgrad_rows8<4, true>(r, label, fl, by, s);
-        else if (rows8_mode() == 4) launch_wgrad_rows8<4, false>(r, label, fl, by, s);
-        else if (stagger) launch_wgrad_rows8<3, true>(r, label, fl, by, s);
-        else launch_wgrad_rows8<3, false>(r, label, fl, by, s);
+        else if (rows8_mode() == 4) launch_wgrad_rows8<4, true>(r, label, fl, by, s);
+        else launch_wgrad_rows8<3, true>(r, label, fl, by, s);
         wgrad_reduce(ws, rp.nsplit, (size_t)9 * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
         return;
     }

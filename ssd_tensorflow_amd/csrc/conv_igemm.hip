@@ -55,6 +55,13 @@ struct GatherArgs {
     int nclass;
     int cls_wg0[5], cls_M[4], cls_DH[4], cls_DW[4], cls_ntaps[4], cls_ph[4], cls_pw[4];
     int cls_dh[4][9], cls_dw[4][9], cls_w[4][9];
+    // fused 2x2 pool (LDS-DMA kernel only, see there): forward -> pooled tensor [PB][PH][PW][DN] (+ record); data gradient ->
+    // through the record into the pool's input gradient [.][UH][UW][DN]
+    float* pool_dst;
+    unsigned short* pool_rec;
+    int PB, PH, PW;
+    const unsigned short* unpool_rec;
+    int UH, UW;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -372,16 +379,23 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs p) {
 
 // STRIDED: data gradient of a stride-2^k convolution (conv8_2, conv9_2): source pixel = (oh + dh) / stride when that
 // division is exact; the validity of a (row, tap) pair is recomputed per iteration with shifts and masks.
-// NS: ring depth of the tile pipeline.  2 (every big layer): tile k + 1 streams in while tile k is multiplied -- the loop is
-// bound by the matrix pipe and a deeper ring only costs resident workgroups.  6 (round 4, the latency-bound small layers --
-// conv8_2 ... conv11_2 and the small maps' heads, a handful of workgroups with 36..144 dependent iterations each): up to four
-// tiles in flight, the iteration no longer waits for a whole DMA round trip.
-// KSPLIT > 1 (round 4, the small layers): KSPLIT groups of four waves share the tile; group g multiplies the k iterations g,
-// g + KSPLIT, ... from its own stages and the groups' accumulators are added through LDS in group order (a fixed order) before
-// group 0 writes the tile out.  What this buys in fp32 is matrix-pipe time: a 3x3 x 256-channel layer with a handful of
-// tiles is 1152 dependent 32x32x2 MFMAs = 31 us per wave however its tiles are staged (profiles/r04_q_ab_small_tile_f32.txt).
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2, int KSPLIT = 1>
-__global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArgs pp) {
+// Two pipeline stages: tile k + 1 streams in while tile k is multiplied -- the loop is bound by the matrix pipe.  (Round 4 also
+// carried a six-stage ring and a k split over four wave groups for the latency-bound small layers; in fp32 their serial k loop is
+// matrix-pipe time -- 1152 dependent 32x32x2 MFMAs = 31 us per wave however the tiles are staged -- and both measured slower in
+// the step: profiles/r04_q_ab_small_tile_f32.txt, r04_ac_ab_ksplit_f32.txt.  Removed in round 5.)
+//
+// Round 5, the 2x2 pools fused into their neighbours (conv.h):
+//  * forward POOL (p.pool_dst): the m index enumerates WINDOWS, not pixels -- row m of the GEMM is cell q = (m>>4 & 1, m & 1)
+//    of window (m >> 5) * 8 + ((m & 15) >> 1) in pooled raster order -- so that the 16 accumulator rows of a lane (MFMA C
+//    layout: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) hold four COMPLETE windows of its channel: the maxima, the first-maximum
+//    cell and its sign are taken in registers, the pooled value leaves as one 128-byte line per 32 lanes, the 12-bit record
+//    of 4 channels is assembled over 4 lanes.  The per-tap staging computes every row's pixel on its own, so the permuted
+//    order costs nothing in the loop; tile rows past the last window or outside an odd image are zero rows.
+//  * data gradient UNPOOL (p.unpool_rec): every pooled pixel's dx goes through the record to the four cells of the pool's
+//    input gradient (recorded cell and positive maximum ? dx : 0).
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, bool POOL = false>
+__global__ __launch_bounds__(256) void conv_gather_dma_kernel(GatherArgs pp) {
+    static_assert(!POOL || (MODE == MODE_FWD && !STRIDED && !PARITY), "fused pool: plain forward only");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     // (no local copy of the argument block: dynamically indexed arrays of a copy would live in scratch)
     const GatherArgs& p = pp;
@@ -408,11 +422,9 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArg
     static_assert(BK % B_RPP == 0, "filter tile vs staging pass");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int grp = KSPLIT > 1 ? wave_all >> 2 : 0;                                      // k-split group of this wave
-    const int wave = KSPLIT > 1 ? (wave_all & 3) : wave_all, lane = threadIdx.x & 63;
-    const int tid = KSPLIT > 1 ? wave * 64 + lane : (int)threadIdx.x;                    // thread index inside the group
-    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem) + grp * (NS * STAGE);      // the group's stages
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
     const int wg = xcd_remap(blockIdx.x - wg_first, wg_count);
     const int mt = wg / p.NT, nt = wg - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -424,12 +436,25 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArg
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
-        const int mm = m < P_M ? m : 0;
-        const int ow = mm % P_DW;
-        const int t2 = mm / P_DW;
-        const int oh = t2 % P_DH;
-        const int b = t2 / P_DH;
-        const int rh = m < P_M ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
+        int ow, oh, b;
+        bool mv = m < P_M;
+        if constexpr (POOL) {      // row m = a cell of a pooling window (see above)
+            const int g = (m >> 5) * 8 + ((m & 15) >> 1);
+            const int pw_ = g % p.PW, t2 = g / p.PW;
+            const int ph_ = t2 % p.PH;
+            b = t2 / p.PH;
+            oh = 2 * ph_ + ((m >> 4) & 1);
+            ow = 2 * pw_ + (m & 1);
+            mv = b < p.PB && oh < P_DH && ow < P_DW;
+            if (!mv) { b = 0; oh = 0; ow = 0; }
+        } else {
+            const int mm = mv ? m : 0;
+            ow = mm % P_DW;
+            const int t2 = mm / P_DW;
+            oh = t2 % P_DH;
+            b = t2 / P_DH;
+        }
+        const int rh = mv ? oh * p.mul : -(1 << 20), rw = ow * p.mul;
         a_off[i] = (unsigned)((b * p.SH * p.SW + rh * p.SW + rw) * p.SC + a_c4) * 4u;
         s_b[i] = b * p.SH * p.SW; s_h[i] = rh; s_w[i] = rw;
         unsigned mk = 0;
@@ -448,7 +473,7 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArg
     int tap_min = 0;
     for (int t = 0; t < P_ntaps; ++t) tap_min = min(tap_min, (P_tap_dh[t] * p.SW + P_tap_dw[t]) * p.SC);
     const unsigned tap_bias = (unsigned)(-tap_min) * 4u;
-    const size_t src_bytes = (size_t)(P_M / (P_DH * P_DW)) * p.SH * p.SW * p.SC * 4u;
+    const size_t src_bytes = (size_t)(POOL ? p.PB : P_M / (P_DH * P_DW)) * p.SH * p.SW * p.SC * 4u;
     const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(const_cast<float*>(p.src)) - (STRIDED ? 0u : tap_bias), 0, (unsigned)(src_bytes + (STRIDED ? 0u : tap_bias)), 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -559,76 +584,109 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_gather_dma_kernel(GatherArg
         }
     };
 
-    if constexpr (KSPLIT > 1) {
-        const int nkg = nk > grp ? (nk - grp + KSPLIT - 1) / KSPLIT : 0;      // this group's iterations
-        const int trips = (nk + KSPLIT - 1) / KSPLIT;                         // every group passes the same barriers
-        static_assert(NS == 2, "the k-split instantiation runs two stages per group");
-        if (nkg > 0) issue(grp, 0);
-        for (int j = 0; j < trips; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (j + 1 < nkg) issue(grp + (j + 1) * KSPLIT, (j + 1) & 1);
-            if (j < nkg) compute(j & 1);
+    // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
+    if (nk > 0) issue(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
+        compute(k & 1);
+    }
+
+    // ---- forward with the fused 2x2 pool: maxima, first-maximum cell and sign in registers (see the kernel's header)
+    if constexpr (POOL) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            // the four windows of this lane in the 32-row block: window wq = cells r = 2 (wq & 1) + 4 (wq >> 1) + {0, 1, 8, 9}
+            unsigned po[4];                               // pooled pixel index, or ~0u
+            bool okw[4], okh[4];
+#pragma unroll
+            for (int wq = 0; wq < 4; ++wq) {
+                const int mb = m0 + wm * 32 * TM + mi * 32;
+                const int g = (mb >> 5) * 8 + (wq & 1) + 4 * (wq >> 1) + 2 * lh;      // window: cc0 = 2 (wq&1) + 8 (wq>>1) + 4 lh, g = cc0 / 2
+                const int pw_ = g % p.PW, t2 = g / p.PW;
+                const int ph_ = t2 % p.PH, b = t2 / p.PH;
+                po[wq] = b < p.PB ? (unsigned)g : ~0u;
+                okw[wq] = 2 * pw_ + 1 < P_DW;
+                okh[wq] = 2 * ph_ + 1 < P_DH;
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * 32 * TN + ni * 32 + li;
+                const bool nv = n < p.DN;
+                const float bv = (p.bias && nv) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int wq = 0; wq < 4; ++wq) {
+                    const int r0 = 2 * (wq & 1) + 4 * (wq >> 1);
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = acc[mi][ni][r0 + (q & 1) + 8 * (q >> 1)] + bv;
+                        v[q] = (p.relu && !(t > 0.f)) ? 0.f : t;
+                    }
+                    const bool ok[4] = {true, okw[wq], okh[wq], okw[wq] && okh[wq]};
+                    float mm = v[0];
+                    unsigned a = 0;
+#pragma unroll
+                    for (int q = 1; q < 4; ++q)
+                        if (ok[q] && v[q] > mm) { mm = v[q]; a = q; }      // strict: the first maximum wins (ops.hip)
+                    unsigned rb = (a | (mm > 0.f ? 4u : 0u)) << (3 * (li & 3));
+                    rb |= (unsigned)__shfl_xor((int)rb, 1, 64);
+                    rb |= (unsigned)__shfl_xor((int)rb, 2, 64);
+                    if (nv && po[wq] != ~0u) {
+                        p.pool_dst[(size_t)po[wq] * p.DN + n] = mm;
+                        if (p.pool_rec && (li & 3) == 0) p.pool_rec[(size_t)po[wq] * (p.DN >> 2) + (n >> 2)] = (unsigned short)rb;
+                    }
+                }
+            }
         }
-        __syncthreads();
-        // groups 1 .. KSPLIT - 1 park their accumulators in LDS (a private 16-float slot per thread and block), group 0 adds them
-        // in group order: thread t of every group holds the same elements of the tile
-        float* park = smem;
-        if (grp > 0) {
+        return;
+    }
+    // ---- data gradient through a pool's record into the pool's input gradient
+    if (MODE == MODE_DGRAD && !PARITY && !STRIDED && p.unpool_rec) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
+            for (int rr = 0; rr < 4; ++rr) {              // four rows of the block at a time (registers)
+                unsigned base[4], mrow[4];
+                bool okm[4], okw[4], okh[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        park[(((grp - 1) * TM * TN + mi * TN + ni) * 16 + r) * 256 + tid] = acc[mi][ni][r];
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * 32 * TM + mi * 32 + e + 8 * rr + 4 * lh;      // r = e + 4 rr
+                    okm[e] = m < P_M;
+                    const int mm = okm[e] ? m : 0;
+                    const int ow = mm % P_DW, t2 = mm / P_DW;
+                    const int oh = t2 % P_DH, b = t2 / P_DH;
+                    mrow[e] = (unsigned)mm;
+                    base[e] = (unsigned)((b * p.UH + 2 * oh) * p.UW + 2 * ow);
+                    okw[e] = 2 * ow + 1 < p.UW;
+                    okh[e] = 2 * oh + 1 < p.UH;
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int n = n0 + wn * 32 * TN + ni * 32 + li;
+                    if (n >= p.DN) continue;
+                    unsigned rc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rc[e] = p.unpool_rec[(size_t)mrow[e] * (p.DN >> 2) + (n >> 2)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!okm[e]) continue;
+                        const unsigned re = (rc[e] >> (3 * (n & 3))) & 7u;
+                        const float v = acc[mi][ni][e + 4 * rr];
+                        const bool ok[4] = {true, okw[e], okh[e], okw[e] && okh[e]};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (!ok[q]) continue;
+                            const unsigned pix = base[e] + (unsigned)((q >> 1) * p.UW + (q & 1));
+                            p.dst[(size_t)pix * p.DN + n] = ((re & 3u) == (unsigned)q && (re & 4u)) ? v : 0.f;
+                        }
+                    }
+                }
+            }
         }
-        __syncthreads();
-        if (grp > 0) return;
-#pragma unroll 1
-        for (int g = 1; g < KSPLIT; ++g)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[mi][ni][r] += park[(((g - 1) * TM * TN + mi * TN + ni) * 16 + r) * 256 + tid];
-    } else if constexpr (NS == 2) {
-        // two stages: tile k+1 streams in while tile k is multiplied; one barrier per iteration
-        if (nk > 0) issue(0, 0);
-        for (int k = 0; k < nk; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
-            compute(k & 1);
-        }
-    } else {
-        // ring of NS stages: tiles k+1 .. k+NS-1 in flight while tile k is multiplied (vmcnt retires a lane's DMA in order:
-        // waiting until at most `ahead` tiles' worth of instructions are outstanding means tile k has landed)
-        constexpr int L = A_N + B_N;
-        static_assert(4 * L <= 63, "vmcnt field");
-#pragma unroll
-        for (int t = 0; t < NS - 1; ++t)
-            if (t < nk) issue(t, t);
-        int st_c = 0, st_i = NS - 1;
-        for (int k = 0; k < nk; ++k) {
-            const int later = nk - 1 - k;
-            const int ahead = later < NS - 2 ? later : NS - 2;
-            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * L) : "memory");
-            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L) : "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
-            compute(st_c);
-            st_c = st_c + 1 == NS ? 0 : st_c + 1;
-            st_i = st_i + 1 == NS ? 0 : st_i + 1;
-        }
+        return;
     }
 
 #pragma unroll
@@ -1164,31 +1222,19 @@ static void check_desc(const ConvDesc& d) {
                 "conv: a tensor of this layer exceeds 4 GiB (32-bit byte offsets): lower the batch");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, int NS = 2, int KSPLIT = 1>
+template <int MODE, int WM, int WN, int TM, int TN, bool STRIDED = false, bool PARITY = false, bool POOL = false>
 static void launch_gather_dma(GatherArgs& a, const char* label, double flops, double bytes, hipStream_t s, int grid = 0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t stages = KSPLIT * NS * (size_t)(BM + BN) * 128, park = (size_t)(KSPLIT - 1) * TM * TN * 16 * 256 * 4;
-    constexpr size_t lds = stages > park ? stages : park;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY, NS, KSPLIT>;
+    auto kern = conv_gather_dma_kernel<MODE, WM, WN, TM, TN, STRIDED, PARITY, POOL>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256 * KSPLIT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
-}
-
-// LDS-DMA staging for the fast path (SSD_GLDS=0 selects the register-staged kernels: A/B switch)
-static bool use_dma() {
-    static const int v = env_int("SSD_GLDS", 1);
-    return v != 0;
-}
-
-static int use_wgrad_dma() {
-    static const int v = env_int("SSD_GLDS_WGRAD", 1);
-    return use_dma() ? v : 0;
 }
 
 // Tile choice: all co-resident workgroups of a CU share its matrix pipes, so a launch costs
@@ -1200,12 +1246,11 @@ static int pick_tile(long long M, int N, int mode) {
     static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
     // relative per-tile efficiency measured on vgg300 layers at batch 32 (tools/bench_conv.py):
     // forward runs 116-125 TF/s on every tile; the data-gradient is fastest on 64x64
-    static const double eff_fwd[4] = {0.98, 1.0, 1.0, 0.95}, eff_dg[4] = {0.93, 0.92, 0.93, 1.0};
-    // ... and again with the LDS-DMA kernels (no staging registers): forward is best on 128x128 (conv2_2 126,
-    // conv3_2 131, conv4_2 125 TF/s), the data gradient on 64x128 (123-128), on 64x64 when N = 64 (conv1_2 110)
+    // (LDS-DMA kernels: forward is best on 128x128 (conv2_2 126, conv3_2 131, conv4_2 125 TF/s), the data gradient on 64x128
+    // (123-128), on 64x64 when N = 64 (conv1_2 110))
     static const double dma_fwd[4] = {1.03, 1.0, 1.0, 0.96}, dma_dg[4] = {0.96, 0.97, 1.0, 0.94};
-    if (use_dma() && mode == MODE_DGRAD && N <= 64) return 3;
-    const double* eff = use_dma() ? (mode == MODE_FWD ? dma_fwd : dma_dg) : (mode == MODE_FWD ? eff_fwd : eff_dg);
+    if (mode == MODE_DGRAD && N <= 64) return 3;
+    const double* eff = mode == MODE_FWD ? dma_fwd : dma_dg;
     int best = 0;
     double bc = 1e300;
     for (int c = 0; c < 4; ++c) {
@@ -1216,31 +1261,18 @@ static int pick_tile(long long M, int N, int mode) {
     return best;
 }
 
-// The small layers (at most one 64 x 64 workgroup per CU) on the deep-ring instantiation: SSD_SMALL_TILE_F32=1, default OFF.
-// Unlike their bf16 counterparts (conv_bf16.hip pick_tile_h: -25 % per launch) these launches are not waiting for their DMA:
-// a 32 x 32 x 2 fp32 MFMA retires two k per 64 cycles, so the serial k loop of a 3x3 x 256-channel layer is 1152 dependent
-// MFMAs = 31 us of matrix pipe per wave whatever the staging does -- per-layer times unchanged, step +0.2 ms from the
-// lost 128 x 64 tiles (profiles/r04_q_ab_small_tile_f32.txt).  What these layers need is k split over the waves of a workgroup.
-// SSD_SMALL_KSPLIT_F32=1 (default OFF): small layers (at most one 64 x 64 workgroup per CU, at least 16 k iterations) on the k-split
-// instantiation, four wave groups per tile.  Measured (profiles/r04_ac_ab_ksplit_f32.txt): conv11_2 forward 37 -> 32 us, the
-// small heads 63 -> 52 us, step 50.42 -> 50.65 ms.  A quarter of the MFMAs per wave bought 5-11 us: with two stages per group
-// every trip of the loop is still one whole DMA round trip from HBM (a handful of workgroups keeps 16 KB in flight per
-// group), and the 1024-thread workgroups start ~8 us apart.  The remedy for these layers is k split ACROSS CUs.
-static bool small_ksplit_f32(long long M, int N, int nk) {
-    static const int on = env_int("SSD_SMALL_KSPLIT_F32", 0), forced = env_int("SSD_TILE", -1);
-    return on && forced < 0 && nk >= 16 && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256;
-}
-static bool small_deep_f32(long long M, int N) {
-    static const int on = env_int("SSD_SMALL_TILE_F32", 0), forced = env_int("SSD_TILE", -1);
-    return on && forced < 0 && (long long)cdiv(M, 64) * cdiv(N, 64) <= 256;
-}
-
 static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, const float* bias, void* y, bool y_bf16, bool relu,
-                         hipStream_t s) {
+                         hipStream_t s, float* y_pool = nullptr, void* rec = nullptr) {
     check_desc(d);
+    const bool pool = y_pool != nullptr;
     GatherArgs a{};
     a.src = x; a.wgt = w; a.bias = bias; a.mask = nullptr; a.dst = static_cast<float*>(y);
     a.M = d.B * d.Ho * d.Wo; a.DH = d.Ho; a.DW = d.Wo; a.DN = d.Co;
+    if (pool) {      // GEMM rows enumerate the cells of the pooling windows, 8 windows per 32-row block (conv_gather_dma_kernel)
+        a.pool_dst = y_pool; a.pool_rec = static_cast<unsigned short*>(rec);
+        a.PB = d.B; a.PH = (d.Ho + 1) / 2; a.PW = (d.Wo + 1) / 2;
+        a.M = cdiv((long long)d.B * a.PH * a.PW, 8) * 32;
+    }
     a.SH = d.Hi; a.SW = d.Wi; a.SC = d.Ci;
     a.ntaps = d.KH * d.KW; a.mul = d.stride; a.div = 1;
     a.wci = d.Ci; a.wco = d.Co; a.relu = relu; a.accum = 0;
@@ -1253,6 +1285,7 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
         }
     const bool smallc = d.Ci % 4 != 0;
     const double fl = conv_flops(d), by = conv_bytes(d);
+    SSD_REQUIRE(!pool || !smallc, "fused pool: not for the packed small-C layer");
     SSD_REQUIRE(!y_bf16 || smallc, "bf16 output from fp32 input: only the packed small-C layer (conv1_1)");
     static const int first_kernel = env_int("SSD_FIRST_F32", 1);        // A/B switch
     if (smallc && !y_bf16 && first_kernel && conv_first_fwd_f32_applicable(d)) {
@@ -1264,31 +1297,23 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
         else launch_gather<MODE_FWD, 4, 1, 1, 2, true, false>(a, "conv_fwd_smallc_128x64", fl, by, s);
         return;
     }
-    if (use_dma() && small_ksplit_f32(a.M, a.DN, cdiv(a.SC, 32) * a.ntaps)) {
-        launch_gather_dma<MODE_FWD, 2, 2, 1, 1, false, false, 2, 4>(a, "conv_fwd_64x64_k4", fl, by, s);
-        return;
-    }
-    if (use_dma() && small_deep_f32(a.M, a.DN)) {
-        launch_gather_dma<MODE_FWD, 2, 2, 1, 1, false, false, 6>(a, "conv_fwd_64x64x6", fl, by, s);
-        return;
-    }
-    if (use_dma()) {
-        // (the cost model counts rounds of workgroups on the chip: the launches that run side by side -- the executor's forward
-        // lanes, g_conv_lanes -- share it.  SSD_TILE_LANES=0: per launch, as before round 4.)
-        static const int lane_aware = env_int("SSD_TILE_LANES", 1);
-        switch (pick_tile((long long)a.M * (lane_aware ? g_conv_lanes : 1), a.DN, MODE_FWD)) {
-        case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2>(a, "conv_fwd_128x128", fl, by, s); break;
-        case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2>(a, "conv_fwd_128x64", fl, by, s); break;
-        case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2>(a, "conv_fwd_64x128", fl, by, s); break;
-        default: launch_gather_dma<MODE_FWD, 2, 2, 1, 1>(a, "conv_fwd_64x64", fl, by, s); break;
+    // (the cost model counts rounds of workgroups on the chip: the launches that run side by side -- the executor's forward
+    // lanes, g_conv_lanes -- share it)
+    const int cfg = pick_tile((long long)a.M * g_conv_lanes, a.DN, MODE_FWD);
+    if (pool) {
+        switch (cfg) {
+        case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2, false, false, true>(a, "conv_fwd_pool_128x128", fl, by, s); break;
+        case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2, false, false, true>(a, "conv_fwd_pool_128x64", fl, by, s); break;
+        case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2, false, false, true>(a, "conv_fwd_pool_64x128", fl, by, s); break;
+        default: launch_gather_dma<MODE_FWD, 2, 2, 1, 1, false, false, true>(a, "conv_fwd_pool_64x64", fl, by, s); break;
         }
         return;
     }
-    switch (pick_tile(a.M, a.DN, MODE_FWD)) {
-    case 0: launch_gather<MODE_FWD, 2, 2, 2, 2, false, false>(a, "conv_fwd_128x128", fl, by, s); break;
-    case 1: launch_gather<MODE_FWD, 4, 1, 1, 2, false, false>(a, "conv_fwd_128x64", fl, by, s); break;
-    case 2: launch_gather<MODE_FWD, 2, 2, 1, 2, false, false>(a, "conv_fwd_64x128", fl, by, s); break;
-    default: launch_gather<MODE_FWD, 2, 2, 1, 1, false, false>(a, "conv_fwd_64x64", fl, by, s); break;
+    switch (cfg) {
+    case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2>(a, "conv_fwd_128x128", fl, by, s); break;
+    case 1: launch_gather_dma<MODE_FWD, 4, 1, 1, 2>(a, "conv_fwd_128x64", fl, by, s); break;
+    case 2: launch_gather_dma<MODE_FWD, 2, 2, 1, 2>(a, "conv_fwd_64x128", fl, by, s); break;
+    default: launch_gather_dma<MODE_FWD, 2, 2, 1, 1>(a, "conv_fwd_64x64", fl, by, s); break;
     }
 }
 
@@ -1296,15 +1321,28 @@ void conv_fwd(const ConvDesc& d, const float* x, const float* w, const float* bi
     conv_fwd_any(d, x, w, bias, y, false, relu, s);
 }
 
+// ---- fused 2x2 pool (conv.h) -------------------------------------------------------------------------------------
+static bool pool_shape(const ConvDesc& d) {      // 3x3 (or any <= 9 taps) stride-1 same-size convolution
+    return d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo && d.Ci % 4 == 0 && d.Co % 4 == 0 && d.KH * d.KW <= 9;
+}
+bool conv_fwd_pool_supported(const ConvDesc& d) { return pool_shape(d); }
+void conv_fwd_pool(const ConvDesc& d, const float* x, const float* w, const float* bias, float* y_pool, void* rec, hipStream_t s) {
+    SSD_REQUIRE(conv_fwd_pool_supported(d), "conv_fwd_pool: unsupported shape");
+    SSD_REQUIRE(y_pool != nullptr, "conv_fwd_pool: null output");
+    conv_fwd_any(d, x, w, bias, nullptr, false, true, s, y_pool, rec);
+}
+bool conv_dgrad_unpool_supported(const ConvDesc& d) { return d.stride == 1 && d.Ci % 4 == 0 && d.Co % 4 == 0; }
+
 void conv_fwd_smallc_bf16out(const ConvDesc& d, const float* x, const float* w, const float* bias, bf16_t* y, bool relu,
                              hipStream_t s) {
     conv_fwd_any(d, x, w, bias, y, true, relu, s);
 }
 
-void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* mask, bool accumulate,
-                hipStream_t s) {
+static void conv_dgrad_any(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* mask, bool accumulate,
+                           hipStream_t s, const void* unpool_rec = nullptr, int UH = 0, int UW = 0) {
     check_desc(d);
     SSD_REQUIRE(d.Ci % 4 == 0, "conv_dgrad: Ci must be a multiple of 4");
+    SSD_REQUIRE(unpool_rec == nullptr || d.stride == 1, "conv_dgrad: the fused un-pool is for stride-1 convolutions");
     GatherArgs a{};
     a.src = dy; a.wgt = w; a.bias = nullptr; a.mask = mask; a.dst = dx;
     a.M = d.B * d.Hi * d.Wi; a.DH = d.Hi; a.DW = d.Wi; a.DN = d.Ci;
@@ -1312,6 +1350,8 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     a.ntaps = d.KH * d.KW; a.mul = 1; a.div = d.stride;
     a.wci = d.Ci; a.wco = d.Co; a.relu = 0; a.accum = accumulate;
     a.wtaps = a.ntaps; a.out_mul = 1; a.out_ph = a.out_pw = 0; a.ODH = a.DH; a.ODW = a.DW;
+    a.unpool_rec = static_cast<const unsigned short*>(unpool_rec); a.UH = UH; a.UW = UW;
+    const bool unpool = unpool_rec != nullptr;
     for (int kh = 0; kh < d.KH; ++kh)
         for (int kw = 0; kw < d.KW; ++kw) {
             a.tap_dh[kh * d.KW + kw] = d.pad_h - kh * d.dil;
@@ -1321,7 +1361,7 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
     const double fl = conv_flops(d), by = conv_bytes(d) + (mask ? 4.0 * d.B * d.Hi * d.Wi * d.Ci : 0.0);
     const int cfg = pick_tile(a.M, a.DN, MODE_DGRAD);
     static const int parity = env_int("SSD_DGRAD_PARITY", 1);      // A/B switch
-    if (d.stride > 1 && use_dma() && parity && d.Co % 4 == 0) {
+    if (d.stride > 1 && parity && d.Co % 4 == 0) {
         // Strided data gradient by parity classes (conv8_2, conv9_2, vgg512 conv10_2).  An input pixel (ih, iw) only
         // meets the taps with (ih + pad - kh dil) divisible by the stride: gathering all taps for every pixel wastes
         // (stride^2 - 1) / stride^2 of the MFMAs on zero rows.  Per class (ih mod s, iw mod s) the pixels form a dense
@@ -1359,31 +1399,32 @@ void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, c
         for (int t = 0; t < 9; ++t) { c.tap_dh[t] = c.cls_dh[0][t]; c.tap_dw[t] = c.cls_dw[0][t]; c.tap_w[t] = c.cls_w[0][t]; }
         if (tile128) launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2, false, true>(c, "conv_dgrad_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
         else launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2, false, true>(c, "conv_dgrad_parity_64x128", fl, by, s, c.cls_wg0[c.nclass]);
-    } else if (d.stride > 1 && use_dma() && (d.stride & (d.stride - 1)) == 0) {      // the all-taps strided kernel (SSD_DGRAD_PARITY=0)
+    } else if (d.stride > 1 && (d.stride & (d.stride - 1)) == 0) {      // the all-taps strided kernel (SSD_DGRAD_PARITY=0)
         if (cfg == 0 || cfg == 1) launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2, true>(a, "conv_dgrad_strided_64x128", fl, by, s);
-    } else if (d.stride > 1) {
+    } else if (d.stride > 1) {      // other strides: the register-staged kernel
         if (cfg == 0 || cfg == 1) launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, true>(a, "conv_dgrad_strided_128x128", fl, by, s);
         else launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, true>(a, "conv_dgrad_strided_64x64", fl, by, s);
-    } else if (use_dma() && small_ksplit_f32(a.M, a.DN, cdiv(a.SC, 32) * a.ntaps)) {
-        launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1, false, false, 2, 4>(a, "conv_dgrad_64x64_k4", fl, by, s);
-    } else if (use_dma() && small_deep_f32(a.M, a.DN)) {
-        launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1, false, false, 6>(a, "conv_dgrad_64x64x6", fl, by, s);
-    } else if (use_dma()) {
-        switch (cfg) {
-        case 0: launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2>(a, "conv_dgrad_128x128", fl, by, s); break;
-        case 1: launch_gather_dma<MODE_DGRAD, 4, 1, 1, 2>(a, "conv_dgrad_128x64", fl, by, s); break;
-        case 2: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2>(a, "conv_dgrad_64x128", fl, by, s); break;
-        default: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1>(a, "conv_dgrad_64x64", fl, by, s); break;
-        }
     } else {
         switch (cfg) {
-        case 0: launch_gather<MODE_DGRAD, 2, 2, 2, 2, false, false>(a, "conv_dgrad_128x128", fl, by, s); break;
-        case 1: launch_gather<MODE_DGRAD, 4, 1, 1, 2, false, false>(a, "conv_dgrad_128x64", fl, by, s); break;
-        case 2: launch_gather<MODE_DGRAD, 2, 2, 1, 2, false, false>(a, "conv_dgrad_64x128", fl, by, s); break;
-        default: launch_gather<MODE_DGRAD, 2, 2, 1, 1, false, false>(a, "conv_dgrad_64x64", fl, by, s); break;
+        case 0: launch_gather_dma<MODE_DGRAD, 2, 2, 2, 2>(a, unpool ? "conv_dgrad_unpool_128x128" : "conv_dgrad_128x128", fl, by, s); break;
+        case 1: launch_gather_dma<MODE_DGRAD, 4, 1, 1, 2>(a, unpool ? "conv_dgrad_unpool_128x64" : "conv_dgrad_128x64", fl, by, s); break;
+        case 2: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 2>(a, unpool ? "conv_dgrad_unpool_64x128" : "conv_dgrad_64x128", fl, by, s); break;
+        default: launch_gather_dma<MODE_DGRAD, 2, 2, 1, 1>(a, unpool ? "conv_dgrad_unpool_64x64" : "conv_dgrad_64x64", fl, by, s); break;
         }
     }
+}
+
+void conv_dgrad(const ConvDesc& d, const float* dy, const float* w, float* dx, const float* mask, bool accumulate,
+                hipStream_t s) {
+    conv_dgrad_any(d, dy, w, dx, mask, accumulate, s);
+}
+
+void conv_dgrad_unpool(const ConvDesc& d, const float* dy, const float* w, float* dx_unpooled, const void* rec, int UH, int UW,
+                       hipStream_t s) {
+    SSD_REQUIRE(conv_dgrad_unpool_supported(d), "conv_dgrad_unpool: unsupported shape");
+    SSD_REQUIRE(rec != nullptr && (UH + 1) / 2 == d.Hi && (UW + 1) / 2 == d.Wi, "conv_dgrad_unpool: record / pooled size mismatch");
+    conv_dgrad_any(d, dy, w, dx_unpooled, nullptr, false, s, rec, UH, UW);
 }
 
 // ---- wgrad planning ---------------------------------------------------------------
@@ -1405,9 +1446,8 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
         // conv4 and deeper: 3 workgroups / CU.  Round 1 took 128x64 tiles (116 vs 107 TFLOP/s on 128x128); re-measured on the
         // round-2 kernels (tools/bench_conv.py sweep, gpurun r02): 64 input channels x 128 output channels is 1-5 % faster on
         // every one of these layers (conv4_1 0.923 -> 0.907, conv4_2 1.800 -> 1.782, conv5_2 0.498 -> 0.475, mod_conv6
-        // 0.954 -> 0.907 ms).  SSD_WGRAD_DEEP_CFG=3 selects the old tile.
-        static const int deep = env_int("SSD_WGRAD_DEEP_CFG", 2);
-        p.cfg = deep == 3 ? 3 : 2;
+        // 0.954 -> 0.907 ms).
+        p.cfg = 2;
     }
     else p.cfg = 0;
     static const int forced = env_int("SSD_WGRAD_CFG", -1);      // tuning override
@@ -1425,8 +1465,7 @@ static WgradPlan plan_wgrad(const ConvDesc& d) {
     // Round quantisation: the grid runs in rounds of `slots` resident workgroups (LDS-limited: 2 per CU with
     // 128x128 tiles, 3 with 128x64 / 64x128, 4 with 64x64).  Among the split counts near `want`, take the one
     // whose last round is fullest (conv4_x at batch 32: 6 splits = 2.25 rounds -> 8 splits = 3.0 rounds).
-    static const int tune = env_int("SSD_WGRAD_ROUNDS", 1);      // A/B switch
-    if (tune && !p.smallc && p.tiles * want > 256) {
+    if (!p.smallc && p.tiles * want > 256) {
         const int slots = 256 * (p.cfg == 0 ? 2 : (p.cfg == 1 ? 4 : 3));
         int best = want;
         double best_fill = 0.0;
@@ -1480,26 +1519,26 @@ static void launch_wgrad_dma(WgradArgs& a, const WgradPlan& pl, const char* labe
     HIP_OK(hipGetLastError());
 }
 
-// ---- grouped form: one launch for a list of layers -------------------------------------------------------------
-constexpr int RG_MAX = 40;
-struct GroupedReduceArgs {
-    int n;
-    int blk_off[RG_MAX + 1];
-    ReduceItem it[RG_MAX];
+// ---- the slabs of ONE layer when there are hundreds of them (conv1_1): `lanes` threads share a float4 element --------------
+struct ManySlabsArgs {
+    const float* ws;
+    const float* w;
+    float* dw;
+    float* db;
+    unsigned long long wcount;
+    int nsplit, Co;
+    float wd;
+    int lanes;          // threads sharing one float4 element
 };
 
-// A workgroup owns 256 / lanes consecutive float4 elements of one layer; `lanes` threads share an element, each
-// summing every lanes-th slab in ascending order; the partials are added in lane order through LDS (fixed order).
-__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(GroupedReduceArgs g) {
+// A workgroup owns 256 / lanes consecutive float4 elements; `lanes` threads share an element, each summing every
+// lanes-th slab in ascending order; the partials are added in lane order through LDS (fixed order).
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ManySlabsArgs it) {
     __shared__ f32x4 part[256];
-    int i = 0;
-    for (int k = 1; k < g.n; ++k)
-        if ((int)blockIdx.x >= g.blk_off[k]) i = k;
-    const ReduceItem& it = g.it[i];
     const int lanes = it.lanes, per = 256 / lanes;
     const int e = threadIdx.x % per, sl = threadIdx.x / per;
     const size_t total = it.wcount + it.Co;
-    const size_t idx = ((size_t)(blockIdx.x - g.blk_off[i]) * per + e) * 4;
+    const size_t idx = ((size_t)blockIdx.x * per + e) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (idx < total) s = slab_sum(it.ws, total, idx, sl, lanes, it.nsplit);
     part[sl * per + e] = s;
@@ -1516,51 +1555,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(GroupedReduce
     }
 }
 
-thread_local ReduceBatch* g_reduce_batch = nullptr;
-
-void wgrad_reduce_flush(ReduceBatch& batch, hipStream_t s) {
-    size_t done = 0;
-    while (done < batch.items.size()) {
-        GroupedReduceArgs g{};
-        int blocks = 0;
-        double bytes = 0.0;
-        for (; done < batch.items.size() && g.n < RG_MAX; ++done) {
-            const ReduceItem& it = batch.items[done];
-            const size_t total = it.wcount + it.Co;
-            g.blk_off[g.n] = blocks;
-            g.it[g.n++] = it;
-            blocks += cdiv((long long)(total / 4), 256 / it.lanes);
-            bytes += 4.0 * (double)total * (it.nsplit + 2);
-        }
-        for (int k = g.n; k <= RG_MAX; ++k) g.blk_off[k] = blocks;
-        ProfScope prof("wgrad_reduce_grouped", 0.0, bytes, s);
-        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3(blocks), dim3(256), 0, s, g);
-        HIP_OK(hipGetLastError());
-    }
-    batch.items.clear();
-}
-
 void wgrad_reduce(const float* ws, int nsplit, size_t wcount, int Co, float* dw, float* db, const float* w, float wd,
                   hipStream_t s) {
-    // measurement aid (tools/step_time.py): SSD_ABLATE=reduce drops the slab reduces to price them inside the overlapped step
-    {
-        const char* v = getenv("SSD_ABLATE");
-        if (v && strstr(v, "reduce")) return;
-    }
-    if (g_reduce_batch) {
-        const size_t total4 = (wcount + Co) / 4;
-        // enough workgroups to spread over the chip, enough slabs per thread to be worth a thread
-        int lanes = 4;
-        if (nsplit >= 256 || (nsplit >= 32 && total4 < 16384)) lanes = 64;
-        else if (nsplit >= 32) lanes = 16;
-        g_reduce_batch->items.push_back(ReduceItem{ws, w, dw, db, (unsigned long long)wcount, nsplit, Co, wd, lanes});
-        return;
-    }
+    if (ablated("reduce")) return;      // measurement aid (tools/step_time.py, ssd_debug_set_ablate)
     const size_t total = wcount + Co;
     if (nsplit >= 256) {        // hundreds of slabs of a small filter (conv1_1): 64 threads share an element
-        ReduceBatch one;
-        one.items.push_back(ReduceItem{ws, w, dw, db, (unsigned long long)wcount, nsplit, Co, wd, 64});
-        wgrad_reduce_flush(one, s);
+        const ManySlabsArgs it{ws, w, dw, db, (unsigned long long)wcount, nsplit, Co, wd, 64};
+        ProfScope prof("wgrad_reduce_many", 0.0, 4.0 * (double)total * (nsplit + 2), s);
+        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(cdiv((long long)(total / 4), 256 / it.lanes)), dim3(256), 0, s, it);
+        HIP_OK(hipGetLastError());
         return;
     }
     int blocks = cdiv((long long)total, 256 * 4);
@@ -1593,14 +1596,10 @@ static void conv_wgrad_any(const ConvDesc& d, const float* x, const void* dy, bo
     const double fl = conv_flops(d), by = conv_bytes(d);
     if (pl.smallc && dy_bf16) launch_wgrad<2, 2, 1, 1, true, true>(a, pl, "conv_wgrad_smallc_64x64_bf16dy", fl, by, s);
     else if (pl.smallc) launch_wgrad<2, 2, 1, 1, true>(a, pl, "conv_wgrad_smallc_64x64", fl, by, s);
-    // LDS-DMA staging pays on the 64-channel layers (conv1_2 86 -> 95, conv2_1 TF/s: their x rows are re-read by 9
-    // taps and the staging registers were the occupancy limit); the 128-wide tiles measure 0..-3 % (SSD_GLDS_WGRAD=2 forces them)
-    else if (use_wgrad_dma() >= 1 && pl.cfg == 1) launch_wgrad_dma<2, 2, 1, 1>(a, pl, "conv_wgrad_64x64", fl, by, s);
-    else if (use_wgrad_dma() >= 1 && pl.cfg == 2) launch_wgrad_dma<2, 2, 1, 2>(a, pl, "conv_wgrad_64x128", fl, by, s);
-    else if (use_wgrad_dma() >= 2 && pl.cfg == 3) launch_wgrad_dma<2, 2, 2, 1>(a, pl, "conv_wgrad_128x64", fl, by, s);
-    else if (use_wgrad_dma() >= 2 && pl.cfg == 0) launch_wgrad_dma<2, 2, 2, 2>(a, pl, "conv_wgrad_128x128", fl, by, s);
-    else if (pl.cfg == 1) launch_wgrad<2, 2, 1, 1, false>(a, pl, "conv_wgrad_64x64", fl, by, s);
-    else if (pl.cfg == 2) launch_wgrad<2, 2, 1, 2, false>(a, pl, "conv_wgrad_64x128", fl, by, s);
+    // LDS-DMA staging on the 64-channel tiles (conv1_2 86 -> 95 TF/s: their x rows are re-read by 9 taps and the staging
+    // registers were the occupancy limit); the 128-wide tiles measured 0..-3 % with it and keep the register-staged kernel
+    else if (pl.cfg == 1) launch_wgrad_dma<2, 2, 1, 1>(a, pl, "conv_wgrad_64x64", fl, by, s);
+    else if (pl.cfg == 2) launch_wgrad_dma<2, 2, 1, 2>(a, pl, "conv_wgrad_64x128", fl, by, s);
     else if (pl.cfg == 3) launch_wgrad<2, 2, 2, 1, false>(a, pl, "conv_wgrad_128x64", fl, by, s);
     else launch_wgrad<2, 2, 2, 2, false>(a, pl, "conv_wgrad_128x128", fl, by, s);
 

@@ -46,6 +46,10 @@ struct Op {
     // pool
     int k = 2;
     void* pool_rec = nullptr;        // forward-written argmax / sign record of a single-consumer 2x2 pool (ops.h)
+    // pool fusion (net.hip plan_pool_fusion): a pool written by its producer's forward epilogue / whose backward is the scatter
+    // in its consumer's data gradient; on conv ops: the pool behind this conv / the pool this conv's data gradient un-pools
+    bool fused_fwd = false, fused_bwd = false;
+    int pool_after = -1, unpool = -1;
     // head op: index of the feature map, else -1
     int head = -1;
 };
@@ -115,6 +119,7 @@ public:
     void save_variable(const char* name, float* host, size_t count, int which);         // 0 params, 1 grads, 2 momentum
     void activation(const char* name, int b, float* out, size_t count);
     void activation_shape(const char* name, int* H, int* W, int* C) const;
+    void pool_fusion(int* out, int cap, int* count) const;      // per 2x2 stride-2 pool in graph order: bit 0 fused forward, bit 1 fused backward
 
     void detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls, int* idx, int* box);
     // asynchronous form: kernels + one device-to-host copy enqueued; dev_out (optional) = the HBM arrays of the slot
@@ -162,39 +167,28 @@ private:
     hipEvent_t ev_dy_ = nullptr, ev_w_ = nullptr;
     hipStream_t hstream_ = nullptr;        // side stream of the multibox heads in forward
     hipEvent_t ev_h_ = nullptr, ev_cast_ = nullptr, ev_fmap_[MAX_MAPS] = {};
-    hipStream_t s2_ = nullptr, h2_ = nullptr;   // second forward lane: its main and head streams (by default both = wstream_: net.hip constructor)
-    hipEvent_t ev2_h_ = nullptr, ev2_dy_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
-    struct BwLane {                             // a lane of the data-gradient chain (net.hip Net::backward_begin)
-        hipStream_t s, h;
-        hipEvent_t ev_dy, ev_h;
-        int b0, nb;
-    } bw_lane_[2] = {};
-    int bw_nl_ = 1;
+    hipStream_t s2_ = nullptr;                  // second forward lane: its main stream, which also runs its heads (= wstream_ in a training handle)
+    hipEvent_t ev2_h_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
     int tail_first_ = 0;                 // op index of conv8_1: the extra layers behind it form backward's side chain
     // Issue orders (net.hip build_orders): forward walks fwd_order_ (every multibox head right behind its feature map), backward
-    // walks bwd_order_ (the latency-bound chain of small heads and extra layers first, the 38x38 head deferred beside mod_conv6)
+    // walks bwd_order_ (reverse graph order)
     std::vector<int> fwd_order_, bwd_order_;
-    int bw_gate_op_ = -1;                // backward: the main stream waits for the side chain before this op (head 1), -1: none
     std::vector<char> bw_conv_done_;     // backward: conv ops processed so far (indexed like ops_)
     // backward stream classes: 0 = a lane's main stream, 1 = its side stream.  bw_issued_[c] counts the kernels class c has been
     // given that write a gradient, bw_seen_[x][y] is the count of class y that class x has already been made to wait for
     long bw_issued_[2] = {0, 0}, bw_seen_[2][2] = {{0, 0}, {0, 0}};
-    hipEvent_t ev_m2s_[2] = {nullptr, nullptr};      // main -> side hand-off, per lane
+    hipEvent_t ev_m2s_ = nullptr;        // main -> side hand-off
     bool bw_first_on_main_ = false;      // the first layer's weight gradient was issued on the main stream (backward_step)
-    std::vector<int> bw_deferred_;       // backward: head ops whose weight gradient waits for the chain to be issued
-    bool bw_chain_done_ = false;
-    bool defers_head_wgrads() const;
     void launch_wgrad(int op_index, int b, hipStream_t ws);
-    void flush_deferred_wgrads();
     void build_orders();
+    void plan_pool_fusion();
     int bw_class(const Op& op, int op_index) const;
-    void bw_sync(int x, int y);          // class x waits for everything class y has been given so far (every lane)
+    void bw_sync(int x, int y);          // class x waits for everything class y has been given so far
     void bw_need(int x, const Tensor& t) { if (t.gstream != x && t.gseq > bw_seen_[x][t.gstream]) bw_sync(x, t.gstream); }
     void bw_wrote(int x, Tensor& t) { t.gstream = x; t.gseq = ++bw_issued_[x]; }
     size_t bw_final_lo() const;          // lowest arena offset such that every filter at or above it has its final gradient
     bool overlap_ = true;
     bool own_wstream_ = true;
-    bool h2_is_s2_ = false;                // the second lane's heads run on its main stream (no side stream of its own)
     bool s2_is_w_ = false;                 // the second forward lane's stream IS the weight-gradient stream (four streams in all)
 
     std::vector<Tensor> tensors_;
@@ -211,7 +205,6 @@ private:
     float* result_ = nullptr;
     float *x_stage_ = nullptr, *y_stage_ = nullptr;
     float* wgrad_ws_ = nullptr;
-    ReduceBatch reduce_batch_;
     float* l2_ws_ = nullptr;
     void* pool_ws_ = nullptr;
     void* loss_ws_ = nullptr;

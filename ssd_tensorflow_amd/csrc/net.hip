@@ -181,15 +181,20 @@ void Net::build_graph() {
     add_var("l2_norm_conv4_3/scale", 1, 512, 0, 0, 0, scale_off_, 1, 512, 512);
 }
 
-// Measurement aid (tools/step_time.py), never set in a product run: SSD_ABLATE=<tokens> drops groups of launches from the
-// step so their price INSIDE the overlapped step can be read off (results are wrong by construction).  Tokens: pool, tail
-// (conv8_2 ... conv11_2 and the small maps' heads), heads01, conv1, conv5, l2norm, reduce (conv_igemm.hip).
-static bool ablated(const char* token) {
-    const char* v = getenv("SSD_ABLATE");      // (not cached: the tool switches it on after un-ablated warmup steps)
-    return v && strstr(v, token);
+// Measurement aid (tools/step_time.py), never set in a product run: ssd_debug_set_ablate("<tokens>") drops groups of launches
+// from the step so their price INSIDE the overlapped step can be read off (results are wrong by construction; a warning goes
+// to stderr whenever the set changes).  Tokens: pool, tail (conv8_2 ... conv11_2 and the small maps' heads), heads01, conv1,
+// conv5, l2norm, reduce (conv_igemm.hip).
+static std::string g_ablate;
+void set_ablate(const char* tokens) {
+    g_ablate = tokens ? tokens : "";
+    if (!g_ablate.empty())
+        fprintf(stderr, "[ssdvgg_hip] WARNING: ablation '%s' is active: the step SKIPS launches, every result is WRONG (timing aid only)\n",
+                g_ablate.c_str());
 }
+bool ablated(const char* token) { return !g_ablate.empty() && g_ablate.find(token) != std::string::npos; }
 static bool op_ablated(const std::string& name, int kind, int head, int k) {
-    if (!getenv("SSD_ABLATE")) return false;
+    if (g_ablate.empty()) return false;
     if (kind == 1) return k == 2 && ablated("pool");
     if (kind == 2) return ablated("l2norm");
     if (head >= 2) return ablated("tail");
@@ -213,98 +218,44 @@ static int env_i(const char* name, int dflt) {
 //    all of them sat behind conv11_2, and because the heads of a lane share one in-order side stream whose first entry
 //    (head 0) needs the l2-norm, the six heads ran back to back AFTER the trunk on a nearly empty chip: 340 us of a
 //    7.47 ms bf16 step with fewer than 256 workgroups in flight (profiles/r04_a_timeline_bf16.txt; fp32: 0.6 ms).
-//  * Backward: REVERSE GRAPH ORDER by default.  SSD_BW_ORDER=1 selects the alternative built here -- the latency-bound chain
-//    (small heads' data gradients -> conv11_2 ... conv8_2, what the first big data gradient waits for, and whose launches queue
-//    for LDS behind whatever fills the CUs beside them: gaps of 35-40 us between two chain kernels in the same trace) first;
-//    head 1's data gradient (main stream) gated behind a point of the chain (SSD_BW_HEAD1_POS chain ops, default: its end);
-//    head 0's data gradient and the l2-norm backward deferred to the side stream beside mod_conv6's data gradient.  Measured:
-//    the chain shrinks from 450 to 264 us and the STEP grows from 7.22 to 7.37 ms (profiles/r04_g_ab_schedule_bf16.txt): what
-//    ran beside the chain on an otherwise empty chip now runs beside the big data gradients on a full one.  Kept as a switch;
-//    the bookkeeping below (bw_need / bw_sync / bw_final_lo) serves any valid order.
-// SSD_FWD_ORDER=0 restores graph order in forward (A/B switch).
+//  * Backward: reverse graph order.  (Round 4 built and measured an alternative -- the latency-bound chain of small heads and
+//    extra layers first, head 0 + l2-norm deferred beside mod_conv6: chain 450 -> 264 us, step 7.22 -> 7.37 ms,
+//    profiles/r04_g_ab_schedule_bf16.txt -- removed in round 5; the bookkeeping below (bw_need / bw_sync / bw_final_lo) still
+//    serves any valid order.)
 void Net::build_orders() {
     const int n = (int)ops_.size();
     fwd_order_.clear();
-    if (env_i("SSD_FWD_ORDER", 1) == 0) {
-        for (int i = 0; i < n; ++i) fwd_order_.push_back(i);
-    } else {
-        std::vector<char> placed(n, 0);
-        std::vector<int> stack;
-        for (int i0 = 0; i0 < n; ++i0) {
-            if (placed[i0]) continue;
-            stack.assign(1, i0);
-            while (!stack.empty()) {
-                const int i = stack.back();
-                stack.pop_back();
-                if (placed[i]) continue;
-                placed[i] = 1;
-                fwd_order_.push_back(i);
-                for (int j = n - 1; j > i; --j)      // (pushed in reverse: popped in graph order)
-                    if (!placed[j] && ops_[j].in == ops_[i].out && (ops_[j].kind == OP_L2NORM || ops_[j].head >= 0)) stack.push_back(j);
-            }
+    std::vector<char> placed(n, 0);
+    std::vector<int> stack;
+    for (int i0 = 0; i0 < n; ++i0) {
+        if (placed[i0]) continue;
+        stack.assign(1, i0);
+        while (!stack.empty()) {
+            const int i = stack.back();
+            stack.pop_back();
+            if (placed[i]) continue;
+            placed[i] = 1;
+            fwd_order_.push_back(i);
+            for (int j = n - 1; j > i; --j)      // (pushed in reverse: popped in graph order)
+                if (!placed[j] && ops_[j].in == ops_[i].out && (ops_[j].kind == OP_L2NORM || ops_[j].head >= 0)) stack.push_back(j);
         }
     }
     bwd_order_.clear();
-    bw_gate_op_ = -1;
-    std::vector<int> R;
-    for (int i = n - 1; i >= 0; --i) R.push_back(i);
-    int h0 = -1, h1 = -1, l2 = -1;
-    for (int i = 0; i < n; ++i) {
-        if (ops_[i].kind == OP_CONV && ops_[i].head == 0) h0 = i;
-        if (ops_[i].kind == OP_CONV && ops_[i].head == 1) h1 = i;
-        if (ops_[i].kind == OP_L2NORM) l2 = i;
-    }
-    if (env_i("SSD_BW_ORDER", 0) == 0 || h0 < 0 || h1 < 0 || l2 < 0) {
-        bwd_order_ = R;
-        return;
-    }
-    std::vector<int> small, tail, rest;
-    for (int i : R) {
-        const Op& op = ops_[i];
-        if (i == h0 || i == h1 || i == l2) continue;
-        if (op.kind == OP_CONV && op.head >= 2) small.push_back(i);
-        else if (op.kind == OP_CONV && op.head < 0 && i > tail_first_) tail.push_back(i);
-        else rest.push_back(i);
-    }
-    int k = env_i("SSD_BW_HEAD1_POS", (int)tail.size());
-    k = std::max(0, std::min(k, (int)tail.size()));
-    bwd_order_ = small;
-    for (int j = 0; j < k; ++j) bwd_order_.push_back(tail[j]);
-    bwd_order_.push_back(h1);
-    if (k > 0) bw_gate_op_ = h1;
-    for (int j = k; j < (int)tail.size(); ++j) bwd_order_.push_back(tail[j]);
-    bool deferred = false;
-    const bool defer = env_i("SSD_BW_DEFER_HEAD0", 1) != 0;
-    if (!defer) { bwd_order_.push_back(h0); bwd_order_.push_back(l2); deferred = true; }
-    for (int i : rest) {
-        bwd_order_.push_back(i);
-        if (!deferred && ops_[i].out == ops_[h1].in) {      // behind the producer of head 1's feature map (mod_conv7)
-            bwd_order_.push_back(h0);
-            bwd_order_.push_back(l2);
-            deferred = true;
-        }
-    }
-    SSD_REQUIRE(deferred && (int)bwd_order_.size() == n, "backward order construction failed");
+    for (int i = n - 1; i >= 0; --i) bwd_order_.push_back(i);
 }
 
 // stream class of an op's data gradient in backward: 0 = main stream, 1 = side stream (see build_orders)
 int Net::bw_class(const Op& op, int op_index) const {
-    static const bool bw_side_on = env_i("SSD_BW_SIDE", 1) != 0;      // A/B switch
-    static const bool defer = env_i("SSD_BW_ORDER", 0) != 0 && env_i("SSD_BW_DEFER_HEAD0", 1) != 0;
-    if (!(hstream_ && overlap_ && bw_side_on)) return 0;
+    if (!(hstream_ && overlap_)) return 0;
     if (op.kind == OP_CONV && op.head >= 2) return 1;                              // small maps' heads: a few workgroups each
     if (op.kind == OP_CONV && op.head < 0 && op_index > tail_first_) return 1;     // conv11_2 ... conv8_2 behind them
-    if (defer && ((op.kind == OP_CONV && op.head == 0) || op.kind == OP_L2NORM)) return 1;
     return 0;
 }
 
 void Net::bw_sync(int x, int y) {
-    for (int li = 0; li < bw_nl_; ++li) {
-        const BwLane& ln = bw_lane_[li];
-        hipEvent_t ev = y == 1 ? ln.ev_h : ev_m2s_[li];
-        HIP_OK(hipEventRecord(ev, y == 1 ? ln.h : ln.s));
-        HIP_OK(hipStreamWaitEvent(x == 1 ? ln.h : ln.s, ev, 0));
-    }
+    hipEvent_t ev = y == 1 ? ev_h_ : ev_m2s_;
+    HIP_OK(hipEventRecord(ev, y == 1 ? hstream_ : stream_));
+    HIP_OK(hipStreamWaitEvent(x == 1 ? hstream_ : stream_, ev, 0));
     bw_seen_[x][y] = bw_issued_[y];
 }
 
@@ -316,6 +267,52 @@ size_t Net::bw_final_lo() const {
         lo = ops_[i].w_off;      // conv ops own descending, adjacent filter ranges
     }
     return lo;
+}
+
+// Pool fusion (round 5).  A 2x2 stride-2 pool whose input has no other consumer (pool1-3: conv4_3 also feeds the l2-norm) is
+// pure HBM traffic between two convolutions: forward reads the producer's output once more to write a quarter of it, backward
+// reads the consumer's data gradient once more to write four times as much.  Where the kernels support it
+//  * the PRODUCER's forward epilogue takes the maxima and writes the pooled tensor and the pool's record; its own output is
+//    then never written -- nothing reads it in backward either (the record carries the argmax and the relu sign);
+//  * the CONSUMER's data gradient scatters through the record straight into the producer's output gradient.
+// SSD_POOL_FUSE: bit 0 forward, bit 1 backward (default 3; 0 = the separate pool kernels, the A/B and the bit-identity check).
+void Net::plan_pool_fusion() {
+    const int mode = env_i("SSD_POOL_FUSE", 3);      // (read per handle: the tests build a fused and an unfused handle in one process)
+    for (int i = 0; i < (int)ops_.size(); ++i) {
+        Op& pl = ops_[i];
+        if (pl.kind != OP_POOL) continue;
+        const Tensor& in = tensors_[pl.in];
+        const Tensor& out = tensors_[pl.out];
+        PoolDesc pd{Bmax_, in.H, in.W, in.C, out.H, out.W, pl.k, pl.stride, pl.pad_h, pl.pad_w};
+        if (!maxpool_rec_applicable(pd) || in.consumers != 1 || out.consumers != 1) continue;
+        int prod = -1, cons = -1;
+        for (int j = 0; j < (int)ops_.size(); ++j) {
+            if (ops_[j].out == pl.in) prod = j;
+            if (ops_[j].in == pl.out) cons = j;
+        }
+        if (prod < 0 || cons < 0 || ops_[prod].kind != OP_CONV || ops_[cons].kind != OP_CONV) continue;
+        if (!ops_[prod].relu || ops_[prod].head >= 0) continue;
+        const ConvDesc dp = conv_desc(ops_[prod], Bmax_), dc = conv_desc(ops_[cons], Bmax_);
+        const bool in_bf16 = bf16_ && !tensors_[ops_[prod].in].data_f32;
+        if ((mode & 1) && (bf16_ ? (in_bf16 && conv_fwd_pool_bf16_supported(dp)) : conv_fwd_pool_supported(dp))) {
+            ops_[prod].pool_after = i;
+            pl.fused_fwd = true;
+        }
+        if ((mode & 2) && training_ && pl.pool_rec && (bf16_ ? conv_dgrad_unpool_bf16_supported(dc) : conv_dgrad_unpool_supported(dc))) {
+            ops_[cons].unpool = i;
+            pl.fused_bwd = true;
+        }
+    }
+}
+
+void Net::pool_fusion(int* out, int cap, int* count) const {
+    int k = 0;
+    for (const Op& op : ops_)
+        if (op.kind == OP_POOL && op.k == 2 && op.stride == 2) {
+            if (out && k < cap) out[k] = (op.fused_fwd ? 1 : 0) | (op.fused_bwd ? 2 : 0);
+            ++k;
+        }
+    if (count) *count = k;
 }
 
 size_t Net::arena_floats(const char* preset, int num_classes) {
@@ -409,9 +406,8 @@ void Net::alloc() {
             }
         pool_ws_ = dalloc(pws);
         // 2x2 pools whose input has no other consumer keep a forward record for their backward (ops.h)
-        static const bool use_rec = [] { const char* v = getenv("SSD_POOL_RECORD"); return !(v && v[0] == '0'); }();      // A/B switch
         for (auto& op : ops_)
-            if (op.kind == OP_POOL && use_rec) {
+            if (op.kind == OP_POOL) {
                 const Tensor& in = tensors_[op.in];
                 const Tensor& out = tensors_[op.out];
                 PoolDesc d{B, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
@@ -487,10 +483,9 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     HIP_OK(hipEventCreateWithFlags(&ev_cast_, hipEventDisableTiming));
 
     HIP_OK(hipEventCreateWithFlags(&ev2_h_, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&ev2_dy_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_l2_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ev_m2s_[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_m2s_, hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev2_fmap_[i], hipEventDisableTiming));
     for (int i = 0; i < MAX_MAPS; ++i) HIP_OK(hipEventCreateWithFlags(&ev_fmap_[i], hipEventDisableTiming));
     if (training_) {
@@ -503,23 +498,16 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     // order.  Measured (gpurun r02_v / r02_w, bf16 step): every stream on its own queue (8 queues) 3075 images/s, the
     // default four queues 4016 (and 3850 for a net created after others in the same process), four STREAMS 4080-4120
     // whatever the queue count.  The second forward lane and the weight gradients are never busy at the same time
-    // (forward / backward), so they are ONE stream.  (SSD_LANE_STREAM=own restores the fifth stream for the A/B.)
-    // SSD_LANE_STREAM: "own" = five streams (A/B), "heads" = four (the second lane keeps a side stream for its heads),
-    // default = THREE: the second lane runs its heads on its own main stream as well, which measures the same as four
-    // (bf16 4142 vs 4081 images/s, r02_w) and leaves the fourth queue to a data-parallel caller's collective stream.
-    static const char lane_mode = [] { const char* v = getenv("SSD_LANE_STREAM"); return v ? v[0] : 'd'; }();
-    if (training_ && lane_mode != 'o') {
+    // (forward / backward), so they are ONE stream, and the second lane runs its heads on its own main stream as well: THREE
+    // streams beside the caller's measure the same as four (bf16 4142 vs 4081 images/s, r02_w) and leave the fourth queue to
+    // a data-parallel caller's collective stream.
+    if (training_) {
         s2_ = wstream_;
         s2_is_w_ = true;
     } else {
         HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     }
-    if (lane_mode == 'o' || lane_mode == 'h') {
-        HIP_OK(hipStreamCreateWithFlags(&h2_, hipStreamNonBlocking));
-    } else {
-        h2_ = s2_;
-        h2_is_s2_ = true;
-    }
+    plan_pool_fusion();
 }
 
 Net::~Net() {
@@ -538,12 +526,10 @@ Net::~Net() {
         (void)hipEventDestroy(ev_h_);
         (void)hipEventDestroy(ev_cast_);
         if (!s2_is_w_) (void)hipStreamDestroy(s2_);
-        if (!h2_is_s2_) (void)hipStreamDestroy(h2_);
         (void)hipEventDestroy(ev2_h_);
-        (void)hipEventDestroy(ev2_dy_);
         (void)hipEventDestroy(ev_l2_);
         (void)hipEventDestroy(ev_join_);
-        for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev_m2s_[i]);
+        (void)hipEventDestroy(ev_m2s_);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev2_fmap_[i]);
         for (int i = 0; i < MAX_MAPS; ++i) (void)hipEventDestroy(ev_fmap_[i]);
     }
@@ -563,7 +549,7 @@ Net::~Net() {
 // steps
 // ---------------------------------------------------------------------------------
 // Forward runs the op list on up to two LANES: the batch is cut in two halves that walk the network side by side (lane 0
-// on the caller's stream + the side stream for its heads, lane 1 on s2_ / h2_, which by default are both the
+// on the caller's stream + the side stream for its heads, lane 1 with its heads on s2_, which is the
 // weight-gradient stream: see the constructor), so that the tail of one half's kernel (its last, partial round of workgroups) is filled by the other half's
 // kernel instead of idle CUs.  Measured on one box (SSD_FWD_LANES=1 / 2, gpurun r02): training step +0.5 % fp32 and
 // +2.7 % bf16, inference at batch 128 +1.6 %.  Nothing in forward couples the samples except the loss's final
@@ -576,11 +562,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     static const int lanes_env = [] { const char* v = getenv("SSD_FWD_LANES"); return v ? atoi(v) : 0; }();
     const int want_lanes = lanes_env > 0 ? lanes_env : 2;
     const int nl = (want_lanes >= 2 && side && s2_ && b >= 8) ? 2 : 1;
-    // A/B switch: with two lanes the multibox heads run as full-batch launches (see the head ops below)
-    static const bool heads_full_on = env_i("SSD_HEADS_FULL", 1) != 0;
-    const bool heads_full = heads_full_on && nl == 2;
-    static const long long merge_m = env_i("SSD_FWD_MERGE_M", 0);      // A/B switch, default OFF (0 = the lanes never merge; 12000 = at the 19x19 maps)
-    int nl_cur = nl;
+    const bool heads_full = nl == 2;      // with two lanes the multibox heads run as full-batch launches (see the head ops below)
     struct Lane {
         hipStream_t s, h;
         hipEvent_t* ev_fmap;
@@ -588,7 +570,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         int b0, nb;
         bool heads_on_side, cast_pending;
     } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false},
-                 {s2_, h2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false}};
+                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false}};
     auto at = [](const Tensor& t, int b0, bool grad = false) -> char* {      // first element of sample b0
         return static_cast<char*>(grad ? t.grad : t.data) + (size_t)b0 * t.per_image() * ((grad ? t.grad_f32 : t.data_f32) ? 4 : 2);
     };
@@ -633,19 +615,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         const Tensor& out = tensors_[op.out];
         prof_.layer = op.name.c_str();
         if (op_ablated(op.name, op.kind, op.head, op.k)) continue;
-        // Optional (SSD_FWD_MERGE_M, default off): the lanes MERGE where the trunk gets small (the 19x19 maps and below at
-        // batch 32).  There a half-batch launch takes as long as the full batch's when it runs alone -- conv5_2 forward 52 us
-        // at batch 16, 61 us at batch 32; mod_conv7 22 / 39 (profiles/r04_f_tile_sweep_19x19_bf16.txt) -- so two lanes looked
-        // like paying the layer twice.  Measured in the step (three interleaved rounds on one box,
-        // profiles/r04_g_ab_schedule_bf16.txt) the merged tail is SLOWER: 7.325 vs 7.274 ms -- side by side the two lanes' kernels
-        // fill each other's partial rounds, which is what the lanes are for.  Kept as a switch.
-        if (nl_cur == 2 && heads_full && op.head < 0 && op.kind != OP_L2NORM && (long long)b * out.H * out.W <= merge_m) {
-            HIP_OK(hipEventRecord(ev_join_, s2_));
-            HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
-            lane[0].nb = b;
-            nl_cur = 1;
-        }
-        for (int li = 0; li < nl_cur; ++li) {
+        for (int li = 0; li < nl; ++li) {
             Lane& ln = lane[li];
             const int nb = ln.nb;
             switch (op.kind) {
@@ -660,8 +630,8 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                         // ONE launch over the whole batch on lane 0's side stream, behind both lanes' feature maps: half the
                         // launches, twice the workgroups each, and lane 1's trunk (whose own "side" stream is its main
                         // stream) does not queue behind its heads
-                        if (li < nl_cur - 1) break;
-                        for (int l = 0; l < nl_cur; ++l) HIP_OK(hipStreamWaitEvent(hstream_, lane[l].ev_fmap[op.head], 0));
+                        if (li < nl - 1) break;
+                        for (int l = 0; l < nl; ++l) HIP_OK(hipStreamWaitEvent(hstream_, lane[l].ev_fmap[op.head], 0));
                         cs = hstream_;
                         run_nb = b; run_b0 = 0;
                         lane[0].heads_on_side = true;
@@ -675,13 +645,28 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 struct LanesScope {      // (tile choice of the bf16 kernel-row gather: the lanes share the chip's workgroup slots)
                     LanesScope(int n) { g_conv_lanes = n; }
                     ~LanesScope() { g_conv_lanes = 1; }
-                } lanes_scope(run_nb == nb ? nl_cur : 1);
+                } lanes_scope(run_nb == nb ? nl : 1);
                 if (ln.cast_pending && !in.data_f32) {
                     HIP_OK(hipStreamWaitEvent(ln.s, ev_cast_, 0));
                     ln.cast_pending = false;
                 }
                 const float* xin = reinterpret_cast<const float*>(at(in, run_b0));
                 void* yout = at(out, run_b0);
+                if (op.pool_after >= 0) {
+                    // Pool fusion (round 5): this conv's epilogue takes the 2x2 maxima itself and writes the POOLED tensor (+ the
+                    // pool's 12-bit record in training); its own output has no other reader -- forward or backward -- and is
+                    // never written (plan_pool_fusion)
+                    const Op& pl = ops_[op.pool_after];
+                    const Tensor& pt = tensors_[pl.out];
+                    void* rec = (pl.pool_rec && train_mode)
+                                    ? static_cast<char*>(pl.pool_rec) + (size_t)run_b0 * pt.H * pt.W * (pt.C / 4) * sizeof(unsigned short) : nullptr;
+                    if (!bf16_)
+                        conv_fwd_pool(d, xin, params_ + op.w_off, params_ + op.b_off, reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
+                    else
+                        conv_fwd_pool_bf16(d, reinterpret_cast<const bf16_t*>(xin), wq_oi_ + op.w_off, params_ + op.b_off,
+                                           reinterpret_cast<bf16_t*>(at(pt, run_b0)), rec, cs);
+                    break;
+                }
                 if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
                 else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
@@ -693,6 +678,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 break;
             }
             case OP_POOL: {
+                if (op.fused_fwd) break;      // written by its producer's epilogue
                 PoolDesc d{nb, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
                 if (op.pool_rec && train_mode) {
                     void* rec = static_cast<char*>(op.pool_rec) + (size_t)ln.b0 * out.H * out.W * (in.C / 4) * sizeof(unsigned short);
@@ -761,17 +747,9 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
 // start all-reducing finished gradient ranges while the rest of backward still runs: filters sit
 // in the arena in forward order, so reverse execution completes them from the END of the filter
 // region towards its beginning, always as one contiguous, growing suffix.
-// The data-gradient chain CAN run on the same two lanes as forward (SSD_BWD_LANES=2: half batches on two sets of streams;
-// a layer's data gradient, pooling backward and the loss gradient are per-sample work, while what couples the samples
-// stays ONE full-batch launch: every weight gradient, on the weight-gradient stream after both lanes' dy, and the l2-norm
-// backward, whose scale gradient sums over the batch).  Default is ONE lane: backward already has the weight-gradient
-// stream filling the data gradients' tails, a third concurrent half-batch kernel only shrinks the tiles' reuse --
-// measured on one box (profiles/r02_l_ab_bwd_lanes_*.txt): fp32 -0.3 %, bf16 -7 %.
-bool Net::defers_head_wgrads() const {
-    static const bool on = env_i("SSD_BW_DEFER_HEAD_WGRAD", 0) != 0;      // default OFF: measured 7.456 vs 7.325 ms (r04_g)
-    return on && wstream_ && overlap_ && tail_first_ + 1 < (int)ops_.size() && bw_class(ops_[tail_first_ + 1], tail_first_ + 1) == 1;
-}
-
+// The data-gradient chain is ONE lane (rounds 2-4 also carried a two-lane form, half batches on two sets of streams:
+// fp32 -0.3 %, bf16 -7 %, profiles/r02_l_ab_bwd_lanes_*.txt -- backward already has the weight-gradient stream filling the
+// data gradients' tails; removed in round 5).
 void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
     const Op& op = ops_[op_index];
     const Tensor& in = tensors_[op.in];
@@ -791,53 +769,18 @@ void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
     }
 }
 
-// the heads' weight gradients held back by backward_step: behind everything the lanes' main streams have been given (their dy
-// is the loss gradient), in the order they were met
-void Net::flush_deferred_wgrads() {
-    if (bw_deferred_.empty()) return;
-    for (int li = 0; li < bw_nl_; ++li) {
-        HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, bw_lane_[li].s));
-        HIP_OK(hipStreamWaitEvent(wstream_, bw_lane_[li].ev_dy, 0));
-    }
-    const char* layer = prof_.layer;
-    for (int i : bw_deferred_) {
-        launch_wgrad(i, bw_b_, wstream_);
-        bw_conv_done_[i] = 1;
-    }
-    prof_.layer = layer;
-    bw_deferred_.clear();
-}
-
 void Net::backward_begin(int b, const float* y) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
     g_prof = &prof_;
     prof_.layer = "loss";
     const bool side = hstream_ && overlap_;
-    static const int lanes_env = [] { const char* v = getenv("SSD_BWD_LANES"); return v ? atoi(v) : 0; }();
-    const int want_lanes = lanes_env > 0 ? lanes_env : 1;
-    bw_nl_ = (want_lanes >= 2 && side && s2_ && b >= 8) ? 2 : 1;
-    bw_lane_[0] = BwLane{stream_, hstream_, ev_dy_, ev_h_, 0, bw_nl_ == 2 ? (b + 1) / 2 : b};
-    bw_lane_[1] = BwLane{s2_, h2_, ev2_dy_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2};
-    const int A = preset_->num_anchors, nv = C_ + 5;
-    if (bw_nl_ == 2) {      // lane 1 starts behind everything issued on the main stream so far (forward, the loss)
-        HIP_OK(hipEventRecord(ev_join_, stream_));
-        HIP_OK(hipStreamWaitEvent(s2_, ev_join_, 0));
-    }
     for (Tensor& t : tensors_) { t.done = 0; t.gstream = 0; t.gseq = 0; }
     bw_issued_[0] = bw_issued_[1] = 0;
     bw_seen_[0][0] = bw_seen_[0][1] = bw_seen_[1][0] = bw_seen_[1][1] = 0;
-    for (int li = 0; li < bw_nl_; ++li) {
-        const BwLane& ln = bw_lane_[li];
-        HeadLayout hl = heads_;
-        for (int i = 0; i < hl.nmaps; ++i)
-            hl.dbuf[i] = static_cast<char*>(heads_.dbuf[i]) + (size_t)ln.b0 * hl.hw[i] * hl.ld[i] * (hl.grad_bf16 ? 2 : 4);
-        multibox_loss_grad(hl, ln.nb, ln.b0, result_ + (size_t)ln.b0 * A * nv, y + (size_t)ln.b0 * A * nv, lw_, ln.s);
-    }
-    for (int t : head_t_) bw_wrote(0, tensors_[t]);      // the loss gradient, on the lanes' main streams
-    if (side) bw_sync(1, 0);      // the side streams start behind it (the small maps' head data gradients: backward_step)
+    multibox_loss_grad(heads_, b, 0, result_, y, lw_, stream_);
+    for (int t : head_t_) bw_wrote(0, tensors_[t]);      // the loss gradient, on the main stream
+    if (side) bw_sync(1, 0);      // the side stream starts behind it (the small maps' head data gradients: backward_step)
     bw_conv_done_.assign(ops_.size(), 0);
-    bw_deferred_.clear();
-    bw_chain_done_ = false;
     bw_first_on_main_ = false;
     bw_pos_ = 0;
     bw_b_ = b;
@@ -849,23 +792,6 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     const size_t hi = bw_done_off_;
     size_t lo = hi;
     bool side_used = false;
-    bw_lane_[0].s = stream_;      // (a caller may have moved the handle to another stream between two stages)
-    // A/B switch, default off: one grouped reduce per ~6 layers measured -0.7 % on the bf16 step, +-0 in fp32 (gpurun
-    // r02_h): the per-layer reduces hide behind the next layer's data gradient, a grouped one is long enough to be exposed
-    static const bool grouped = [] { const char* v = getenv("SSD_REDUCE_GROUPED"); return v && v[0] == '1'; }();
-    struct BatchScope {      // queue this stage's slab reduces (conv.h ReduceBatch); flushed below as one launch
-        ReduceBatch* prev;
-        BatchScope(ReduceBatch* b) : prev(g_reduce_batch) { g_reduce_batch = b; }
-        ~BatchScope() { g_reduce_batch = prev; }
-    } batch_scope(grouped ? &reduce_batch_ : nullptr);
-    reduce_batch_.items.clear();
-    auto at = [](const Tensor& t, int b0, bool grad) -> char* {      // first element of sample b0
-        return static_cast<char*>(grad ? t.grad : t.data) + (size_t)b0 * t.per_image() * ((grad ? t.grad_f32 : t.data_f32) ? 4 : 2);
-    };
-    // A/B switch: the first layer's weight gradient (no data gradient behind it: the main stream has gone idle by then) runs
-    // on the MAIN stream beside conv1_2's weight gradient instead of queueing behind it -- both are HBM-bound at half the
-    // achievable bandwidth (profiles/r04_a_timeline_bf16.txt: 7013 .. 7391 us of the step ran one such kernel at a time)
-    static const bool first_main = [] { const char* v = getenv("SSD_BW_FIRST_ON_MAIN"); return !(v && v[0] == '0'); }();
     const int n_order = (int)bwd_order_.size();
     while (bw_pos_ < n_order && hi - lo < min_floats) {
         const int op_index = bwd_order_[bw_pos_++];
@@ -875,142 +801,95 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         const bool need_dx = op.in != input_t_;
         const bool last = in.done + 1 == in.consumers;
         prof_.layer = op.name.c_str();
-        // Where this op's data gradient runs (build_orders / bw_class): the small maps' heads, the chain of extra layers behind
-        // them and -- deferred -- head 0 with the l2-norm backward on the lanes' side streams, everything else on their main
-        // streams.  Hand-offs between the two are events placed where a kernel reads or accumulates into a gradient that the
-        // other class wrote last (bw_need): conv8_1 joins the chain, pool4's backward joins the deferred pair.
+        // Where this op's data gradient runs (bw_class): the small maps' heads and the chain of extra layers behind them on the
+        // side stream, everything else on the main stream.  Hand-offs between the two are events placed where a kernel reads
+        // or accumulates into a gradient that the other class wrote last (bw_need): conv8_1 joins the chain.
         const int cls = bw_class(op, op_index);
+        hipStream_t ds = cls == 1 ? hstream_ : stream_;
         if (op_ablated(op.name, op.kind, op.head, op.k)) {
             if (op.kind == OP_CONV) { bw_conv_done_[op_index] = 1; lo = bw_final_lo(); }
             in.done++;
             continue;
         }
-        if (op_index == bw_gate_op_ && cls == 0 && bw_issued_[1] > bw_seen_[0][1]) bw_sync(0, 1);
         switch (op.kind) {
         case OP_CONV: {
             const ConvDesc d = conv_desc(op, b);
             // The weight gradient only feeds the optimizer; the data gradient is on the critical
             // path.  They read the same dy and write disjoint buffers, so the weight gradient goes
             // to a side stream: its workgroups fill the CUs the data-gradient's last partial wave
-            // of workgroups leaves idle (and vice versa).  It is ONE launch over the whole batch: it waits for the dy
-            // of every lane, on the stream class that wrote it.
+            // of workgroups leaves idle (and vice versa).
+            // The first layer's weight gradient (no data gradient behind it: the main stream has gone idle by then) runs on the
+            // MAIN stream beside conv1_2's weight gradient instead of queueing behind it -- both are HBM-bound at half the
+            // achievable bandwidth (profiles/r04_a_timeline_bf16.txt: 7013 .. 7391 us of the step ran one such kernel at a time)
             const bool side = wstream_ && overlap_;
-            const bool on_main = side && !need_dx && first_main && bw_nl_ == 1;
+            const bool on_main = side && !need_dx;
             hipStream_t ws = (side && !on_main) ? wstream_ : stream_;
-            float* slab = wgrad_ws_ + op.ws_off;
-            // Optional (SSD_BW_DEFER_HEAD_WGRAD=1, default off): the heads' weight gradients (one-round kernels of up to 252
-            // workgroups x 136 KB of LDS that live for 60-80 us) held back until the latency-bound chain behind the small heads
-            // has been ISSUED: beside it they take every CU's LDS and a chain kernel of a handful of workgroups waits tens of
-            // microseconds for a slot (profiles/r04_d_timeline_bf16.txt: a 4-workgroup launch "running" for 67 us).  The chain
-            // does get shorter, the step does not (+1.8 %): the held-back kernels then run beside conv8_1 / mod_conv7 / mod_conv6's
-            // data gradients on a full chip instead of beside the chain on an empty one.  Flushed at conv8_1.
-            const bool defer_w = op.head >= 0 && !bw_chain_done_ && defers_head_wgrads();
-            if (op_index == tail_first_) {      // conv8_1: the chain has been issued
-                bw_chain_done_ = true;
-                if (!bw_deferred_.empty()) { flush_deferred_wgrads(); side_used = true; }
-            }
-            if (defer_w) {
-                // (nothing to wait for yet: flush_deferred_wgrads orders the launch behind the main streams)
-            } else if (side && !on_main) {
-                // (dy written on the main streams but already waited for by the side streams, and this op lives there: the
-                // side stream is the one that is less far ahead -- head 0's weight gradient need not wait for mod_conv7)
+            if (side && !on_main) {
+                // (dy written on the main stream but already waited for by the side stream, and this op lives there: the
+                // side stream is the one that is less far ahead -- a small head's weight gradient need not wait for mod_conv7)
                 const bool from_side = out.gstream == 1 || (cls == 1 && bw_seen_[1][0] >= out.gseq);
-                for (int li = 0; li < bw_nl_; ++li) {
-                    HIP_OK(hipEventRecord(bw_lane_[li].ev_dy, from_side ? bw_lane_[li].h : bw_lane_[li].s));
-                    HIP_OK(hipStreamWaitEvent(wstream_, bw_lane_[li].ev_dy, 0));
-                }
+                HIP_OK(hipEventRecord(ev_dy_, from_side ? hstream_ : stream_));
+                HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
                 side_used = true;
             } else {
                 bw_need(0, out);
                 if (on_main) bw_first_on_main_ = true;
             }
-            const bool mask = last && in.relu_out;
-            if (defer_w) bw_deferred_.push_back(op_index);
-            else launch_wgrad(op_index, b, ws);
+            launch_wgrad(op_index, b, ws);
             if (need_dx) {
                 bw_need(cls, out);
-                if (in.done > 0) bw_need(cls, in);      // accumulates into what the other class wrote
-                for (int li = 0; li < bw_nl_; ++li) {
-                    const BwLane& ln = bw_lane_[li];
-                    const ConvDesc dl = conv_desc(op, ln.nb);
-                    hipStream_t ds = cls == 1 ? ln.h : ln.s;
-                    if (!bf16_)
-                        conv_dgrad(dl, reinterpret_cast<const float*>(at(out, ln.b0, true)), params_ + op.w_off,
-                                   reinterpret_cast<float*>(at(in, ln.b0, true)), mask ? reinterpret_cast<const float*>(at(in, ln.b0, false)) : nullptr,
-                                   in.done > 0, ds);
-                    else
-                        conv_dgrad_bf16(dl, reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)), wq_io_ + op.w_off,
-                                        reinterpret_cast<bf16_t*>(at(in, ln.b0, true)),
-                                        mask ? reinterpret_cast<const bf16_t*>(at(in, ln.b0, false)) : nullptr, in.done > 0, ds);
+                // Pool fusion (round 5): when this conv reads a recorded 2x2 pool's output, its data gradient routes every
+                // pooled pixel's dx through the record straight into the four cells of the POOL'S INPUT gradient (relu mask of
+                // that tensor's producer included, from the record's sign bit): the pooled tensor's own gradient is never
+                // written and the pool's backward pass is not launched.
+                const Op* up = op.unpool >= 0 ? &ops_[op.unpool] : nullptr;
+                Tensor& dst = up ? tensors_[up->in] : in;
+                if (!up && in.done > 0) bw_need(cls, in);      // accumulates into what the other class wrote
+                const bool mask = !up && last && in.relu_out;
+                if (!bf16_) {
+                    if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
+                    else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
+                } else {
+                    if (up) conv_dgrad_unpool_bf16(d, out.gh(), wq_io_ + op.w_off, dst.gh(), up->pool_rec, dst.H, dst.W, ds);
+                    else conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
                 }
-                bw_wrote(cls, in);
+                bw_wrote(cls, dst);
             }
-            if (!defer_w) bw_conv_done_[op_index] = 1;
+            bw_conv_done_[op_index] = 1;
             lo = bw_final_lo();
-            // a handful of layers per grouped reduce: few launches, yet interleaved with the data gradients instead of
-            // one long pass after the last layer (which nothing would hide)
-            if (reduce_batch_.items.size() >= 6) wgrad_reduce_flush(reduce_batch_, ws);
             break;
         }
-        case OP_POOL:
+        case OP_POOL: {
+            if (op.fused_bwd) break;      // its consumer's data gradient has already written in.grad through the record
             bw_need(0, out);
             if (in.done > 0) bw_need(0, in);
-            for (int li = 0; li < bw_nl_; ++li) {
-                const BwLane& ln = bw_lane_[li];
-                PoolDesc d{ln.nb, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
-                const size_t win = (size_t)ln.b0 * out.H * out.W * (in.C / 4);        // windows x 4 channels before this lane
-                void* pws = maxpool_bwd_ws_bytes(d) ? static_cast<char*>(pool_ws_) + win * sizeof(unsigned) : nullptr;
-                if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
-                    const void* rec = static_cast<const char*>(op.pool_rec) + win * sizeof(unsigned short);
-                    if (bf16_) maxpool_bwd_rec(d, rec, reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)), reinterpret_cast<bf16_t*>(at(in, ln.b0, true)), in.relu_out, ln.s);
-                    else maxpool_bwd_rec(d, rec, reinterpret_cast<const float*>(at(out, ln.b0, true)), reinterpret_cast<float*>(at(in, ln.b0, true)), in.relu_out, ln.s);
-                } else if (bf16_)
-                    maxpool_bwd(d, reinterpret_cast<const bf16_t*>(at(in, ln.b0, false)), reinterpret_cast<const bf16_t*>(at(out, ln.b0, true)),
-                                reinterpret_cast<bf16_t*>(at(in, ln.b0, true)), in.done > 0, last && in.relu_out, pws, ln.s);
-                else
-                    maxpool_bwd(d, reinterpret_cast<const float*>(at(in, ln.b0, false)), reinterpret_cast<const float*>(at(out, ln.b0, true)),
-                                reinterpret_cast<float*>(at(in, ln.b0, true)), in.done > 0, last && in.relu_out, pws, ln.s);
-            }
+            PoolDesc d{b, in.H, in.W, in.C, out.H, out.W, op.k, op.stride, op.pad_h, op.pad_w};
+            void* pws = maxpool_bwd_ws_bytes(d) ? pool_ws_ : nullptr;
+            if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
+                if (bf16_) maxpool_bwd_rec(d, op.pool_rec, out.gh(), in.gh(), in.relu_out, stream_);
+                else maxpool_bwd_rec(d, op.pool_rec, out.gf(), in.gf(), in.relu_out, stream_);
+            } else if (bf16_)
+                maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
+            else
+                maxpool_bwd(d, in.f(), out.gf(), in.gf(), in.done > 0, last && in.relu_out, pws, stream_);
             bw_wrote(0, in);
             break;
+        }
         case OP_L2NORM: {
             SSD_REQUIRE(in.done == 0 && !last, "l2norm backward must be the first of several consumers");
             bw_need(cls, out);
-            // the scale gradient sums over the batch: one launch on lane 0's stream (of this op's class) behind lane 1's head
-            // gradient; lane 1 continues (pool4's backward accumulates into the same tensor) behind it
-            hipStream_t s0 = cls == 1 ? bw_lane_[0].h : bw_lane_[0].s, s1 = cls == 1 ? bw_lane_[1].h : bw_lane_[1].s;
-            if (bw_nl_ == 2) {
-                HIP_OK(hipEventRecord(bw_lane_[1].ev_dy, s1));
-                HIP_OK(hipStreamWaitEvent(s0, bw_lane_[1].ev_dy, 0));
-            }
             if (bf16_)
-                l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, s0);
+                l2norm_bwd(b * in.H * in.W, in.C, in.h(), params_ + scale_off_, out.gh(), in.gh(), grads_ + scale_off_, l2_ws_, ds);
             else
-                l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, s0);
-            if (bw_nl_ == 2) {
-                HIP_OK(hipEventRecord(ev_l2_, s0));
-                HIP_OK(hipStreamWaitEvent(s1, ev_l2_, 0));
-            }
+                l2norm_bwd(b * in.H * in.W, in.C, in.f(), params_ + scale_off_, out.gf(), in.gf(), grads_ + scale_off_, l2_ws_, ds);
             bw_wrote(cls, in);
             break;
         }
         }
         in.done++;
     }
-    if (!reduce_batch_.items.empty()) {
-        prof_.layer = "stage";
-        wgrad_reduce_flush(reduce_batch_, (wstream_ && overlap_) ? wstream_ : stream_);
-    }
     const bool finished = bw_pos_ >= n_order;
-    if (finished && !bw_deferred_.empty()) {
-        flush_deferred_wgrads();
-        lo = bw_final_lo();
-    }
     if (finished && bw_issued_[1] > bw_seen_[0][1]) bw_sync(0, 1);      // (every side-stream result has a main-stream reader: a no-op)
-    if (finished && bw_nl_ == 2) {      // the end of backward: lane 1 joins the main stream
-        HIP_OK(hipEventRecord(ev_join_, s2_));
-        HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
-    }
     // The returned range is final in the weight-gradient stream's order.  Make it final in
     // main-stream order too unless the caller consumes it on the weight-gradient stream itself
     // (sync_main = false keeps the data gradients running ahead); the last stage always joins.
@@ -1021,7 +900,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
     // Overlap switched off (ssd_set_overlap(0) / SSD_OVERLAP_WGRAD=0): the weight gradients ran on the main
     // stream.  A caller that consumes the range on the weight-gradient stream (sync_main = false) must still
     // find it final there, so that stream waits for the main stream instead.  The same holds for the first layer's weight
-    // gradient when it was issued on the main stream (above).
+    // gradient, which is issued on the main stream (above).
     if (wstream_ && !sync_main && (!overlap_ || (finished && bw_first_on_main_))) {
         HIP_OK(hipEventRecord(ev_dy_, stream_));
         HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
@@ -1045,26 +924,12 @@ std::vector<std::pair<size_t, size_t>> Net::backward_ranges(size_t min_floats) c
         return lo;
     };
     size_t hi = nfilters_, pos = 0;
-    const bool defers = defers_head_wgrads();
-    bool chain_done = false;
-    std::vector<int> deferred;
     while (pos < bwd_order_.size()) {
         size_t lo = hi;
         while (pos < bwd_order_.size() && hi - lo < min_floats) {      // exactly backward_step's loop
             const int i = bwd_order_[pos++];
             if (ops_[i].kind != OP_CONV) continue;
-            if (i == tail_first_) {
-                chain_done = true;
-                for (int j : deferred) done[j] = 1;
-                deferred.clear();
-            }
-            if (ops_[i].head >= 0 && !chain_done && defers) deferred.push_back(i);
-            else done[i] = 1;
-            lo = final_lo();
-        }
-        if (pos >= bwd_order_.size() && !deferred.empty()) {
-            for (int j : deferred) done[j] = 1;
-            deferred.clear();
+            done[i] = 1;
             lo = final_lo();
         }
         if (hi > lo) out.emplace_back(lo, hi - lo);
@@ -1079,7 +944,6 @@ void Net::set_wgrad_stream(hipStream_t s) {
     wstream_ = s;
     own_wstream_ = false;
     if (s2_is_w_) s2_ = s;      // the second forward lane lives on the weight-gradient stream
-    if (h2_is_s2_) h2_ = s2_;
 }
 
 void Net::backward(int b, const float* y) {
@@ -1102,39 +966,13 @@ void Net::apply_gradients(float grad_scale) {
     ++global_step;
 }
 
-// backward + update of a single-GPU step with the optimizer overlapped: the filter region of the arena completes from its
-// end (heads, conv11 ... conv1), so once the bulk of it is final its momentum update runs on the weight-gradient stream
-// beside the data gradients of the first layers; only the small remainder (conv1_x / conv2_x filters, biases, scale) is
-// updated after the last layer.  Same arithmetic as backward() + apply_gradients().
+// backward + update of a single-GPU step.  (Rounds 2-4 carried an "early update" of the finished arena suffix on the
+// weight-gradient stream: +-0.1 %, profiles/r02_h -- backward ends with conv1_1's weight gradient alone on that stream, both
+// are HBM-bound, there is nothing for the update to hide behind.  Removed in round 5.)
 void Net::backward_apply(int b, const float* y, float grad_scale) {
     SSD_REQUIRE(training_, "handle was created with training = 0");
-    backward_begin(b, y);
-    const float lr = current_lr();
-    size_t off = 0, count = 0, o2, c2;
-    const bool more = backward_step(nfilters_ / 2, &off, &count, false);
-    // A/B switch, default off: measured +-0.1 % (gpurun r02_h) -- backward ends with conv1_1's weight gradient alone on the
-    // weight-gradient stream, both it and the update are HBM-bound, there is nothing for the update to hide behind
-    static const bool early_on = [] { const char* v = getenv("SSD_EARLY_UPDATE"); return v && v[0] == '1'; }();
-    const bool early = early_on && more && count > 0 && wstream_ && overlap_;
-    if (early) {
-        // the updated filters must no longer be read by a data gradient still running on the main stream
-        HIP_OK(hipEventRecord(ev_dy_, stream_));
-        HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
-        g_prof = &prof_;
-        prof_.layer = "optimizer";
-        momentum_update(params_ + off, mom_ + off, grads_ + off, count, lr, momentum_, grad_scale, wstream_);
-    }
-    if (more)
-        while (backward_step(nparams_, &o2, &c2, true)) {}
-    g_prof = &prof_;
-    prof_.layer = "optimizer";
-    if (early) {
-        if (off > 0) momentum_update(params_, mom_, grads_, off, lr, momentum_, grad_scale, stream_);
-        momentum_update(params_ + nfilters_, mom_ + nfilters_, grads_ + nfilters_, nparams_ - nfilters_, lr, momentum_, grad_scale, stream_);
-    } else {
-        momentum_update(params_, mom_, grads_, nparams_, lr, momentum_, grad_scale, stream_);
-    }
-    ++global_step;
+    backward(b, y);
+    apply_gradients(grad_scale);
 }
 
 void Net::null_gradients_step() {
@@ -1242,9 +1080,16 @@ void Net::activation(const char* name, int b, float* out, size_t count) {
     // "grad:<scope>" returns d(loss)/d(pre-activation) of that layer from the last backward
     const bool want_grad = name && !strncmp(name, "grad:", 5);
     if (want_grad) name += 5;
-    for (const Tensor& t : tensors_) {
+    for (size_t ti = 0; ti < tensors_.size(); ++ti) {
+        const Tensor& t = tensors_[ti];
         if (t.name != name || !t.data) continue;
         SSD_REQUIRE(!want_grad || t.grad != nullptr, "no gradient storage (training = 0?)");
+        for (const Op& op : ops_) {
+            SSD_REQUIRE(!(op.kind == OP_POOL && op.fused_fwd && op.in == (int)ti && !want_grad),
+                        "activation %s is not materialised: its 2x2 pool is fused into the convolution (SSD_POOL_FUSE=0 keeps it)", name);
+            SSD_REQUIRE(!(op.kind == OP_POOL && op.fused_bwd && op.out == (int)ti && want_grad),
+                        "gradient of %s is not materialised: the pool's backward is fused into its consumer's data gradient (SSD_POOL_FUSE=0 keeps it)", name);
+        }
         SSD_REQUIRE(count == t.per_image() * b, "activation %s holds %zu floats for b=%d, got %zu", name, t.per_image() * b, b,
                     count);
         const void* src = want_grad ? t.grad : t.data;
@@ -1287,7 +1132,6 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     const int A = preset_->num_anchors;
     if (!detect_ws_) {
         detect_ws_ = dalloc(detect_ws_bytes(Bmax_, A));
-        HIP_OK(hipMemset(detect_ws_, 0, detect_ws_bytes(Bmax_, A)));      // (the fused pass' per-image tickets start at zero and return to it)
     }
     det_cur_ ^= 1;
     DetectSlot& sl = det_slot_[det_cur_];
@@ -1299,9 +1143,8 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     // The survivors (a few hundred KB per batch, only count-many entries per image are written) go STRAIGHT into pinned,
     // device-mapped host memory from the per-image kernel's ordered emit -- like the four losses (alloc()): a
     // device-to-host copy of the whole [b][out_cap] arrays is a blit KERNEL of its own behind the pass (13 us per batch of
-    // 128 in the rocprofv3 trace, a third of the pass) plus one more launch for the host to issue.  SSD_DETECT_MAPPED=0
-    // keeps the HBM arrays + copy (A/B switch).
-    static const bool mapped = [] { const char* v = getenv("SSD_DETECT_MAPPED"); return !(v && v[0] == '0'); }();
+    // 128 in the rocprofv3 trace, a third of the pass) plus one more launch for the host to issue.
+    const bool mapped = true;
     const size_t need = det_count_bytes(b) + (size_t)b * out_cap * 28;
     if (need > sl.bytes) {
         if (sl.dev && !sl.mapped) HIP_OK(hipFree(sl.dev));
@@ -1326,7 +1169,7 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     prof_.layer = "detect";
     DetectOut d;
     detect_slot_carve(sl, d, sl.dev);
-    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_, true);
+    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
     if (!sl.mapped) HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipEventRecord(sl.ready, stream_));
     if (dev_out) *dev_out = d;

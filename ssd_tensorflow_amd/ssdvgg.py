@@ -412,6 +412,14 @@ class SSDVGG:
         check(lib.ssd_activation(self._h, name.encode(), b, np_ptr(a), a.size))
         return a
 
+    def pool_fusion(self):
+        """Per 2x2 stride-2 pool of the graph (pool1 ... in graph order): (fused into its producer's forward epilogue, fused into
+        its consumer's data gradient).  A fused pool's input / its output gradient are not materialised (activation() refuses)."""
+        out = (C.c_int * 8)()
+        n = C.c_int()
+        check(lib.ssd_pool_fusion(self._h, out, 8, C.byref(n)))
+        return [(bool(out[i] & 1), bool(out[i] & 2)) for i in range(n.value)]
+
     # device-resident steps (torch tensors on this net's GPU)
     def forward_backward_dev(self, x_t, y_t):
         check(lib.ssd_forward_backward_dev(self._h, x_t.data_ptr(), y_t.data_ptr(), x_t.shape[0]))

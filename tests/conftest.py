@@ -26,3 +26,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def unfused_pools(monkeypatch):
+    """Handles created inside the test keep pool1-3 as separate kernels (SSD_POOL_FUSE=0, read per handle), so every
+    activation and gradient is materialised for the layer-local oracle checks; tests/test_gpu_pool_fusion.py shows the fused
+    step bit-identical to this one."""
+    monkeypatch.setenv('SSD_POOL_FUSE', '0')

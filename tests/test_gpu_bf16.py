@@ -261,6 +261,7 @@ def layer_local_forward_check(net, m, preset, b, x, only=None):
     return worst
 
 
+@pytest.mark.usefixtures('unfused_pools')
 @pytest.mark.parametrize('pname,b', [('vgg300', 2), ('vgg512', 1)])
 def test_bf16_step_layer_local(pname, b):
     preset = ob.get_preset(pname)

@@ -270,17 +270,3 @@ def test_overlap_mirrors_golden(pname):
         assert np.array_equal(su.compute_location(bx, an), g7['enc'][i])
         c, s = su.decode_location(g7['loc'][i].copy(), an)
         assert [float(c.x), float(c.y), s.w, s.h] == list(g7['dec'][i])
-
-
-def test_detect_single_launch_form_is_bit_identical():
-    """SSD_DETECT_FUSED=1 (the single-launch decode + NMS pass, off by default because it measured slower) hands the scan's
-    candidate segments to the per-image phase INSIDE one launch: the golden, fast/general-path, full-size and empty-input cases
-    again in a child process with the switch set (the library reads it once per process)."""
-    import os, subprocess, sys
-    if os.environ.get('SSD_DETECT_FUSED') == '1':
-        pytest.skip('already the forced configuration')
-    env = dict(os.environ, SSD_DETECT_FUSED='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_detect_ and not single_launch',
-                        '-p', 'no:cacheprovider'], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

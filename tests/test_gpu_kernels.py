@@ -118,19 +118,14 @@ def test_conv_large_layers(case):
     test_conv_fwd_dgrad_wgrad(case)
 
 
-# every fp32 tile / staging / split / parity switch the step can take, forced for ALL layers of a child
-# process (the library reads the switches once): the cost model only picks most of them at batch-32 sizes
+# every fp32 tile / parity switch the step can take, forced for ALL layers of a child process (the library
+# reads the switches once): the cost model only picks most of them at batch-32 sizes.  (Round 5 removed the register-staged
+# gather kernels, the deep-ring / k-split small-layer twins and the split-count switch together with their variants here.)
 FP32_VARIANTS = [
-    dict(SSD_TILE='0', SSD_WGRAD_CFG='0'),                                            # 128x128 everywhere, LDS-DMA staging
-    dict(SSD_TILE='1', SSD_WGRAD_CFG='1', SSD_WGRAD_ROUNDS='0'),                      # 128x64 / 64x64, plain split count
+    dict(SSD_TILE='0', SSD_WGRAD_CFG='0'),                                            # 128x128 everywhere
+    dict(SSD_TILE='1', SSD_WGRAD_CFG='1'),                                            # 128x64 / 64x64
     dict(SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_DGRAD_PARITY='0'),                      # 64x128, all-taps strided data gradient
-    dict(SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_GLDS_WGRAD='2'),                        # 64x64 / 128x64, DMA weight gradient on every tile
-    dict(SSD_GLDS='0', SSD_TILE='0', SSD_WGRAD_CFG='0', SSD_GLDS_WGRAD='0'),          # register-staged kernels
-    dict(SSD_GLDS='0', SSD_TILE='1', SSD_WGRAD_CFG='1'),
-    dict(SSD_GLDS='0', SSD_TILE='2', SSD_WGRAD_CFG='2', SSD_FIRST_F32='0', SSD_FIRST_WGRAD_F32='0'),
-    dict(SSD_GLDS='0', SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_DGRAD_PARITY='0', SSD_WGRAD_ROUNDS='0'),
-    dict(SSD_SMALL_TILE_F32='1'),                                                      # round 4: the small layers' deep ring ...
-    dict(SSD_SMALL_KSPLIT_F32='1'),                                                    # ... and their k split over four wave groups (both off by default)
+    dict(SSD_TILE='3', SSD_WGRAD_CFG='3', SSD_FIRST_F32='0', SSD_FIRST_WGRAD_F32='0'),  # 64x64 / 128x64, conv1_1 on the generic small-C kernels
 ]
 
 

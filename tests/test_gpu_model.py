@@ -131,6 +131,7 @@ def layer_local_backward_check(net, m, preset, b, x, y, wq=lambda w: w, tol_dout
     return worst_w, worst_x
 
 
+@pytest.mark.usefixtures('unfused_pools')
 def test_step_vgg300():
     b = 2
     preset, m, sess, net = make_pair('vgg300', b)
@@ -212,6 +213,7 @@ def test_train_steps_track_oracle():
     sess.close()
 
 
+@pytest.mark.usefixtures('unfused_pools')
 def test_step_vgg512_b1():
     b = 1
     preset, m, sess, net = make_pair('vgg512', b)

@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import boxes as ob, ssdvgg_ref as ref          # synthetic batch only (test infrastructure)
 from ssd_tensorflow_amd.ssdvgg import SSDVGG, Session
+from ssd_tensorflow_amd._lib import lib, check
 
 
 def main():
@@ -34,12 +35,13 @@ def main():
         net.build_optimizer(learning_rate=1e-4, weight_decay=0.0005, momentum=0.9)
         net.set_stream(torch.cuda.current_stream().cuda_stream)
         xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-        ablate = os.environ.pop('SSD_ABLATE', None)      # warm up un-ablated: every buffer holds what a real step leaves in it
+        ablate = os.environ.pop('SSD_ABLATE', None)      # (this TOOL's switch; the library is told through ssd_debug_set_ablate)
+        # warm up un-ablated: every buffer holds what a real step leaves in it
         for _ in range(a.warmup):
             net.train_step_dev(xd, yd)
         torch.cuda.synchronize()
         if ablate:
-            os.environ['SSD_ABLATE'] = ablate
+            check(lib.ssd_debug_set_ablate(ablate.encode()))
             for _ in range(3):
                 net.train_step_dev(xd, yd)
         out = []
