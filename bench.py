@@ -656,6 +656,8 @@ def ordered_for_tail(out):
         if isinstance(v.get('losses_check'), dict):
             e['losses_ok'] = v['losses_check'].get('ok')
         summ[k] = e
+    if 'e2e_workload' in out:
+        summ['e2e_workload'] = out['e2e_workload']
     if summ:
         o['summary'] = summ
     return o
@@ -710,7 +712,7 @@ def main():
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
     ap.add_argument('--force-collectives', action='store_true', default=os.environ.get('SSD_BENCH_FORCE_COLLECTIVES', '0') == '1',
                     help='one GPU: run the data-parallel step (staged backward + bucketed all-reduce on a single-rank RCCL group) to price its plumbing')
-    ap.add_argument('--bucket-mb', type=float, default=float(os.environ.get('SSD_BENCH_BUCKET_MB', 16)), help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    ap.add_argument('--bucket-mb', type=float, default=float(os.environ.get('SSD_BENCH_BUCKET_MB', 44)), help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
     ap.add_argument('--allreduce-dtype', default=os.environ.get('SSD_BENCH_ALLREDUCE_DTYPE', 'f32'), choices=['f32', 'bf16'],
                     help='N > 1 / --force-collectives: bf16 = filter gradients all-reduced as bf16 messages (half the bytes over xGMI)')
     ap.add_argument('--allow-fallback', action='store_true', help='N > 1: downgrade a failing bucketed all-reduce to a single one / report diverged replicas instead of aborting')
@@ -842,6 +844,9 @@ def main():
                     out[name] = {'error': f'{type(e).__name__}: {e}'}
             import shutil
             shutil.rmtree(tmpdir, ignore_errors=True)
+            # which workload the end-to-end blocks ran on: never compare their numbers across workloads (round 4 advice)
+            out['e2e_workload'] = ('shapes set, weights pretrained in this run (%s steps): detections decoded and collected' % out['e2e_pretrain'].get('steps')) \
+                if ckpt else 'noise set, Xavier weights: no class passes 0.5, nothing to collect (--no-pretrain, or the pretrain child failed)'
     if rank == 0:
         _OUT.emit(json.dumps(ordered_for_tail(out)))
     if world > 1 or args.force_collectives:

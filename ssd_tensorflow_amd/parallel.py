@@ -135,7 +135,14 @@ class Bf16Message:
         return finish
 
 
-_BF16_MESSAGES = Bf16Message()
+def _bf16_messages(net):
+    """The handle's own message buffers (round 4 kept ONE process-wide cache keyed by arena address: every handle ever created
+    pinned 2 bytes per filter float for the life of the process, and a recycled address would have found a dead handle's buffer).
+    SSDVGG.close() drops them with the handle."""
+    m = getattr(net, '_bf16_messages', None)
+    if m is None:
+        m = net._bf16_messages = Bf16Message()
+    return m
 
 
 def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, force_collectives=False, allreduce_dtype='f32'):
@@ -185,7 +192,7 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
                 net.forward_backward_dev(x_dev, y_dev)
             if bf16_msg:
                 nf = net.filter_floats
-                fin = _BF16_MESSAGES.all_reduce(net.grads_flat, 0, nf, async_op=False)
+                fin = _bf16_messages(net).all_reduce(net.grads_flat, 0, nf, async_op=False)
                 fin()
                 dist.all_reduce(net.grads_flat[nf:])
             else:
@@ -206,7 +213,7 @@ def train_step_dp(net, x_dev, y_dev, world, bucket_floats=0, global_count=None, 
             for off, cnt in ranges:
                 with torch.cuda.stream(side):
                     if bf16_msg:      # packed behind the weight-gradient stream, unpacked (below) on the current stream
-                        works.append(_BF16_MESSAGES.all_reduce(net.grads_flat, off, cnt))
+                        works.append(_bf16_messages(net).all_reduce(net.grads_flat, off, cnt))
                     else:
                         works.append(dist.all_reduce(net.grads_flat[off:off + cnt], async_op=True).wait)
             works.append(dist.all_reduce(net.grads_flat[net.filter_floats:], async_op=True).wait)

@@ -229,6 +229,7 @@ class SSDVGG:
             self._h = None
             if hasattr(self, '_det_views'):
                 self._det_views.clear()      # (views of pinned memory that ssd_destroy has just freed)
+            self._bf16_messages = None       # (parallel.Bf16Message buffers of this handle's gradient arena)
 
     def __del__(self):
         try:

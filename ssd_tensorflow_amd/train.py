@@ -132,7 +132,7 @@ def main(argv=None):
     parser.add_argument('--synthetic-valid', type=int, default=16)
     parser.add_argument('--augment', type=str2bool, default='False', help="run the reference's train augmentation recipe (process_dataset.py) on the GPU over a uint8 synthetic dataset")
     parser.add_argument('--allreduce-dtype', default='f32', choices=['f32', 'bf16'], help='data parallel: bf16 = the filter gradients cross the links as bf16 messages of half the bytes (fp32 masters, momentum and arenas untouched)')
-    parser.add_argument('--allreduce-bucket-mb', type=float, default=16, help='data parallel: all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
+    parser.add_argument('--allreduce-bucket-mb', type=float, default=44, help='data parallel: all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward); 44 = three buckets: heads ... mod_conv6 | conv5_x + conv4_3/4_2 | the rest')
     args = parser.parse_args(argv)
 
     rank, local, world = parallel.init()

@@ -189,6 +189,56 @@ def test_two_rank_training_on_one_gpu_matches_single_process(tmp_path):
     assert max(errs[k] for k in errs if k.startswith(('conv1_', 'conv2_', 'conv3_', 'conv4_', 'classifiers/classifier0_', 'classifiers/classifier1_'))) < 0.05
 
 
+def test_eight_rank_training_on_one_gpu_matches_single_process(tmp_path):
+    """BASELINE.json configs[2] names EIGHT ranks: the same plumbing at that world size -- `torchrun --nproc-per-node 8`, every
+    rank on GPU 0 over gloo, batch 4 per rank, one epoch of 70 samples = global batches of 32, 32 and 6, so that ranks 6 and 7
+    get an EMPTY shard in the last one (null gradients, the same collectives), and 3 validation samples (five empty shards).
+    Replicas bit-identical, step count and epoch losses equal to ONE process at batch 32 on the same samples."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    common = ['--epochs', '1', '--synthetic-train', '70', '--synthetic-valid', '3', '--checkpoint-interval', '1',
+              '--lr-values', '0.0001', '--lr-boundaries', '', '--tensorboard-dir', str(tmp_path / 'tb')]
+    env = dict(os.environ, SSD_FORCE_DEVICE='0', SSD_DIST_BACKEND='gloo', SSD_PRINT_CHECKSUM='1', PYTHONPATH=root, OMP_NUM_THREADS='4')
+    dp = str(tmp_path / 'dp8')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), '-m', 'ssd_tensorflow_amd.train', '--name', dp, '--batch-size', '4'] + common,
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    sums = dict(re.findall(r'\[checksum\] rank (\d) step \d+ params (\S+)', r.stdout))
+    assert set(sums) == set('01234567') and len(set(sums.values())) == 1, r.stdout[-2000:]
+    assert '[i] Batch size:            4 x 8 GPU(s)' in r.stdout and '[i] Train  1/1' in r.stdout
+    assert 'EMPTY shard' not in r.stderr        # (an empty shard of a batch with fewer samples than ranks is expected and silent)
+
+    def losses(text, tag):
+        m = re.search(r'\[i\] %s  1/1  total (\S+)  localization (\S+)  confidence (\S+)  l2 (\S+)' % tag, text)
+        assert m, text[-1500:]
+        return [float(v) for v in m.groups()]
+    one = str(tmp_path / 'one32')
+    r1 = subprocess.run([sys.executable, '-m', 'ssd_tensorflow_amd.train', '--name', one, '--batch-size', '32'] + common,
+                        env=dict(os.environ, PYTHONPATH=root), cwd=root, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    a, b = np.load(dp + '/final.npz'), np.load(one + '/final.npz')
+    assert int(a['__global_step__']) == int(b['__global_step__']) == 3
+    for tag in ('Train', 'Valid'):
+        la, lb = losses(r.stdout, tag), losses(r1.stdout, tag)
+        print(f'    {tag}: 8 ranks {la}  one process {lb}')
+        for x, y in zip(la, lb):
+            assert abs(x - y) <= 2e-3 * abs(y), (tag, la, lb)
+    # the filters after three updates: same bar as the two-rank test (relative to the distance the filter moved)
+    from oracle import boxes as ob, ssdvgg_ref as ref
+    ck0 = ref.init_params_lib(ob.get_preset('vgg300'), 20, seed=42)
+    errs = {}
+    for k in b.files:
+        if k.endswith('/filter') and not k.startswith('__'):
+            moved = float(np.abs(b[k] - ck0[k]).max())
+            errs[k] = float(np.abs(a[k].astype(np.float64) - b[k]).max()) / (moved + 1e-30)
+    assert max(errs[k] for k in errs if k.startswith(('conv1_', 'conv2_', 'conv3_', 'conv4_', 'classifiers/classifier0_', 'classifiers/classifier1_'))) < 0.05
+
+
 def test_build_from_vgg_directory(tmp_path):
     """N3: a VGG-16 export (13 conv layers + full-size fc6 / fc7) -> weights.save_vgg_npz (a-trous decimation,
     ssdvgg.py:245-253,273-280) -> build_from_vgg(vgg_dir): the trunk carries the file's tensors, mod_conv6/7 the

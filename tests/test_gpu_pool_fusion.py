@@ -5,6 +5,7 @@ The separate passes -- conv, maxpool_fwd_rec, conv data gradient, maxpool_bwd_re
 (test_gpu_kernels.py, test_gpu_bf16.py, the layer-local tests on SSD_POOL_FUSE=0 handles).  Here the fused kernels must
 reproduce them BIT FOR BIT: pooled tensor, 12-bit record, un-pooled gradient; then whole training steps of a fused and an
 unfused handle, at small and at the benchmarked batch sizes, in both dtypes: result, losses, every gradient identical."""
+import os
 import zlib
 
 import numpy as np
@@ -119,12 +120,22 @@ def test_fused_pool_bf16_bit_identical(case):
     p_got = torch.full((b, ph, pw, co), 9.0, dtype=torch.bfloat16, device='cuda')
     r_got = torch.full((b, ph, pw, co // 4), -2, dtype=torch.int16, device='cuda')
     check(lib.ssd_op_conv2d_fwd_pool_bf16(ptr(x_), ptr(woi), ptr(b_), ptr(p_got), ptr(r_got), *geom, None))
-    assert np.array_equal(raw(p_got), raw(p_ref)), f'{name}: pooled tensor differs'
-    assert np.array_equal(raw(r_got), raw(r_ref)), f'{name}: record differs'
+    if ci == 64 and co == 64 and os.environ.get('SSD_C64_BF16') != '2':
+        # The fused 64 -> 64 kernel is the 2-D form of the PERSISTENT 64 -> 64 kernel, which a small stand-alone layer does not
+        # take (conv_bf16.hip gather_c64_applicable: the per-tap 256 x 64 kernel runs instead).  Those two unfused kernels agree
+        # to an fp32 ulp of the sum, not bit for bit (measured: 2 of 46,080 outputs one bf16 step apart), so here the pooled
+        # tensor is only close; test_fused_pool_c64_against_the_persistent_kernel repeats these cases with the persistent
+        # kernel forced, bit for bit -- as the whole-step test below does at sizes where the step takes it anyway.
+        a, r = p_got.float().cpu().numpy(), p_ref.float().cpu().numpy()
+        assert np.abs(a - r).max() <= 2.0 ** -7 * np.abs(r).max() and (a != r).mean() < 1e-3, f'{name}: pooled tensor differs'
+        r_ref = r_got          # (the backward half below then runs on the fused kernel's own record)
+    else:
+        assert np.array_equal(raw(p_got), raw(p_ref)), f'{name}: pooled tensor differs'
+        assert np.array_equal(raw(r_got), raw(r_ref)), f'{name}: record differs'
     assert np.count_nonzero(raw(p_ref)) > 0.3 * p_ref.numel()
     p2 = torch.full((b, ph, pw, co), 9.0, dtype=torch.bfloat16, device='cuda')
     check(lib.ssd_op_conv2d_fwd_pool_bf16(ptr(x_), ptr(woi), ptr(b_), ptr(p2), None, *geom, None))
-    assert np.array_equal(raw(p2), raw(p_ref))
+    assert np.array_equal(raw(p2), raw(p_got))
 
     # ---- backward through the record, for the three kinds of consumers: 64 / 128 / 256 input-gradient channels take the
     # per-tap and the kernel-row data-gradient kernels (conv2_1, conv3_1, conv4_1 of the step)
@@ -144,6 +155,19 @@ def test_fused_pool_bf16_bit_identical(case):
     check(lib.ssd_op_conv2d_dgrad_unpool_bf16(ptr(dy_), ptr(w2io), ptr(dx_got), ptr(r_ref), h, w, *geom2, None))
     assert np.array_equal(raw(dx_got), raw(dx_ref)), f'{name}: un-pooled data gradient differs'
     assert np.count_nonzero(raw(dx_ref)) > 0.02 * dx_ref.numel()
+
+
+def test_fused_pool_c64_against_the_persistent_kernel():
+    """The 64 -> 64 cases again in a child process with SSD_C64_BF16=2 (the persistent kernel on every 64 -> 64 layer, however
+    small; the library reads the switch once): the fused 2-D form must equal it bit for bit, pooled tensor and record."""
+    import subprocess, sys
+    if os.environ.get('SSD_C64_BF16') == '2':
+        pytest.skip('already the forced configuration')
+    env = dict(os.environ, SSD_C64_BF16='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_fused_pool_bf16_bit_identical and c64',
+                        '-p', 'no:cacheprovider'], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '3 passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_fused_pool_refuses_what_it_cannot_do():
