@@ -124,6 +124,8 @@ SIGNATURES = {
     'ssd_op_conv2d_fwd_pool_bf16': (i32, [vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_dgrad_unpool': (i32, [vp, vp, vp, vp, i32, i32] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_dgrad_unpool_bf16': (i32, [vp, vp, vp, vp, i32, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_dgrad_first_wgrad_bf16_ws_floats': (sz, [i32, i32, i32]),
+    'ssd_op_conv2d_dgrad_first_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     'ssd_pool_fusion': (i32, [handle, p_i32, i32, p_i32]),
     'ssd_debug_set_ablate': (i32, [cstr]),
     'ssd_op_maxpool_fwd': (i32, [vp, vp] + [i32] * 10 + [vp]),

@@ -890,6 +890,18 @@ int ssd_op_conv2d_dgrad_unpool_bf16(const void* dy, const void* w_io, void* dx_u
                            (bf16_t*)dx_unpooled, rec, uh, uw, (hipStream_t)stream);
     API_END
 }
+// data gradient of a 64 -> 64 3x3 layer (geometry b, h, w) with the weight gradient of the 3-channel 3x3 first layer below it
+// fused in (conv.h conv_dgrad_first_wgrad_bf16): dw1 [3][3][3][64], dbias1 [64]; dx itself is not produced
+size_t ssd_op_conv2d_dgrad_first_wgrad_bf16_ws_floats(int b, int h, int w) {
+    return conv_dgrad_first_wgrad_bf16_ws_floats(mk(b, h, w, 3, h, w, 64, 3, 3, 1, 1, 1, 1));
+}
+int ssd_op_conv2d_dgrad_first_wgrad_bf16(const void* dy, const void* w_io, const void* mask, const float* image, float* dw1, float* dbias1,
+                                         const float* w1, float weight_decay, float* ws, int b, int h, int w, void* stream) {
+    API_BEGIN
+    conv_dgrad_first_wgrad_bf16(mk(b, h, w, 64, h, w, 64, 3, 3, 1, 1, 1, 1), (const bf16_t*)dy, (const bf16_t*)w_io, (const bf16_t*)mask,
+                                mk(b, h, w, 3, h, w, 64, 3, 3, 1, 1, 1, 1), image, dw1, dbias1, w1, weight_decay, ws, (hipStream_t)stream);
+    API_END
+}
 // which of its 2x2 pools the handle runs fused: bit 0 of out[i] = forward (producer's epilogue), bit 1 = backward (consumer's
 // data gradient); i counts the 2x2 stride-2 pools in graph order; *count = their number
 int ssd_pool_fusion(ssd_handle h, int* out, int cap, int* count) {

@@ -93,6 +93,15 @@ void conv_fwd_pool_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* w_oi, 
 bool conv_dgrad_unpool_bf16_supported(const ConvDesc& d);
 void conv_dgrad_unpool_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx_unpooled, const void* rec, int UH, int UW,
                             hipStream_t s);
+// Round 5: the data gradient of the 64 -> 64 layer d (conv1_2) with the WEIGHT gradient of the first layer d1 below it (conv1_1:
+// 3 input channels, 3x3) computed from the dx tiles while they are in LDS: dx is never written, conv1_1's own weight-gradient
+// kernel is not launched.  dw1 / dbias1 = sum over pixels (+ weight_decay * w1), reduced from one slab per workgroup in ws
+// (conv_dgrad_first_wgrad_bf16_ws_floats).  mask = the first layer's output (relu mask of dx).
+bool conv_dgrad_first_wgrad_bf16_applicable(const ConvDesc& d, const ConvDesc& d1);
+size_t conv_dgrad_first_wgrad_bf16_ws_floats(const ConvDesc& d1);
+void conv_dgrad_first_wgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, const bf16_t* mask, const ConvDesc& d1,
+                                 const float* image, float* dw1, float* dbias1, const float* w1, float weight_decay, float* ws,
+                                 hipStream_t s);
 size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d);
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s);

@@ -664,10 +664,27 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 // Wave w owns pixel rows 32 w .. 32 w + 31 of the tile x all 64 channels (2 accumulator tiles); the results leave
 // straight from the accumulators (4 consecutive channels of one pixel per register quad = one 8-byte store).
 // =================================================================================
-template <int MODE>
-__global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks) {
+// FIRSTW (round 5; data gradient of conv1_2 only): the layer below is the FIRST layer (conv1_1: 3 input channels, K = taps x 3
+// = 27 <= 32), whose only use for this kernel's result is its weight gradient dW1[k][n] = sum_pixels im2col(image)[pixel][k] *
+// dx[pixel][n].  The dx rows of a tile are in LDS anyway (the write-out staging): each wave multiplies its 32 rows against the
+// 32 im2col rows of the same pixels (built from the fp32 image by all threads, one 16-byte LDS store per pixel and 8 k; k = 27
+// carries a one so that row 27 of the product is the bias gradient) -- 4 MFMAs per wave and tile beside the 72 of the
+// convolution -- into accumulators that live for the whole kernel; the workgroup's eight partial products are added in wave
+// order at the end and leave as ONE slab.  dx itself is never written: 368 MB less to store and 368 MB less to read back at
+// batch 32, and conv1_1's own weight-gradient kernel is not launched (0.274 + 0.126 ms -> one kernel).
+struct FirstWArgs {
+    const float* img;       // [B][DH][DW][3] fp32 (the first layer is 3x3 stride 1 SAME: its image has this kernel's output size)
+    float* ws;              // [workgroups][K * 64 + 64] slabs
+    int Ci, ntaps;
+    int tap_dh[9], tap_dw[9];
+};
+
+template <int MODE, bool FIRSTW = false>
+__global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p, int ntiles, int xcd_chunks, FirstWArgs fw) {
     constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
     constexpr int ZROW = (AROWS - 1) * 128;
+    constexpr int XT_BASE = A_BASE + 2 * A_BYTES, XROWB = 64;      // FIRSTW: im2col tile [256 pixels][32 k] bf16
+    static_assert(!FIRSTW || MODE == MODE_DGRAD, "the fused first-layer weight gradient belongs to the data gradient");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -728,6 +745,27 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[ni][g][e] = (MODE == MODE_FWD && p.bias) ? p.bias[ni * 32 + 8 * g + 4 * lh + e] : 0.f;
 
+    // FIRSTW: im2col staging map -- thread -> pixel rows (tid >> 2) + 128 pass, k = 8 (tid & 3) .. + 7
+    const int xr = tid >> 2, xq = tid & 3;
+    int koff[8];
+    unsigned kbit[8];
+    f32x16 accw[2];
+    __amdgpu_buffer_rsrc_t img_rsrc = src_rsrc;
+    if constexpr (FIRSTW) {
+        const int K = fw.ntaps * fw.Ci;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = xq * 8 + j;
+            const bool kv = k < K;
+            const int tp = kv ? k / fw.Ci : 0, c = kv ? k - tp * fw.Ci : 0;
+            koff[j] = ((fw.tap_dh[tp] * p.DW + fw.tap_dw[tp]) * fw.Ci + c) * 4;
+            kbit[j] = kv ? (1u << tp) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[0][r] = accw[1][r] = 0.f;
+        img_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fw.img), 0, (unsigned)((size_t)p.M * fw.Ci * 4u), 0x00020000);
+    }
+
     // Which tiles: workgroup w runs on XCD w % 8.  An input pixel row is fetched three times (once per kernel row, by the
     // output tiles W pixels before / at / after it = neighbouring tiles): with xcd_chunks the tile range is cut in 8
     // contiguous chunks, one per XCD, so the three fetches meet in ONE L2 instead of three (plain round robin otherwise).
@@ -758,6 +796,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
         // (one workgroup per CU: nothing else would hide that round trip)
         u32x2 pre_old[2][4];
         u32x4 row_mask[4];
+        float xim[2][8];
 #pragma unroll
         for (int kr = 0; kr < 3; ++kr, ++gunit) {
             wait_tiles_and_sync<1>(0);                    // this unit's tile (and, the first time, the filter) has landed
@@ -780,6 +819,31 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             }
             if (kr < 2) issue(tile, kr + 1, (gunit + 1) & 1);
             else if (tile + tstep < tend) issue(tile + tstep, 0, (gunit + 1) & 1);
+            if constexpr (FIRSTW) {
+                if (kr == 1) {      // the tile's im2col values: 16 gathers per thread, in flight while two kernel rows multiply
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int r2 = xr + 128 * ps, m2 = m0 + r2;
+                        const bool pv = r2 < BMV && m2 < p.M;
+                        const int mm = pv ? m2 : 0;
+                        const int ow = mm % p.DW, t2 = mm / p.DW;
+                        const int oh = t2 % p.DH;
+                        unsigned mk = 0;
+                        for (int t = 0; t < fw.ntaps; ++t) {
+                            const int sh = oh + fw.tap_dh[t], sw = ow + fw.tap_dw[t];
+                            if ((unsigned)sh < (unsigned)p.DH && (unsigned)sw < (unsigned)p.DW) mk |= 1u << t;
+                        }
+                        if (!pv) mk = 0;
+                        const unsigned base = (unsigned)mm * (unsigned)(fw.Ci * 4);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned ok = 0u - (unsigned)((mk & kbit[j]) != 0u);
+                            xim[ps][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rsrc, ((base + (unsigned)koff[j]) & ok) | (OOBH & ~ok), 0, 0));
+                        }
+                        if (xq == 3) xim[ps][3] = pv ? 1.f : 0.f;      // k = 27 = K (host check): the ones column -> row 27 of the product is the bias gradient
+                    }
+                }
+            }
             const unsigned char* A = smem + A_BASE + (gunit & 1) * A_BYTES;
             int ua[3];
 #pragma unroll
@@ -808,6 +872,12 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             // accumulators every 128-byte line is touched by 8 different 16-byte requests (and as many for the mask).  The
             // staging area is this wave's 32 rows of the activation buffer the last unit has just consumed; 16-byte chunk c
             // of row r lives at chunk c ^ sw(r).
+            if constexpr (FIRSTW) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+                    *reinterpret_cast<u32x4*>(smem + XT_BASE + (xr + 128 * ps) * XROWB + xq * 16) =
+                        u32x4{pack2(xim[ps][0], xim[ps][1]), pack2(xim[ps][2], xim[ps][3]), pack2(xim[ps][4], xim[ps][5]), pack2(xim[ps][6], xim[ps][7])};
+            }
             __syncthreads();                              // the neighbours have read their halo rows of that buffer
             unsigned char* S = smem + A_BASE + ((gunit - 1) & 1) * A_BYTES + wave * (32 * 128);
             const int swl = (li ^ (li >> 3)) & 7;
@@ -842,8 +912,57 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                         v[e] &= (lo | hi);
                     }
                 }
-                if (r2 < BMV && m2 < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m2 * 64 + ch * 8) = v;
+                if constexpr (FIRSTW) {      // the masked row back into the staging area (zeros for rows that are not pixels)
+                    if (!(r2 < BMV && m2 < p.M)) v = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(S + row * 128 + ((ch ^ ((row ^ (row >> 3)) & 7)) * 16)) = v;
+                } else {
+                    if (r2 < BMV && m2 < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m2 * 64 + ch * 8) = v;
+                }
             }
+            if constexpr (FIRSTW) {
+                // dW1 += im2col^T (k x pixels) * dx (pixels x channels) over this wave's 32 rows: both operands k-major through the
+                // transpose read (conv_first_bf16.hip); the im2col tile was published by the barrier above, the dx rows are this
+                // wave's own (its LDS writes are ordered before its reads)
+                asm volatile("" ::: "memory");
+                const int q = lane & 15, cb = (lane >> 4) & 1;
+                auto tr8 = [&](const unsigned char* a0, const unsigned char* a1) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)LDS_PTR(a1));
+                    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                };
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int pr0 = st * 16 + lh * 8 + (q >> 2), pr1 = pr0 + 4;      // rows inside the wave's block
+                    const unsigned char* X = smem + XT_BASE + wave * 32 * XROWB + (cb * 2 + ((q >> 1) & 1)) * 16 + (q & 1) * 8;
+                    const s16x8 a = tr8(X + pr0 * XROWB, X + pr1 * XROWB);
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int ych = nh * 4 + cb * 2 + ((q >> 1) & 1);
+                        const s16x8 bq = tr8(S + pr0 * 128 + ((ych ^ ((pr0 ^ (pr0 >> 3)) & 7)) * 16) + (q & 1) * 8,
+                                             S + pr1 * 128 + ((ych ^ ((pr1 ^ (pr1 >> 3)) & 7)) * 16) + (q & 1) * 8);
+                        accw[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), accw[nh], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (FIRSTW) {
+        // the workgroup's slab: its eight waves' products added in wave order (fixed order: run-to-run identical), rows 0..26 =
+        // dW1[k][n], row 27 = the bias gradient
+        __syncthreads();
+        float* Rw = reinterpret_cast<float*>(smem + A_BASE);      // [8 waves][32 k][64 n] floats = the two activation buffers
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Rw[wave * 2048 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + nh * 32 + li] = accw[nh][r];
+        __syncthreads();
+        const int K = fw.ntaps * fw.Ci;
+        float* slab = fw.ws + (size_t)blockIdx.x * (K * 64 + 64);
+        for (int idx = tid; idx < (K + 1) * 64; idx += 512) {
+            float sum = Rw[idx];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sum += Rw[w * 2048 + idx];
+            slab[idx] = sum;      // (k = K lands at K * 64 + n: the slab's bias row)
         }
     }
 }
@@ -2298,10 +2417,10 @@ static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, d
     constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128;
     const int ntiles = cdiv(a.M, 253);
     ProfScope prof(label, flops, bytes, s);
-    auto kern = conv_gather_bf16_c64_kernel<MODE>;
+    auto kern = conv_gather_bf16_c64_kernel<MODE, false>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0, FirstWArgs{});
     HIP_OK(hipGetLastError());
 }
 
@@ -2460,6 +2579,49 @@ static void conv_dgrad_bf16_any(const ConvDesc& d, const bf16_t* dy, const bf16_
 void conv_dgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, bf16_t* dx, const bf16_t* mask, bool accumulate,
                      hipStream_t s) {
     conv_dgrad_bf16_any(d, dy, w_io, dx, mask, accumulate, s, nullptr, 0, 0);
+}
+
+// ---- conv1_2's data gradient with conv1_1's weight gradient inside (conv_gather_bf16_c64_kernel<MODE_DGRAD, true>) ----------
+bool conv_dgrad_first_wgrad_bf16_applicable(const ConvDesc& d, const ConvDesc& d1) {
+    return gather_c64_applicable(d, false) && d1.Ci * d1.KH * d1.KW == 27 && d1.Co == 64 && d1.KH == 3 && d1.KW == 3 && d1.stride == 1 &&
+           d1.dil == 1 && d1.pad_h == 1 && d1.pad_w == 1 && d1.Hi == d.Hi && d1.Wi == d.Wi && d1.Ho == d.Hi && d1.Wo == d.Wi && d1.B == d.B;
+}
+size_t conv_dgrad_first_wgrad_bf16_ws_floats(const ConvDesc& d1) { return (size_t)256 * (27 * 64 + 64); }
+void conv_dgrad_first_wgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16_t* w_io, const bf16_t* mask, const ConvDesc& d1,
+                                 const float* image, float* dw1, float* dbias1, const float* w1, float weight_decay, float* ws,
+                                 hipStream_t s) {
+    check_desc_h(d);
+    SSD_REQUIRE(conv_dgrad_first_wgrad_bf16_applicable(d, d1), "conv_dgrad_first_wgrad_bf16: not a 64 -> 64 layer on top of a 3-channel 3x3 first layer");
+    GatherArgsH a{};
+    a.src = dy; a.wgt = w_io; a.bias = nullptr; a.mask = mask; a.dst = nullptr;
+    a.M = d.B * d.Hi * d.Wi; a.DH = d.Hi; a.DW = d.Wi; a.DN = d.Ci;
+    a.SH = d.Ho; a.SW = d.Wo; a.SC = d.Co;
+    a.ntaps = 9; a.mul = 1; a.div = 1;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            a.tap_dh[kh * 3 + kw] = d.pad_h - kh;
+            a.tap_dw[kh * 3 + kw] = d.pad_w - kw;
+        }
+    FirstWArgs fw{};
+    fw.img = image; fw.ws = ws; fw.Ci = d1.Ci; fw.ntaps = 9;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            fw.tap_dh[kh * 3 + kw] = kh - d1.pad_h;
+            fw.tap_dw[kh * 3 + kw] = kw - d1.pad_w;
+        }
+    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128 + 256 * 64;
+    const int ntiles = cdiv(a.M, 253);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    {
+        ProfScope prof("conv_dgrad_bf16_c64_first_wgrad", conv_flops(d) + conv_flops(d1),
+                       2.0 * ((double)d.B * d.Ho * d.Wo * d.Co + (double)d.B * d.Hi * d.Wi * d.Ci) + 4.0 * d1.B * d1.Hi * d1.Wi * d1.Ci, s);
+        auto kern = conv_gather_bf16_c64_kernel<MODE_DGRAD, true>;
+        static bool once = (set_lds(kern, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0, fw);
+        HIP_OK(hipGetLastError());
+    }
+    wgrad_reduce(ws, grid, (size_t)27 * 64, 64, dw1, dbias1, w1, weight_decay, s);
 }
 
 bool conv_dgrad_unpool_bf16_supported(const ConvDesc& d) { return d.stride == 1 && d.Ci % 8 == 0 && d.Co % 8 == 0; }

@@ -1299,7 +1299,10 @@ static void conv_fwd_any(const ConvDesc& d, const float* x, const float* w, cons
     }
     // (the cost model counts rounds of workgroups on the chip: the launches that run side by side -- the executor's forward
     // lanes, g_conv_lanes -- share it)
-    const int cfg = pick_tile((long long)a.M * g_conv_lanes, a.DN, MODE_FWD);
+    // (the fused pool's GEMM has up to 3 % more rows -- the cells an odd image lacks: the tile is picked for the convolution's own
+    // pixel count, or conv3_3 lands one modelled round above conv3_2 and takes the 128 x 64 tile: 1741 us against 1624,
+    // profiles/r05_b_per_layer_f32.txt)
+    const int cfg = pick_tile((long long)d.B * d.Ho * d.Wo * g_conv_lanes, a.DN, MODE_FWD);
     if (pool) {
         switch (cfg) {
         case 0: launch_gather_dma<MODE_FWD, 2, 2, 2, 2, false, false, true>(a, "conv_fwd_pool_128x128", fl, by, s); break;

@@ -179,6 +179,9 @@ private:
     long bw_issued_[2] = {0, 0}, bw_seen_[2][2] = {{0, 0}, {0, 0}};
     hipEvent_t ev_m2s_ = nullptr;        // main -> side hand-off
     bool bw_first_on_main_ = false;      // the first layer's weight gradient was issued on the main stream (backward_step)
+    bool fuse_first_wgrad_ = false;      // bf16: conv1_1's weight gradient inside conv1_2's data gradient where the kernel applies (plan_pool_fusion)
+    bool bw_first_fused_ = false;        // ... and this backward pass took it
+    int fused_first_out_ = -1;           // the tensor whose gradient that pass did not materialise (conv1_1's output)
     void launch_wgrad(int op_index, int b, hipStream_t ws);
     void build_orders();
     void plan_pool_fusion();

@@ -275,9 +275,11 @@ size_t Net::bw_final_lo() const {
 //  * the PRODUCER's forward epilogue takes the maxima and writes the pooled tensor and the pool's record; its own output is
 //    then never written -- nothing reads it in backward either (the record carries the argmax and the relu sign);
 //  * the CONSUMER's data gradient scatters through the record straight into the producer's output gradient.
-// SSD_POOL_FUSE: bit 0 forward, bit 1 backward (default 3; 0 = the separate pool kernels, the A/B and the bit-identity check).
+// SSD_POOL_FUSE: bit 0 forward, bit 1 backward, bit 2 (bf16) conv1_1's weight gradient inside conv1_2's data gradient
+// (backward_step); default 7; 0 = the separate kernels, for the A/B and the identity checks.
 void Net::plan_pool_fusion() {
-    const int mode = env_i("SSD_POOL_FUSE", 3);      // (read per handle: the tests build a fused and an unfused handle in one process)
+    const int mode = env_i("SSD_POOL_FUSE", 7);      // (read per handle: the tests build a fused and an unfused handle in one process)
+    fuse_first_wgrad_ = (mode & 4) != 0 && bf16_ && training_;
     for (int i = 0; i < (int)ops_.size(); ++i) {
         Op& pl = ops_[i];
         if (pl.kind != OP_POOL) continue;
@@ -389,7 +391,7 @@ void Net::alloc() {
                 for (int b = 1; b <= B; ++b) {
                     const ConvDesc d = conv_desc(op, b);
                     ws = std::max(ws, (bf16_ && d.Ci % 8 == 0) ? conv_wgrad_bf16_ws_floats(d) : conv_wgrad_ws_floats(d));
-                    if (bf16_ && first_layer_kernel(d)) ws = std::max(ws, conv_first_wgrad_bf16_ws_floats(d));
+                    if (bf16_ && first_layer_kernel(d)) ws = std::max(ws, std::max(conv_first_wgrad_bf16_ws_floats(d), conv_dgrad_first_wgrad_bf16_ws_floats(d)));
                 }
                 op.ws_off = ws_total;
                 ws_total += (ws + 63) / 64 * 64;
@@ -782,6 +784,7 @@ void Net::backward_begin(int b, const float* y) {
     if (side) bw_sync(1, 0);      // the side stream starts behind it (the small maps' head data gradients: backward_step)
     bw_conv_done_.assign(ops_.size(), 0);
     bw_first_on_main_ = false;
+    bw_first_fused_ = false;
     bw_pos_ = 0;
     bw_b_ = b;
     bw_done_off_ = nfilters_;
@@ -835,7 +838,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 bw_need(0, out);
                 if (on_main) bw_first_on_main_ = true;
             }
-            launch_wgrad(op_index, b, ws);
+            if (!(bw_first_fused_ && !need_dx)) launch_wgrad(op_index, b, ws);      // (conv1_1's came out of conv1_2's data gradient: below)
             if (need_dx) {
                 bw_need(cls, out);
                 // Pool fusion (round 5): when this conv reads a recorded 2x2 pool's output, its data gradient routes every
@@ -846,6 +849,25 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 Tensor& dst = up ? tensors_[up->in] : in;
                 if (!up && in.done > 0) bw_need(cls, in);      // accumulates into what the other class wrote
                 const bool mask = !up && last && in.relu_out;
+                // conv1_2 in bf16: the layer below is the first layer, whose only use for dx is its weight gradient -- computed
+                // here from the dx tiles while they are in LDS (conv.h conv_dgrad_first_wgrad_bf16); dx is never written and
+                // conv1_1's own weight-gradient kernel is skipped when its turn comes
+                int first = -1;
+                if (fuse_first_wgrad_ && !up && mask && in.done == 0)
+                    for (int j = 0; j < (int)ops_.size(); ++j)
+                        if (ops_[j].kind == OP_CONV && ops_[j].out == op.in && ops_[j].in == input_t_) first = j;
+                if (first >= 0 && cls == 0 && conv_dgrad_first_wgrad_bf16_applicable(d, conv_desc(ops_[first], b))) {
+                    const Op& f = ops_[first];
+                    prof_.layer = "conv1_2+conv1_1";
+                    conv_dgrad_first_wgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.h(), conv_desc(f, b), tensors_[input_t_].f(),
+                                                grads_ + f.w_off, grads_ + f.b_off, params_ + f.w_off, wd_, wgrad_ws_ + f.ws_off, ds);
+                    bw_first_fused_ = true;
+                    fused_first_out_ = op.in;
+                    bw_wrote(cls, in);
+                    bw_conv_done_[op_index] = 1;
+                    lo = bw_final_lo();
+                    break;
+                }
                 if (!bf16_) {
                     if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
@@ -1084,6 +1106,8 @@ void Net::activation(const char* name, int b, float* out, size_t count) {
         const Tensor& t = tensors_[ti];
         if (t.name != name || !t.data) continue;
         SSD_REQUIRE(!want_grad || t.grad != nullptr, "no gradient storage (training = 0?)");
+        SSD_REQUIRE(!(want_grad && bw_first_fused_ && fused_first_out_ == (int)ti),
+                    "gradient of %s is not materialised: the first layer's weight gradient was computed inside the next layer's data gradient (SSD_POOL_FUSE=3 keeps it)", name);
         for (const Op& op : ops_) {
             SSD_REQUIRE(!(op.kind == OP_POOL && op.fused_fwd && op.in == (int)ti && !want_grad),
                         "activation %s is not materialised: its 2x2 pool is fused into the convolution (SSD_POOL_FUSE=0 keeps it)", name);
