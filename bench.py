@@ -710,6 +710,7 @@ def main():
     ap.add_argument('--zero-input', action='store_true', help='DVFS probe: all-zero images (NOT a valid benchmark number)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses GPU 0 (gloo only)')
+    ap.add_argument('--null-collective', action='store_true', help='with --force-collectives on one GPU: the all-reduce is an event hand-off only (prices the plumbing without the single-rank RCCL kernels)')
     ap.add_argument('--force-collectives', action='store_true', default=os.environ.get('SSD_BENCH_FORCE_COLLECTIVES', '0') == '1',
                     help='one GPU: run the data-parallel step (staged backward + bucketed all-reduce on a single-rank RCCL group) to price its plumbing')
     ap.add_argument('--bucket-mb', type=float, default=float(os.environ.get('SSD_BENCH_BUCKET_MB', 44)), help='all-reduce finished gradient ranges of >= this many MB while backward still runs (0 = one all-reduce after backward)')
@@ -745,6 +746,9 @@ def main():
             sys.exit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
     if args.same_device:
         local = 0
+    if world > 1 or args.force_collectives:
+        from ssd_tensorflow_amd import parallel
+        parallel.reserve_hw_queues()      # (before the first HIP call: an RCCL communicator's streams need queues of their own)
     torch.cuda.set_device(local)
     _lib.set_device(local)
     if world > 1 or args.force_collectives:
@@ -755,6 +759,32 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(args.backend)
+
+    if args.null_collective:
+        # Measurement aid for --force-collectives on ONE GPU: RCCL's single-rank all-reduce is not free -- rocprofv3 shows 20
+        # `__amd_rocclr_copyBuffer` launches per call (profiles/r05_e_dp_single_*_kernel_stats.csv) that a real ring never runs.
+        # With this flag the collective is an event hand-off on a side stream and nothing else, so what remains is THIS
+        # package's plumbing: staged backward, the cross-stream events, the update after the last bucket.
+        assert world == 1, '--null-collective is a one-GPU measurement aid'
+        _cs = torch.cuda.Stream()
+
+        class _Work:
+            def __init__(self, ev):
+                self.ev = ev
+
+            def wait(self):
+                torch.cuda.current_stream().wait_event(self.ev)
+
+        def _null_all_reduce(t, op=None, async_op=False):
+            _cs.wait_stream(torch.cuda.current_stream())
+            ev = torch.cuda.Event()
+            ev.record(_cs)
+            w = _Work(ev)
+            if async_op:
+                return w
+            w.wait()
+            return None
+        dist.all_reduce = _null_all_reduce
 
     if args.mode == 'augment':
         return bench_augment(args, rank, world, local)

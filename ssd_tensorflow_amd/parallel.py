@@ -13,6 +13,16 @@ import torch
 import torch.distributed as dist
 
 
+def reserve_hw_queues():
+    """A process that creates an RCCL communicator needs more hardware queues than ROCm's default four
+    (GPU_MAX_HW_QUEUES): the executor keeps three streams busy (caller's, heads / side, weight gradients), RCCL brings its
+    own, and a stream that has to SHARE a queue with another is time-multiplexed.  Measured on one MI355X, bf16 step,
+    single-rank group (profiles/r05_g_dp_hw_queues.txt): no group 6.92 ms; group initialised -- even if never used -- 7.15-7.19 ms
+    (+3.5 %); the same with 8 queues 6.95-6.99 ms.  The variable is read when the HIP runtime starts, so this must run before
+    the first torch.cuda call (train.py and bench.py call it first thing; a value the user set wins)."""
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
 def env():
     """(rank, local_rank, world_size) from the launcher's environment.  SSD_FORCE_DEVICE pins the GPU ordinal of
     every rank (plumbing tests on a one-GPU box: all ranks on GPU 0, backend gloo)."""
@@ -22,6 +32,8 @@ def env():
 
 def init(backend=None):
     rank, local, world = env()
+    if world > 1:
+        reserve_hw_queues()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
