@@ -667,8 +667,10 @@ __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH 
 // FIRSTW (round 5; data gradient of conv1_2 only): the layer below is the FIRST layer (conv1_1: 3 input channels, K = taps x 3
 // = 27 <= 32), whose only use for this kernel's result is its weight gradient dW1[k][n] = sum_pixels im2col(image)[pixel][k] *
 // dx[pixel][n].  The dx rows of a tile are in LDS anyway (the write-out staging): each wave multiplies its 32 rows against the
-// 32 im2col rows of the same pixels (built from the fp32 image by all threads, one 16-byte LDS store per pixel and 8 k; k = 27
-// carries a one so that row 27 of the product is the bias gradient) -- 4 MFMAs per wave and tile beside the 72 of the
+// 32 im2col rows of the same pixels (k = 27 carries a one so that row 27 of the product is the bias gradient).  The im2col
+// tile is built from three linear RUNS of the image (pixels m0 - 1 + dh W ... + 254, dh = -1, 0, 1: contiguous memory, fetched
+// as coalesced dwords by all threads and parked in LDS as bf16 -- the first version gathered its 16 values per thread
+// straight from global memory, 4 bytes per lane and ~10 cache lines per instruction: + 2.2 us per tile) -- 4 MFMAs per wave and tile beside the 72 of the
 // convolution -- into accumulators that live for the whole kernel; the workgroup's eight partial products are added in wave
 // order at the end and leave as ONE slab.  dx itself is never written: 368 MB less to store and 368 MB less to read back at
 // batch 32, and conv1_1's own weight-gradient kernel is not launched (0.274 + 0.126 ms -> one kernel).
@@ -684,6 +686,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
     constexpr int AROWS = 256, BMV = 253, A_BYTES = AROWS * 128, B_TAP = 64 * 128, A_BASE = 9 * B_TAP;
     constexpr int ZROW = (AROWS - 1) * 128;
     constexpr int XT_BASE = A_BASE + 2 * A_BYTES, XROWB = 64;      // FIRSTW: im2col tile [256 pixels][32 k] bf16
+    constexpr int SR_BASE = XT_BASE + 256 * XROWB, SR_RUN = (BMV + 2) * 3;      // ... and three runs of BMV + 2 image pixels x 3 channels (bf16), one per kernel row
     static_assert(!FIRSTW || MODE == MODE_DGRAD, "the fused first-layer weight gradient belongs to the data gradient");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
 
     // FIRSTW: im2col staging map -- thread -> pixel rows (tid >> 2) + 128 pass, k = 8 (tid & 3) .. + 7
     const int xr = tid >> 2, xq = tid & 3;
-    int koff[8];
+    int sidx[8];                 // this thread's 8 k: element (kh, (kw) * 3 + c) of the runs, relative to its pixel
     unsigned kbit[8];
     f32x16 accw[2];
     __amdgpu_buffer_rsrc_t img_rsrc = src_rsrc;
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             const int k = xq * 8 + j;
             const bool kv = k < K;
             const int tp = kv ? k / fw.Ci : 0, c = kv ? k - tp * fw.Ci : 0;
-            koff[j] = ((fw.tap_dh[tp] * p.DW + fw.tap_dw[tp]) * fw.Ci + c) * 4;
+            sidx[j] = (tp / 3) * SR_RUN + (tp % 3) * 3 + c;      // (3x3 taps in kh-major order, dh = kh - 1, dw = kw - 1: host check)
             kbit[j] = kv ? (1u << tp) : 0u;
         }
 #pragma unroll
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
         // (one workgroup per CU: nothing else would hide that round trip)
         u32x2 pre_old[2][4];
         u32x4 row_mask[4];
-        float xim[2][8];
+        float simg[5];
 #pragma unroll
         for (int kr = 0; kr < 3; ++kr, ++gunit) {
             wait_tiles_and_sync<1>(0);                    // this unit's tile (and, the first time, the filter) has landed
@@ -820,7 +823,23 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             if (kr < 2) issue(tile, kr + 1, (gunit + 1) & 1);
             else if (tile + tstep < tend) issue(tile + tstep, 0, (gunit + 1) & 1);
             if constexpr (FIRSTW) {
-                if (kr == 1) {      // the tile's im2col values: 16 gathers per thread, in flight while two kernel rows multiply
+                unsigned short* SR = reinterpret_cast<unsigned short*>(smem + SR_BASE);
+                if (kr == 0) {      // the three image runs of this tile: 3 x 765 dwords, coalesced, in flight while the first kernel row multiplies
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int g = tid + 512 * u;
+                        const int sr = g / SR_RUN, e = g - sr * SR_RUN;
+                        const long long first = (long long)(m0 - 1 + (sr - 1) * p.DW) * 3 + e;      // dword index in the image (negative / past the end: zero)
+                        const unsigned off = (g < 3 * SR_RUN && first >= 0 && first < (long long)p.M * 3) ? (unsigned)first * 4u : OOBH;
+                        simg[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rsrc, off, 0, 0));
+                    }
+                } else if (kr == 1) {      // (landed: the unit's wait drains vmcnt) -> LDS as bf16; published by the next unit's barrier
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int g = tid + 512 * u;
+                        if (g < 3 * SR_RUN) SR[g] = f2bf(simg[u]);
+                    }
+                } else {      // im2col rows of this thread's two pixels x 8 k: 16 two-byte LDS reads, one 16-byte store each
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
                         const int r2 = xr + 128 * ps, m2 = m0 + r2;
@@ -829,18 +848,20 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                         const int ow = mm % p.DW, t2 = mm / p.DW;
                         const int oh = t2 % p.DH;
                         unsigned mk = 0;
-                        for (int t = 0; t < fw.ntaps; ++t) {
-                            const int sh = oh + fw.tap_dh[t], sw = ow + fw.tap_dw[t];
+                        for (int t = 0; t < 9; ++t) {
+                            const int sh = oh + t / 3 - 1, sw = ow + t % 3 - 1;
                             if ((unsigned)sh < (unsigned)p.DH && (unsigned)sw < (unsigned)p.DW) mk |= 1u << t;
                         }
                         if (!pv) mk = 0;
-                        const unsigned base = (unsigned)mm * (unsigned)(fw.Ci * 4);
+                        unsigned hv[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const unsigned ok = 0u - (unsigned)((mk & kbit[j]) != 0u);
-                            xim[ps][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rsrc, ((base + (unsigned)koff[j]) & ok) | (OOBH & ~ok), 0, 0));
+                            const unsigned v = SR[sidx[j] + r2 * 3];
+                            hv[j] = (mk & kbit[j]) ? v : 0u;
                         }
-                        if (xq == 3) xim[ps][3] = pv ? 1.f : 0.f;      // k = 27 = K (host check): the ones column -> row 27 of the product is the bias gradient
+                        if (xq == 3) hv[3] = pv ? 0x3F80u : 0u;      // k = 27 = K (host check): the ones column -> row 27 of the product is the bias gradient
+                        *reinterpret_cast<u32x4*>(smem + XT_BASE + r2 * XROWB + xq * 16) =
+                            u32x4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
                     }
                 }
             }
@@ -872,13 +893,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
             // accumulators every 128-byte line is touched by 8 different 16-byte requests (and as many for the mask).  The
             // staging area is this wave's 32 rows of the activation buffer the last unit has just consumed; 16-byte chunk c
             // of row r lives at chunk c ^ sw(r).
-            if constexpr (FIRSTW) {
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps)
-                    *reinterpret_cast<u32x4*>(smem + XT_BASE + (xr + 128 * ps) * XROWB + xq * 16) =
-                        u32x4{pack2(xim[ps][0], xim[ps][1]), pack2(xim[ps][2], xim[ps][3]), pack2(xim[ps][4], xim[ps][5]), pack2(xim[ps][6], xim[ps][7])};
-            }
-            __syncthreads();                              // the neighbours have read their halo rows of that buffer
+            __syncthreads();                              // the neighbours have read their halo rows of that buffer (FIRSTW: and the im2col tile is complete)
             unsigned char* S = smem + A_BASE + ((gunit - 1) & 1) * A_BYTES + wave * (32 * 128);
             const int swl = (li ^ (li >> 3)) & 7;
 #pragma unroll
@@ -2609,7 +2624,8 @@ void conv_dgrad_first_wgrad_bf16(const ConvDesc& d, const bf16_t* dy, const bf16
             fw.tap_dh[kh * 3 + kw] = kh - d1.pad_h;
             fw.tap_dw[kh * 3 + kw] = kw - d1.pad_w;
         }
-    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128 + 256 * 64;
+    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * 256 * 128 + 256 * 64 + 3 * 255 * 3 * 2 + 26;      // + the im2col tile + three image runs (bf16)
+    static_assert(lds <= 160 * 1024, "LDS");
     const int ntiles = cdiv(a.M, 253);
     const int grid = ntiles < 256 ? ntiles : 256;
     {
