@@ -2332,14 +2332,14 @@ static void check_desc_h(const ConvDesc& d) {
 //   3: 256x128 x3 (1/CU)   4: 128x128 x4 (1/CU)  5: 128x64 x3 (2/CU)
 //   6: 256x128 x3, 8 waves (1/CU)   7: 256x128 x2, 8 waves (1/CU)   8: 256x64 x2, 8 waves (2/CU)
 //   9: 64x64 x6 (1/CU): the latency-bound small layers (see pick_tile_h)   10: 64x64 x2, k split over 4 wave groups (16 waves, 1/CU)
-constexpr int NCFG_H = 11;
+constexpr int NCFG_H = 12;
 static int pick_tile_h(long long M, int N, int mode, int nk = 0) {
     static const int forced = env_int("SSD_TILE_BF16", -1);      // tuning override
     if (forced >= 0 && forced < NCFG_H) return forced;
-    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256, 64, 64}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
-    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2, 1, 1};
+    static const int bm[NCFG_H] = {128, 128, 64, 256, 128, 128, 256, 256, 256, 64, 64, 64}, bn[NCFG_H] = {128, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 64};
+    static const int per_cu[NCFG_H] = {2, 2, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2};
     // > 0: in the automatic choice.  256x64 (8 waves) serves the 64-channel layers: conv1_2 forward 427 -> 462, data gradient 423 -> 474 TF/s
-    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93, 0.0, 0.0};
+    static const double eff[NCFG_H] = {1.0, 0.85, 0.85, 0.0, 0.0, 0.0, 0.0, 0.0, 0.93, 0.0, 0.0, 0.0};
     int best = 0;
     double bc = 1e300;
     for (int c = 0; c < NCFG_H; ++c) {
@@ -2368,8 +2368,9 @@ static int pick_tile_h(long long M, int N, int mode, int nk = 0) {
                 best = 9;
                 // ... and with at least 8 iterations to share, four wave groups split the k loop (conv_gather_bf16_kernel, KSPLIT):
                 // SSD_SMALL_KSPLIT=0 keeps the deep ring
-                static const int ksplit = env_int("SSD_SMALL_KSPLIT", 1);
-                if (ksplit && nk >= 8) best = 10;
+                static const int ksplit = env_int("SSD_SMALL_KSPLIT", 1);      // 1: four wave groups (16 waves, 128 KB of LDS: needs an EMPTY CU); 2: two groups (8 waves, 64 KB)
+                if (ksplit == 2 && nk >= 8) best = 11;
+                else if (ksplit && nk >= 8) best = 10;
             }
         }
     }
@@ -2381,14 +2382,14 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
     static const char* const names[2][NCFG_H] = {
         {"conv_fwd_bf16_128x128", "conv_fwd_bf16_128x64", "conv_fwd_bf16_64x128", "conv_fwd_bf16_256x128x3", "conv_fwd_bf16_128x128x4",
          "conv_fwd_bf16_128x64x3", "conv_fwd_bf16_256x128x3_8w", "conv_fwd_bf16_256x128x2_8w", "conv_fwd_bf16_256x64_8w", "conv_fwd_bf16_64x64x6",
-         "conv_fwd_bf16_64x64_k4"},
+         "conv_fwd_bf16_64x64_k4", "conv_fwd_bf16_64x64_k2"},
         {"conv_dgrad_bf16_128x128", "conv_dgrad_bf16_128x64", "conv_dgrad_bf16_64x128", "conv_dgrad_bf16_256x128x3",
          "conv_dgrad_bf16_128x128x4", "conv_dgrad_bf16_128x64x3", "conv_dgrad_bf16_256x128x3_8w", "conv_dgrad_bf16_256x128x2_8w",
-         "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6", "conv_dgrad_bf16_64x64_k4"}};
+         "conv_dgrad_bf16_256x64_8w", "conv_dgrad_bf16_64x64x6", "conv_dgrad_bf16_64x64_k4", "conv_dgrad_bf16_64x64_k2"}};
     static const char* const unpool_names[NCFG_H] = {
         "conv_dgrad_unpool_bf16_128x128", "conv_dgrad_unpool_bf16_128x64", "conv_dgrad_unpool_bf16_64x128", "conv_dgrad_unpool_bf16_256x128x3",
         "conv_dgrad_unpool_bf16_128x128x4", "conv_dgrad_unpool_bf16_128x64x3", "conv_dgrad_unpool_bf16_256x128x3_8w", "conv_dgrad_unpool_bf16_256x128x2_8w",
-        "conv_dgrad_unpool_bf16_256x64_8w", "conv_dgrad_unpool_bf16_64x64x6", "conv_dgrad_unpool_bf16_64x64_k4"};
+        "conv_dgrad_unpool_bf16_256x64_8w", "conv_dgrad_unpool_bf16_64x64x6", "conv_dgrad_unpool_bf16_64x64_k4", "conv_dgrad_unpool_bf16_64x64_k2"};
     const char* label = unpool ? unpool_names[cfg] : names[MODE][cfg];
     switch (cfg) {
     case 0: launch_gather_h<MODE, 2, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
@@ -2401,6 +2402,7 @@ static void launch_gather_cfg(int cfg, GatherArgsH& a, double fl, double by, hip
     case 7: launch_gather_h<MODE, 4, 2, 2, 2, false, 2>(a, label, fl, by, s); break;
     case 8: launch_gather_h<MODE, 8, 1, 1, 2, false, 2>(a, label, fl, by, s); break;
     case 9: launch_gather_h<MODE, 2, 2, 1, 1, false, 6>(a, label, fl, by, s); break;
+    case 11: launch_gather_h<MODE, 2, 2, 1, 1, false, 2, false, 2>(a, label, fl, by, s); break;
     default: launch_gather_h<MODE, 2, 2, 1, 1, false, 2, false, 4>(a, label, fl, by, s); break;
     }
 }
@@ -2570,7 +2572,9 @@ static void conv_dgrad_bf16_any(const ConvDesc& d, const bf16_t* dy, const bf16_
                 ++c.nclass;
             }
         c.M = c.cls_M[0]; c.DH = c.cls_DH[0]; c.DW = c.cls_DW[0]; c.ntaps = c.cls_ntaps[0];
-        if (small) launch_gather_h<MODE_DGRAD, 2, 2, 1, 1, false, 2, true, 4>(c, "conv_dgrad_bf16_parity_64x64_k4", fl, by, s, c.cls_wg0[c.nclass]);
+        static const int small_k2 = env_int("SSD_SMALL_KSPLIT", 1) == 2;
+        if (small && small_k2) launch_gather_h<MODE_DGRAD, 2, 2, 1, 1, false, 2, true, 2>(c, "conv_dgrad_bf16_parity_64x64_k2", fl, by, s, c.cls_wg0[c.nclass]);
+        else if (small) launch_gather_h<MODE_DGRAD, 2, 2, 1, 1, false, 2, true, 4>(c, "conv_dgrad_bf16_parity_64x64_k4", fl, by, s, c.cls_wg0[c.nclass]);
         else launch_gather_h<MODE_DGRAD, 2, 2, 2, 2, false, 2, true>(c, "conv_dgrad_bf16_parity_128x128", fl, by, s, c.cls_wg0[c.nclass]);
         return;
     }
@@ -2794,6 +2798,8 @@ static int rows8_mode() {
 }
 static bool rows8_applicable(const ConvDesc& d) {
     const bool shape = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Hi == d.Ho && d.Wi == d.Wo;
+    // (round 5 tried the fused heads -- Co = 104 / 152 -- on the per-tap kernel, because a rows8 launch takes every CU's LDS for
+    // 60-80 us while backward's latency-bound chain runs beside it: the step did not move, profiles/r05_m_ab_tail_bf16.txt)
     return shape && rows8_mode() >= 2 && d.Ci >= 128 && rows_mode() != 2;
 }
 // one workgroup per CU and a single round: the fewest pixel splits (= the least fp32 slab traffic) that fill the chip

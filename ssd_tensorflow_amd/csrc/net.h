@@ -210,6 +210,7 @@ private:
     float* wgrad_ws_ = nullptr;
     float* l2_ws_ = nullptr;
     void* pool_ws_ = nullptr;
+    int pool_arg_op_ = -1;               // the 3x3 stride-1 pool whose first-maximum taps the last training forward left in pool_ws_
     void* loss_ws_ = nullptr;
     LossWork lw_{};
     static constexpr int LOSS_RING = 4;

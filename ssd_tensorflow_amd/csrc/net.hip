@@ -480,7 +480,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     init_weights(seed);
     const char* ov = getenv("SSD_OVERLAP_WGRAD");
     overlap_ = !(ov && ov[0] == '0');
-    HIP_OK(hipStreamCreateWithFlags(&hstream_, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&hstream_, hipStreamNonBlocking));      // (a high-priority side stream was measured again in round 5: +-0)
     HIP_OK(hipEventCreateWithFlags(&ev_h_, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ev_cast_, hipEventDisableTiming));
 
@@ -560,6 +560,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d (max_batch)", b, Bmax_);
     g_prof = &prof_;
     tensors_[input_t_].data = const_cast<float*>(x);
+    pool_arg_op_ = -1;
     const bool side = hstream_ && overlap_;
     static const int lanes_env = [] { const char* v = getenv("SSD_FWD_LANES"); return v ? atoi(v) : 0; }();
     const int want_lanes = lanes_env > 0 ? lanes_env : 2;
@@ -611,13 +612,28 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         l2_partials(params_, nfilters_, lw_, side ? hstream_ : stream_);
         if (nl == 2) HIP_OK(hipEventRecord(ev_l2_, hstream_));
     }
+    // Round 5: the lanes MERGE at conv8_1.  The extra layers behind it are a chain of sixteen dependent launches of a handful of
+    // workgroups each (conv8_1 ... conv11_2 on two lanes: 6-37 us per launch, every one of them latency- not work-bound): a
+    // timeline of the step (profiles/r05_j_timeline_bf16.txt) shows 285 us between mod_conv7 and the loss with a nearly empty chip.
+    // One lane runs the eight layers once, at twice the rows per launch and the same latency; the second lane's stream -- idle
+    // from here on -- takes every other small head, which used to queue behind each other on the one side stream.
+    // (Round 4 merged at the 19x19 maps, i.e. incl. conv5_x / mod_conv6, where two lanes fill each other's partial rounds: slower.)
+    static const bool merge_tail = env_i("SSD_FWD_MERGE_TAIL", 1) != 0;      // A/B switch
+    int nl_cur = nl;
+    int small_heads = 0;
     for (const int op_index : fwd_order_) {
         const Op& op = ops_[op_index];
         const Tensor& in = tensors_[op.in];
         const Tensor& out = tensors_[op.out];
         prof_.layer = op.name.c_str();
         if (op_ablated(op.name, op.kind, op.head, op.k)) continue;
-        for (int li = 0; li < nl; ++li) {
+        if (nl_cur == 2 && merge_tail && heads_full && op_index == tail_first_) {
+            HIP_OK(hipEventRecord(ev_join_, s2_));
+            HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
+            lane[0].nb = b;
+            nl_cur = 1;
+        }
+        for (int li = 0; li < nl_cur; ++li) {
             Lane& ln = lane[li];
             const int nb = ln.nb;
             switch (op.kind) {
@@ -632,9 +648,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                         // ONE launch over the whole batch on lane 0's side stream, behind both lanes' feature maps: half the
                         // launches, twice the workgroups each, and lane 1's trunk (whose own "side" stream is its main
                         // stream) does not queue behind its heads
-                        if (li < nl - 1) break;
-                        for (int l = 0; l < nl; ++l) HIP_OK(hipStreamWaitEvent(hstream_, lane[l].ev_fmap[op.head], 0));
-                        cs = hstream_;
+                        if (li < nl_cur - 1) break;
+                        // (after the merge: the small maps' heads alternate between the side stream and the idle second lane's)
+                        cs = (nl_cur == 1 && op.head >= 2 && (small_heads++ & 1)) ? s2_ : hstream_;
+                        for (int l = 0; l < nl_cur; ++l) HIP_OK(hipStreamWaitEvent(cs, lane[l].ev_fmap[op.head], 0));
                         run_nb = b; run_b0 = 0;
                         lane[0].heads_on_side = true;
                     } else {
@@ -647,7 +664,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 struct LanesScope {      // (tile choice of the bf16 kernel-row gather: the lanes share the chip's workgroup slots)
                     LanesScope(int n) { g_conv_lanes = n; }
                     ~LanesScope() { g_conv_lanes = 1; }
-                } lanes_scope(run_nb == nb ? nl : 1);
+                } lanes_scope(run_nb == nb ? nl_cur : 1);
                 if (ln.cast_pending && !in.data_f32) {
                     HIP_OK(hipStreamWaitEvent(ln.s, ev_cast_, 0));
                     ln.cast_pending = false;
@@ -686,6 +703,12 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     void* rec = static_cast<char*>(op.pool_rec) + (size_t)ln.b0 * out.H * out.W * (in.C / 4) * sizeof(unsigned short);
                     if (bf16_) maxpool_fwd_rec(d, reinterpret_cast<const bf16_t*>(at(in, ln.b0)), reinterpret_cast<bf16_t*>(at(out, ln.b0)), rec, ln.s);
                     else maxpool_fwd_rec(d, reinterpret_cast<const float*>(at(in, ln.b0)), reinterpret_cast<float*>(at(out, ln.b0)), rec, ln.s);
+                } else if (train_mode && pool_ws_ && maxpool_arg_applicable(d)) {
+                    // mod_pool5: the windows' first-maximum taps stay in pool_ws_ (this pool is its only user) for backward
+                    void* arg = static_cast<char*>(pool_ws_) + (size_t)ln.b0 * out.H * out.W * (in.C / 4) * sizeof(unsigned);
+                    if (bf16_) maxpool_fwd_arg(d, reinterpret_cast<const bf16_t*>(at(in, ln.b0)), reinterpret_cast<bf16_t*>(at(out, ln.b0)), arg, ln.s);
+                    else maxpool_fwd_arg(d, reinterpret_cast<const float*>(at(in, ln.b0)), reinterpret_cast<float*>(at(out, ln.b0)), arg, ln.s);
+                    pool_arg_op_ = op_index;
                 } else if (bf16_) maxpool_fwd(d, reinterpret_cast<const bf16_t*>(at(in, ln.b0)), reinterpret_cast<bf16_t*>(at(out, ln.b0)), ln.s);
                 else maxpool_fwd(d, reinterpret_cast<const float*>(at(in, ln.b0)), reinterpret_cast<float*>(at(out, ln.b0)), ln.s);
                 break;
@@ -890,6 +913,9 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             if (op.pool_rec && in.done == 0 && last) {      // single consumer: dx is overwritten from the forward record
                 if (bf16_) maxpool_bwd_rec(d, op.pool_rec, out.gh(), in.gh(), in.relu_out, stream_);
                 else maxpool_bwd_rec(d, op.pool_rec, out.gf(), in.gf(), in.relu_out, stream_);
+            } else if (pool_arg_op_ == op_index && pws && maxpool_arg_applicable(d)) {      // the forward pass of this step left the record
+                if (bf16_) maxpool_bwd_arg(d, in.h(), pws, out.gh(), in.gh(), in.done > 0, last && in.relu_out, stream_);
+                else maxpool_bwd_arg(d, in.f(), pws, out.gf(), in.gf(), in.done > 0, last && in.relu_out, stream_);
             } else if (bf16_)
                 maxpool_bwd(d, in.h(), out.gh(), in.gh(), in.done > 0, last && in.relu_out, pws, stream_);
             else

@@ -23,6 +23,14 @@ void maxpool_bwd(const PoolDesc& d, const float* x, const float* dy, float* dx, 
 void maxpool_bwd(const PoolDesc& d, const bf16_t* x, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask,
                  void* ws, hipStream_t s);
 
+// 3x3 stride-1 pooling whose forward pass keeps the windows' first-maximum taps in `arg` (maxpool_bwd_ws_bytes): backward from that
+// record is maxpool_bwd's second pass alone
+bool maxpool_arg_applicable(const PoolDesc& d);
+void maxpool_fwd_arg(const PoolDesc& d, const float* x, float* y, void* arg, hipStream_t s);
+void maxpool_fwd_arg(const PoolDesc& d, const bf16_t* x, bf16_t* y, void* arg, hipStream_t s);
+void maxpool_bwd_arg(const PoolDesc& d, const float* x, const void* arg, const float* dy, float* dx, bool accumulate, bool relu_mask, hipStream_t s);
+void maxpool_bwd_arg(const PoolDesc& d, const bf16_t* x, const void* arg, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask, hipStream_t s);
+
 // 2x2 stride-2 pooling with a forward-written record (per window and channel: first maximum's cell + "maximum is
 // positive"): backward = record + dy -> dx without re-reading the pooled tensor.  For a pooled tensor with a single
 // consumer (dx is overwritten, not accumulated); relu_mask as above.

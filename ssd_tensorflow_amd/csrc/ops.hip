@@ -530,6 +530,36 @@ size_t maxpool_bwd_ws_bytes(const PoolDesc& d) {
 void maxpool_fwd(const PoolDesc& d, const float* x, float* y, hipStream_t s) { maxpool_fwd_t(d, x, y, s); }
 void maxpool_fwd(const PoolDesc& d, const bf16_t* x, bf16_t* y, hipStream_t s) { maxpool_fwd_t(d, x, y, s); }
 
+// 3x3 stride-1 pooling (mod_pool5) whose forward pass keeps every window's first-maximum tap (the scratch of maxpool_bwd, 4
+// bytes per window and 4 channels): backward then runs its second pass only -- the first one, which recomputes exactly this,
+// sat on the data-gradient chain's critical path (28 of 51 us at batch 32, profiles/r05_l_timeline_merged_tail_bf16.txt)
+bool maxpool_arg_applicable(const PoolDesc& d) { return d.k == 3 && d.stride == 1 && d.C % 4 == 0 && (double)d.B * d.Hi * d.Wi * d.C < 2.0e9; }
+template <typename T>
+static void maxpool_fwd_arg_t(const PoolDesc& d, const T* x, T* y, void* arg, hipStream_t s) {
+    SSD_REQUIRE(maxpool_arg_applicable(d) && arg != nullptr, "maxpool_fwd_arg: 3x3 stride-1 pooling with a record buffer");
+    const size_t total = (size_t)d.B * d.Ho * d.Wo * (d.C / 4);
+    ProfScope prof("maxpool_fwd", 0.0, sizeof(T) * (double)d.C * d.B * ((double)d.Hi * d.Wi + (double)d.Ho * d.Wo) + 4.0 * total, s);
+    hipLaunchKernelGGL((maxpool_taps_kernel<T, 3>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, y, (unsigned*)arg);
+    HIP_OK(hipGetLastError());
+}
+template <typename T>
+static void maxpool_bwd_arg_t(const PoolDesc& d, const T* x, const void* arg, const T* dy, T* dx, bool accumulate, bool relu_mask, hipStream_t s) {
+    SSD_REQUIRE(maxpool_arg_applicable(d) && arg != nullptr, "maxpool_bwd_arg: 3x3 stride-1 pooling with the forward pass' record");
+    const size_t total = (size_t)d.B * d.Hi * d.Wi * (d.C / 4);
+    ProfScope prof("maxpool_bwd", 0.0, sizeof(T) * (double)d.C * d.B * (2.0 * d.Hi * d.Wi + (double)d.Ho * d.Wo), s);
+    hipLaunchKernelGGL((maxpool_bwd_arg_s1_kernel<T, 3>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, d, x, (const unsigned*)arg, dy, dx,
+                       (int)accumulate, (int)relu_mask);
+    HIP_OK(hipGetLastError());
+}
+void maxpool_fwd_arg(const PoolDesc& d, const float* x, float* y, void* arg, hipStream_t s) { maxpool_fwd_arg_t(d, x, y, arg, s); }
+void maxpool_fwd_arg(const PoolDesc& d, const bf16_t* x, bf16_t* y, void* arg, hipStream_t s) { maxpool_fwd_arg_t(d, x, y, arg, s); }
+void maxpool_bwd_arg(const PoolDesc& d, const float* x, const void* arg, const float* dy, float* dx, bool accumulate, bool relu_mask, hipStream_t s) {
+    maxpool_bwd_arg_t(d, x, arg, dy, dx, accumulate, relu_mask, s);
+}
+void maxpool_bwd_arg(const PoolDesc& d, const bf16_t* x, const void* arg, const bf16_t* dy, bf16_t* dx, bool accumulate, bool relu_mask, hipStream_t s) {
+    maxpool_bwd_arg_t(d, x, arg, dy, dx, accumulate, relu_mask, s);
+}
+
 template <typename T>
 static void maxpool_bwd_t(const PoolDesc& d, const T* x, const T* dy, T* dx, bool accumulate, bool relu_mask, void* ws,
                           hipStream_t s) {
