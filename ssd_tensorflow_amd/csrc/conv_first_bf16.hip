@@ -307,10 +307,10 @@ static int first_wgrad_splits(const ConvDesc& d, int* mchunk) {
     const int M = d.B * d.Ho * d.Wo;
     int ns = cdiv(M, 64 * 24);                 // >= 24 iterations per workgroup
     // Bytes in flight set this kernel's rate (one 8-KB dy tile per workgroup: 1024 x 8 KB / ~3 us of loaded round trip =
-    // 2.8 TB/s, measured 2.5): 88 registers let five workgroups share a CU -> 1280 (SSD_FIRST_WGRAD_WGS; 1024 = round 2).
+    // 2.8 TB/s, measured 2.5): 88 registers let five workgroups share a CU -> 1280 (1024 = round 2).
     // Round 3, per-layer events of the step: 0.159 ms -> 0.136 with the bias gradient on the matrix cores -> 0.129 with
     // 1280 workgroups; 1536 (a second, partial round) gains nothing.
-    static const int cap = env_int("SSD_FIRST_WGRAD_WGS", 1280);
+    constexpr int cap = 1280;
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     *mchunk = cdiv(cdiv(M, ns), 64) * 64;

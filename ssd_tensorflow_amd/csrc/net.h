@@ -21,6 +21,8 @@ struct Tensor {
     int done = 0;            // backward bookkeeping
     int gstream = 0;         // backward: stream class (0 main, 1 side) of the last kernel that wrote grad ...
     long gseq = 0;           // ... and its number in that class' issue order (net.hip bw_need)
+    hipEvent_t gev = nullptr;    // optional: recorded behind every kernel that writes grad, so a reader on the other class waits for
+    bool gev_set = false;        // THAT kernel instead of everything its class has been given (the small heads' feature maps)
     bool data_f32 = true;    // storage of data: fp32, or bf16 (bf16 configuration, every tensor but the image and the head outputs)
     bool grad_f32 = true;    // storage of grad
     void* data = nullptr;
@@ -187,8 +189,8 @@ private:
     void plan_pool_fusion();
     int bw_class(const Op& op, int op_index) const;
     void bw_sync(int x, int y);          // class x waits for everything class y has been given so far
-    void bw_need(int x, const Tensor& t) { if (t.gstream != x && t.gseq > bw_seen_[x][t.gstream]) bw_sync(x, t.gstream); }
-    void bw_wrote(int x, Tensor& t) { t.gstream = x; t.gseq = ++bw_issued_[x]; }
+    void bw_need(int x, const Tensor& t);
+    void bw_wrote(int x, Tensor& t);
     size_t bw_final_lo() const;          // lowest arena offset such that every filter at or above it has its final gradient
     bool overlap_ = true;
     bool own_wstream_ = true;

@@ -245,9 +245,15 @@ void Net::build_orders() {
 }
 
 // stream class of an op's data gradient in backward: 0 = main stream, 1 = side stream (see build_orders)
+// Round 5: of the small maps' heads only the LAST one's data gradient starts the side chain (conv11_2's needs it); the others'
+// (maps 2 .. n-2) run on the MAIN stream in front of the two big heads.  On the one side stream the four of them ran back to back
+// -- 200 us at 30-66 us each beside the big heads' kernels -- before conv11_2's data gradient could start, and the main stream then
+// waited 316 us for the chain's end (profiles/r05_l_timeline_merged_tail_bf16.txt).  The chain picks their results up through an
+// event per feature map (Tensor::gev), not through a join of the streams.  SSD_BW_SMALL_HEADS_MAIN=0: all of them on the side stream.
 int Net::bw_class(const Op& op, int op_index) const {
     if (!(hstream_ && overlap_)) return 0;
-    if (op.kind == OP_CONV && op.head >= 2) return 1;                              // small maps' heads: a few workgroups each
+    static const bool small_main = env_i("SSD_BW_SMALL_HEADS_MAIN", 1) != 0;
+    if (op.kind == OP_CONV && op.head >= 2) return (small_main && op.head != heads_.nmaps - 1) ? 0 : 1;      // small maps' heads: a few workgroups each
     if (op.kind == OP_CONV && op.head < 0 && op_index > tail_first_) return 1;     // conv11_2 ... conv8_2 behind them
     return 0;
 }
@@ -257,6 +263,21 @@ void Net::bw_sync(int x, int y) {
     HIP_OK(hipEventRecord(ev, y == 1 ? hstream_ : stream_));
     HIP_OK(hipStreamWaitEvent(x == 1 ? hstream_ : stream_, ev, 0));
     bw_seen_[x][y] = bw_issued_[y];
+}
+
+void Net::bw_need(int x, const Tensor& t) {
+    if (t.gstream == x || t.gseq <= bw_seen_[x][t.gstream]) return;
+    if (t.gev && t.gev_set) HIP_OK(hipStreamWaitEvent(x == 1 ? hstream_ : stream_, t.gev, 0));      // exactly the kernel that wrote it
+    else bw_sync(x, t.gstream);
+}
+
+void Net::bw_wrote(int x, Tensor& t) {
+    t.gstream = x;
+    t.gseq = ++bw_issued_[x];
+    if (t.gev) {
+        HIP_OK(hipEventRecord(t.gev, x == 1 ? hstream_ : stream_));
+        t.gev_set = true;
+    }
 }
 
 size_t Net::bw_final_lo() const {
@@ -510,6 +531,10 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
         HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     }
     plan_pool_fusion();
+    if (training_)
+        for (const Op& op : ops_)
+            if (op.kind == OP_CONV && op.head >= 2 && !tensors_[op.in].gev)
+                HIP_OK(hipEventCreateWithFlags(&tensors_[op.in].gev, hipEventDisableTiming));
 }
 
 Net::~Net() {
@@ -540,6 +565,8 @@ Net::~Net() {
         (void)hipEventDestroy(ev_dy_);
         (void)hipEventDestroy(ev_w_);
     }
+    for (Tensor& t : tensors_)
+        if (t.gev) (void)hipEventDestroy(t.gev);
     for (void* p : allocs_) (void)hipFree(p);
     if (losses_host_) (void)hipHostFree(losses_host_);
     for (int i = 0; i < LOSS_RING; ++i)
@@ -799,7 +826,7 @@ void Net::backward_begin(int b, const float* y) {
     g_prof = &prof_;
     prof_.layer = "loss";
     const bool side = hstream_ && overlap_;
-    for (Tensor& t : tensors_) { t.done = 0; t.gstream = 0; t.gseq = 0; }
+    for (Tensor& t : tensors_) { t.done = 0; t.gstream = 0; t.gseq = 0; t.gev_set = false; }
     bw_issued_[0] = bw_issued_[1] = 0;
     bw_seen_[0][0] = bw_seen_[0][1] = bw_seen_[1][0] = bw_seen_[1][1] = 0;
     multibox_loss_grad(heads_, b, 0, result_, y, lw_, stream_);
