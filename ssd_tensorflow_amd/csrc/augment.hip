@@ -179,13 +179,19 @@ __device__ static void hsv2bgr_u8(float* px) {
     }
 }
 
-__device__ static void photometric(const ssd_augment_params& p, int row, float* px) {
-    if (p.brightness_on)
-        for (int c = 0; c < 3; ++c) px[c] = u8f(px[c] + (float)p.brightness_delta);
-    for (int i = 0; i < p.n_distort; ++i) {
-        const int kind = p.distort_kind[i];
-        const float val = p.distort_val[i];
-        if (kind == 0) {                                   // contrast
+// one step of the chain on a pixel of image row `row`: kind 0 contrast, 1 saturation, 2 hue, 3 brightness, 4 channel reorder
+__device__ static void photometric_step(int kind, float val, int row, float* px) {
+    {
+        if (kind == 3) {                                   // brightness
+            for (int c = 0; c < 3; ++c) px[c] = u8f(px[c] + val);
+        } else if (kind == 4) {                            // reorder: out channel c = in channel (code >> 2c) & 3
+            const int code = (int)val;
+            const float q[3] = {px[0], px[1], px[2]};
+            for (int c = 0; c < 3; ++c) {
+                const int sc = (code >> (2 * c)) & 3;
+                px[c] = sc == 0 ? q[0] : (sc == 1 ? q[1] : q[2]);
+            }
+        } else if (kind == 0) {                            // contrast
             for (int c = 0; c < 3; ++c) px[c] = u8f(px[c] * val);
         } else if (kind == 1) {                            // saturation: HSV round trip; image ROW 1 is scaled (reference quirk)
             bgr2hsv_u8(px);
@@ -206,13 +212,25 @@ __device__ static void photometric(const ssd_augment_params& p, int row, float* 
     }
 }
 
+// the whole chain: brightness -> distort chain -> channel reorder (the reference's recipe order) -> the extra steps of a second pass
+__device__ static void photometric(const ssd_augment_params& p, int row, float* px) {
+    if (p.brightness_on) photometric_step(3, (float)p.brightness_delta, row, px);
+    for (int i = 0; i < p.n_distort; ++i) photometric_step(p.distort_kind[i], p.distort_val[i], row, px);
+    {
+        const float q[3] = {px[0], px[1], px[2]};
+        for (int c = 0; c < 3; ++c) px[c] = p.reorder[c] == 0 ? q[0] : (p.reorder[c] == 1 ? q[1] : q[2]);
+    }
+    for (int i = 0; i < p.n_extra; ++i) photometric_step(p.extra_kind[i], p.extra_val[i], row, px);
+}
+
 // Pass 0 (round 3): the photometric chain depends on the SOURCE pixel only, yet the gather evaluated it per tap -- up to 64
 // taps per output pixel (Lanczos), two HSV round trips each.  Its result is an exact uint8 value (every step ends in a
 // truncation / rounding to 0..255), so images whose chain is not the identity are transformed once, pixel by pixel, into a
 // uint8 copy in the workspace (AUG_PRE_BYTES per image; a larger image keeps the per-tap path) and the gather reads bytes.
 constexpr size_t AUG_PRE_BYTES = 1310720;      // 1.25 MiB: a 660 x 660 BGR image
 
-__device__ __forceinline__ bool aug_has_photometric(const ssd_augment_params& p) { return p.brightness_on || p.n_distort > 0; }
+// (a plan whose chain is a bare channel reorder reads the source bytes and permutes them in the gather)
+__device__ __forceinline__ bool aug_has_photometric(const ssd_augment_params& p) { return p.brightness_on || p.n_distort > 0 || p.n_extra > 0; }
 __device__ __forceinline__ bool aug_uses_pre(const ssd_augment_params& p) {
     return aug_has_photometric(p) && (size_t)p.src_w * p.src_h * 3 <= AUG_PRE_BYTES;
 }
@@ -278,8 +296,9 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
                 if (last_px) v = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
                 else v = *reinterpret_cast<const u32_unaligned*>(q);
                 float raw[3] = {(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u)};
-                if (per_tap) photometric(p, y0, raw);
-                for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
+                if (per_tap) photometric(p, y0, raw);      // (incl. the reorder)
+                if (per_tap || from_pre) { px[0] = raw[0]; px[1] = raw[1]; px[2] = raw[2]; }
+                else for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
             } else {
                 for (int c = 0; c < 3; ++c) px[c] = (float)mean[c];
             }
@@ -312,6 +331,8 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
         SSD_REQUIRE(p.src_w >= 1 && p.src_h >= 1 && p.crop_w >= 1 && p.crop_h >= 1, "augment: image %d has an empty source or crop window", i);
         SSD_REQUIRE(p.resize_alg >= 0 && p.resize_alg <= 4, "augment: image %d: unknown resize algorithm %d", i, p.resize_alg);
         SSD_REQUIRE(p.n_distort >= 0 && p.n_distort <= 3, "augment: image %d: distort chain length %d", i, p.n_distort);
+        SSD_REQUIRE(p.n_extra >= 0 && p.n_extra <= 8, "augment: image %d: %d extra photometric steps", i, p.n_extra);
+        for (int k = 0; k < p.n_extra; ++k) SSD_REQUIRE(p.extra_kind[k] >= 0 && p.extra_kind[k] <= 4, "augment: image %d: extra step kind %d", i, p.extra_kind[k]);
         for (int c = 0; c < 3; ++c) SSD_REQUIRE(p.reorder[c] >= 0 && p.reorder[c] <= 2, "augment: image %d: channel permutation", i);
         const double sx = (double)p.crop_w / out_w, sy = (double)p.crop_h / out_h;
         SSD_REQUIRE(p.resize_alg != ALG_AREA || (sx <= AUG_TMAX - 2 && sy <= AUG_TMAX - 2), "augment: image %d shrinks by more than %dx (INTER_AREA tap table)",
@@ -333,7 +354,7 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
     for (int i = 0; i < b; ++i) {
         const ssd_augment_params& p = params_host[i];
         const size_t bytes = (size_t)p.src_w * p.src_h * 3;
-        if ((p.brightness_on || p.n_distort > 0) && bytes <= AUG_PRE_BYTES && p.src_w * p.src_h > pre_pixels) pre_pixels = p.src_w * p.src_h;
+        if ((p.brightness_on || p.n_distort > 0 || p.n_extra > 0) && bytes <= AUG_PRE_BYTES && p.src_w * p.src_h > pre_pixels) pre_pixels = p.src_w * p.src_h;
     }
     if (pre_pixels > 0) {
         ProfScope prof("augment_photometric", 0.0, (double)b * pre_pixels * 6, s);

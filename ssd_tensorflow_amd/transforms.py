@@ -10,9 +10,16 @@ the host, exactly as the reference does (transform_box / transform_gt, transform
 
 LabelCreatorTransform (transforms.py:57-114) is backed by the HIP label encoder.
 
-Order the kernel supports (what process_dataset.py:126-136 builds): photometric* -> expand? -> crop* ->
-flip? -> resize.  A transform applied outside that order raises NotImplementedError rather than
-silently producing something else.
+The plan's canonical form is the reference's own recipe order (process_dataset.py:126-136): brightness -> distort chain ->
+channel reorder -> expand -> crop -> flip -> resize.  Round 5: transforms composed in OTHER orders are rewritten into that
+form wherever the composition is one (tests/test_augment.py runs them against the free composition of the oracle's pixel
+operations): a second photometric pass -- any brightness / contrast / saturation / hue / reorder after the canonical slots
+are taken -- becomes a list of up to 8 extra pointwise steps the kernel runs behind the canonical chain; photometric steps
+after a flip commute with it; a crop, an expand or another flip after a flip are mirrored index maps; a second expand adds
+its offsets.  What is NOT a composition of this form still raises NotImplementedError rather than silently producing
+something else: a photometric step after an expand or a crop (the image is floating point from the expand on, and Hue /
+Saturation index image ROWS 0 / 1 of the current array), an expand after a crop (the canvas would show source pixels the
+crop had removed), anything after ResizeTransform, another fill value than 104, 117, 123.
 """
 import ctypes as C
 import os
@@ -25,6 +32,8 @@ from . import _lib
 from ._lib import lib, check
 from .ssdutils import encode_labels_batch
 from .utils import Size, Sample, Point, Box, abs2prop, prop2abs
+
+MAX_EXTRA = 8        # ssd_augment_params.extra_kind / extra_val
 
 # cv2's interpolation enum values (the mirror does not import cv2)
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
@@ -42,6 +51,8 @@ class ImagePlan:
         self.brightness = None
         self.distort = []              # [(kind, value)] kind: 0 contrast, 1 saturation, 2 hue
         self.reorder = [0, 1, 2]
+        self.extra = []                # further pointwise steps behind the canonical chain, in order: (kind, value) with kind
+                                       # 0..2 as above, 3 brightness (value = delta), 4 reorder (value = [c0, c1, c2])
         self.expand = None             # (Size new, h_off, w_off)
         self.crop = None               # (x0, y0, w, h) in the (expanded) frame, before the flip
         self.flip = False
@@ -59,9 +70,17 @@ class ImagePlan:
         s = Size(self.resize[0], self.resize[1]) if self.resize is not None else self.size
         return (s.h, s.w, 3)
 
-    def _photometric_ok(self, what):
-        if self.expand is not None or self.crop is not None or self.flip or self.resize is not None:
-            raise NotImplementedError(what + ' after a geometric transform is outside the order the batch kernel runs')
+    def _photometric_ok(self, what, per_pixel=False):
+        # (a flip is a pure permutation of columns and the Hue / Saturation row quirk indexes ROWS: pointwise steps commute with it)
+        # per_pixel: brightness, contrast and the channel order act on every pixel alike, so they commute with a crop as well;
+        # hue / saturation act on image ROWS 0 / 1 (the reference's quirk, transforms.py:201-203,218-220), which a crop moves.
+        if self.expand is not None or self.resize is not None or (self.crop is not None and not per_pixel):
+            raise NotImplementedError(what + ' after an expand, a resize' + ('' if per_pixel else ', a crop') + ' is not a composition the batch kernel runs')
+
+    def _extra_step(self, kind, value, what):
+        if len(self.extra) >= MAX_EXTRA:
+            raise NotImplementedError(what + ': the batch kernel runs at most %d photometric steps behind the canonical chain' % MAX_EXTRA)
+        self.extra.append((kind, value))
 
     def _geometric_ok(self, what):
         if self.resize is not None:
@@ -150,20 +169,20 @@ class BrightnessTransform(Transform):
     """Parameters: delta (transforms.py:164-176)"""
     def __call__(self, data, label, gt):
         delta = random.randint(-self.delta, self.delta)
-        data._photometric_ok('BrightnessTransform')
-        if data.brightness is not None or data.distort or data.reorder != [0, 1, 2]:
-            raise NotImplementedError('the batch kernel runs brightness once, before the distort chain')
-        data.brightness = int(delta)
+        data._photometric_ok('BrightnessTransform', per_pixel=True)
+        if data.brightness is not None or data.distort or data.reorder != [0, 1, 2] or data.extra:
+            data._extra_step(3, int(delta), 'BrightnessTransform')      # the canonical slot is taken or behind us
+        else:
+            data.brightness = int(delta)
         return data, label, gt
 
 
 def _distort(data, kind, value, what):
-    data._photometric_ok(what)
-    if data.reorder != [0, 1, 2]:
-        raise NotImplementedError(what + ' after ReorderChannelsTransform is outside the order the batch kernel runs')
-    if len(data.distort) >= 3:
-        raise NotImplementedError('the batch kernel runs at most 3 distort steps')
-    data.distort.append((kind, float(value)))
+    data._photometric_ok(what, per_pixel=(kind == 0))
+    if data.reorder != [0, 1, 2] or data.extra or len(data.distort) >= 3:
+        data._extra_step(kind, float(value), what)
+    else:
+        data.distort.append((kind, float(value)))
 
 
 class ContrastTransform(Transform):
@@ -192,8 +211,11 @@ class ReorderChannelsTransform(Transform):
     def __call__(self, data, label, gt):
         channels = [0, 1, 2]
         random.shuffle(channels)
-        data._photometric_ok('ReorderChannelsTransform')
-        data.reorder = [data.reorder[c] for c in channels]
+        data._photometric_ok('ReorderChannelsTransform', per_pixel=True)
+        if data.extra:
+            data._extra_step(4, list(channels), 'ReorderChannelsTransform')
+        else:
+            data.reorder = [data.reorder[c] for c in channels]
         return data, label, gt
 
 
@@ -224,13 +246,17 @@ class ExpandTransform(Transform):
         h_off = random.randint(0, new_size.h - orig_size.h)
         w_off = random.randint(0, new_size.w - orig_size.w)
         data._geometric_ok('ExpandTransform')
-        if data.expand is not None or data.crop is not None or data.flip:
-            raise NotImplementedError('the batch kernel expands once, before any crop or flip')
+        if data.crop is not None:
+            raise NotImplementedError('an expand after a crop is not a composition the batch kernel runs (the canvas would show what the crop removed)')
         if list(getattr(self, 'mean_value', [104, 117, 123])) != [104, 117, 123]:
             raise NotImplementedError('the batch kernel fills with the mean value 104, 117, 123')
-        if (orig_size.w, orig_size.h) != tuple(data.src):
-            raise ValueError('gt.imgsize %s does not match the loaded image %s' % (orig_size, data.src))
-        data.expand = (new_size, int(h_off), int(w_off))
+        if (orig_size.w, orig_size.h) != tuple(data.size):
+            raise ValueError('gt.imgsize %s does not match the image at this point of the chain %s' % (orig_size, data.size))
+        # the plan expands BEFORE it flips: an expand behind a flip places the image at the mirrored column offset; a second
+        # expand adds its offsets to the first one's (the same fill value surrounds both canvases)
+        w_plan = new_size.w - orig_size.w - w_off if data.flip else w_off
+        h0, w0 = (data.expand[1], data.expand[2]) if data.expand is not None else (0, 0)
+        data.expand = (new_size, h0 + int(h_off), w0 + int(w_plan))
         gt = transform_gt(gt, new_size, h_off, w_off)
         return data, label, gt
 
@@ -282,10 +308,10 @@ class SamplerTransform(Transform):
         new_size = Size(int(window[1] - window[0]), int(window[3] - window[2]))
         out = _copy_plan(data)
         out._geometric_ok('SamplerTransform')
-        if out.flip:
-            raise NotImplementedError('the batch kernel crops before it flips')
+        # the plan crops BEFORE it flips: a window of the flipped frame is the mirrored window of the unflipped one
+        left_plan = out.size.w - (left + new_size.w) if out.flip else left
         x0, y0 = (out.crop[0], out.crop[1]) if out.crop is not None else (0, 0)
-        out.crop = (x0 + left, y0 + top, new_size.w, new_size.h)
+        out.crop = (x0 + left_plan, y0 + top, new_size.w, new_size.h)
         return out, label, transform_gt(gt, new_size, -top, -left)
 
 
@@ -294,6 +320,7 @@ def _copy_plan(p):
     q.__dict__.update(p.__dict__)
     q.distort = list(p.distort)
     q.reorder = list(p.reorder)
+    q.extra = list(p.extra)
     return q
 
 
@@ -371,7 +398,8 @@ class _Params(C.Structure):
                 ('reorder', C.c_int * 3),
                 ('expand_on', C.c_int), ('exp_w', C.c_int), ('exp_h', C.c_int), ('exp_hoff', C.c_int), ('exp_woff', C.c_int),
                 ('crop_x0', C.c_int), ('crop_y0', C.c_int), ('crop_w', C.c_int), ('crop_h', C.c_int),
-                ('flip', C.c_int), ('resize_alg', C.c_int)]
+                ('flip', C.c_int), ('resize_alg', C.c_int),
+                ('n_extra', C.c_int), ('extra_kind', C.c_int * MAX_EXTRA), ('extra_val', C.c_float * MAX_EXTRA)]
 
 
 def plan_params(plans, width, height):
@@ -401,6 +429,10 @@ def plan_params(plans, width, height):
         x0, y0, cw, ch = p.crop if p.crop is not None else (0, 0, frame.w, frame.h)
         q.crop_x0 = x0; q.crop_y0 = y0; q.crop_w = cw; q.crop_h = ch
         q.flip = int(p.flip); q.resize_alg = p.resize[2]
+        q.n_extra = len(p.extra)
+        for k, (kind, val) in enumerate(p.extra):
+            q.extra_kind[k] = kind
+            q.extra_val[k] = float(val[0] + 4 * val[1] + 16 * val[2]) if kind == 4 else float(val)      # a permutation travels as a base-4 code
         n = p.image.size
         packed[offs[i]:offs[i] + n] = p.image.reshape(-1)
         packed[offs[i] + n:offs[i] + (n + 15) // 16 * 16] = 0

@@ -117,7 +117,9 @@ def test_plan_order_is_enforced():
     p = T.ImagePlan(np.zeros((8, 8, 3), np.uint8))
     gt = _sample((8, 8), [(0.5, 0.5, 0.5, 0.5)], [1])
     p, _, gt = T.HorizontalFlipTransform()(p, None, gt)
-    with pytest.raises(NotImplementedError):
+    p, _, gt = T.BrightnessTransform(delta=3)(p, None, gt)         # round 5: a per-pixel step commutes with the flip
+    p, _, gt = T.ExpandTransform(max_ratio=2.0, mean_value=[104, 117, 123])(p, None, gt)
+    with pytest.raises(NotImplementedError):                       # ... but not with the canvas's fill colour
         T.BrightnessTransform(delta=3)(p, None, gt)
     with pytest.raises(ValueError):
         T.ImagePlan(np.zeros((8, 8, 3), np.float32))
@@ -193,3 +195,39 @@ def test_native_sampler_exhausted_trials_and_degenerate_pickers():
     random.seed(3)
     d, _, g = pickers[1](T.ImagePlan(np.zeros((222, 333, 3), np.uint8)), None, tiny)
     assert d.crop is None or d.crop[2] > 0
+
+
+def test_free_compositions_are_rewritten_into_the_plan():
+    """Round 5 (transforms.py:117-391 composes freely): transform lists outside the recipe's order -- crop /
+    expand / flip after a flip, two expands, a second photometric pass, photometric steps after a flip or a reorder -- become ONE
+    plan of the batch kernel's canonical form.  The plan, executed with the oracle's pixel operations in ITS order, must give the
+    pixels of the free composition executed in the USER'S order, exactly; and the ground-truth boxes are the mirror's own."""
+    import compose_util as cu
+    for li, steps in enumerate(cu.FREE_LISTS):
+        for rep in range(3):
+            img = cu.test_image(100 * li + rep)
+            seed = 9000 + 10 * li + rep
+            plan, gt = cu.compose_mirror(steps, img, seed)
+            want = cu.compose_pixels(steps, img, seed)
+            got = cu.run_plan(plan)
+            assert got.shape == want.shape == (80, 96, 3), (li, got.shape, want.shape)
+            assert np.array_equal(got, want), f'list {li} rep {rep}: the plan is not the composition (max diff {np.abs(got - want).max()})'
+            assert len(plan.extra) <= 8
+    # the recipe itself still lands in the canonical slots, nothing spills into the extra list
+    from ssd_tensorflow_amd import transforms as T
+    from ssd_tensorflow_amd.ssdutils import get_preset_by_name
+    preset = get_preset_by_name('vgg300')
+    img = cu.test_image(5, (200, 160))
+    for seed in range(20):
+        random.seed(seed)
+        args = (None, None, _sample((200, 160), [(0.5, 0.5, 0.5, 0.5)], [3]))
+        for t in [t for t in T.build_train_transforms(preset, 20, 50, 0.5, images={'img': img}) if not isinstance(t, T.LabelCreatorTransform)]:
+            args = t(*args)
+        assert args[0].extra == []
+
+
+def test_what_is_not_a_composition_is_refused():
+    import compose_util as cu
+    for steps in cu.REFUSED_LISTS:
+        with pytest.raises(NotImplementedError):
+            cu.compose_mirror(steps, cu.test_image(1), 1)

@@ -169,3 +169,25 @@ def test_training_data_augmented_batches_feed_the_step():
         res, L = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
         assert np.isfinite(L['total'])
     sess.close()
+
+
+def test_free_compositions_on_the_batch_kernel():
+    """Round 5: transform lists composed outside the recipe's order (tests/compose_util.py: crop / expand / flip after a flip, two
+    expands, a second photometric pass) through the batch kernel against the FREE composition of the oracle's pixel operations
+    in the user's order.  Same tolerances as the recipe test."""
+    import compose_util as cu
+    plans, wants, expanded = [], [], []
+    for li, steps in enumerate(cu.FREE_LISTS):
+        for rep in range(2):
+            img = cu.test_image(300 + 10 * li + rep)
+            seed = 9100 + 10 * li + rep
+            plan, _ = cu.compose_mirror(steps, img, seed)
+            plans.append(plan)
+            wants.append(cu.compose_pixels(steps, img, seed))
+            expanded.append(plan.expand is not None)
+    out = T.augment_batch(plans, 96, 80)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert any(p.extra for p in plans) and any(expanded) and not all(expanded)
+    for i, (w, e) in enumerate(zip(wants, expanded)):
+        _compare(got[i], w, e, f'free list {i // 2} rep {i % 2}')
