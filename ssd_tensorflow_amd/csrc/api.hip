@@ -21,6 +21,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err.c_str(); }
 
 thread_local Profiler* g_prof = nullptr;
+thread_local hipEvent_t g_stop_event = nullptr;
 hipEvent_t Profiler::get() {
     if (used == pool.size()) {
         hipEvent_t e;

@@ -1,6 +1,7 @@
 // Shared host-side helpers for the gfx950 SSD-VGG library.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdarg>
 #include <cstdint>
@@ -80,6 +81,20 @@ struct Profiler {
     ~Profiler();
 };
 extern thread_local Profiler* g_prof;
+
+// A launch can carry the event its consumers on OTHER streams wait for (hipExtLaunchKernelGGL's stop event: the kernel packet's
+// own completion signal).  An event recorded BEHIND the kernel is a packet of its own that the stream's next kernel queues
+// behind: on this chip a chain of dependent kernels pays 1.5 us per link bare, 6.8 us with "record, the other stream waits and
+// runs a kernel", 3.3 us when the kernel carries the event (tools/probes/event_gap.hip, profiles/r05_s_event_gap.txt).  The
+// executor arms g_stop_event right before the one call whose (single, last) launch should carry it; the gather launchers take it.
+extern thread_local hipEvent_t g_stop_event;
+inline hipEvent_t take_stop_event() {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}
+#define SSD_LAUNCH_STOP(kern, grid, block, lds, stream, ...) \
+    hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ssd::take_stop_event(), 0, __VA_ARGS__)
 
 // RAII: records an event before and after the launches issued inside the scope.
 struct ProfScope {

@@ -2316,7 +2316,7 @@ static void launch_gather_h(GatherArgsH& a, const char* label, double flops, dou
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(64 * WM * WN * KSPLIT), lds, s, a);
+    SSD_LAUNCH_STOP(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(64 * WM * WN * KSPLIT), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -2437,7 +2437,7 @@ static void launch_gather_c64(GatherArgsH& a, const char* label, double flops, d
     auto kern = conv_gather_bf16_c64_kernel<MODE, false>;
     static bool once = (set_lds(kern, lds), true);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0, FirstWArgs{});
+    SSD_LAUNCH_STOP(kern, dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, s, a, ntiles, ntiles >= 2048 ? 1 : 0, FirstWArgs{});
     HIP_OK(hipGetLastError());
 }
 
@@ -2452,7 +2452,7 @@ static void launch_gather_rows(GatherArgsH& a, int dil, const char* label, doubl
     a.NT = cdiv(a.DN, BN);
     const int bmv = TM == 2 ? 128 : 256 - 2 * dil - 1;
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, bmv) * a.NT), dim3(256), lds, s, a, dil);
+    SSD_LAUNCH_STOP(kern, dim3(cdiv(a.M, bmv) * a.NT), dim3(256), lds, s, a, dil);
     HIP_OK(hipGetLastError());
 }
 // 128 x 64 tiles (three workgroups per CU) -- where they cut PADDED COLUMNS: the fused 19x19 head (N = 152: three 64-wide tiles carry

@@ -1207,7 +1207,7 @@ static void launch_gather(GatherArgs& a, const char* label, double flops, double
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
+    SSD_LAUNCH_STOP(kern, dim3(MT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 
@@ -1233,7 +1233,7 @@ static void launch_gather_dma(GatherArgs& a, const char* label, double flops, do
     const int MT = cdiv(a.M, BM);
     a.NT = cdiv(a.DN, BN);
     ProfScope prof(label, flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256), lds, s, a);
+    SSD_LAUNCH_STOP(kern, dim3(grid > 0 ? grid : MT * a.NT), dim3(256), lds, s, a);
     HIP_OK(hipGetLastError());
 }
 

@@ -218,10 +218,10 @@ static int env_i(const char* name, int dflt) {
 //    all of them sat behind conv11_2, and because the heads of a lane share one in-order side stream whose first entry
 //    (head 0) needs the l2-norm, the six heads ran back to back AFTER the trunk on a nearly empty chip: 340 us of a
 //    7.47 ms bf16 step with fewer than 256 workgroups in flight (profiles/r04_a_timeline_bf16.txt; fp32: 0.6 ms).
-//  * Backward: reverse graph order.  (Round 4 built and measured an alternative -- the latency-bound chain of small heads and
-//    extra layers first, head 0 + l2-norm deferred beside mod_conv6: chain 450 -> 264 us, step 7.22 -> 7.37 ms,
-//    profiles/r04_g_ab_schedule_bf16.txt -- removed in round 5; the bookkeeping below (bw_need / bw_sync / bw_final_lo) still
-//    serves any valid order.)
+//  * Backward: reverse graph order, in bf16 with the big heads behind the chain (below).  (Round 4 built and measured another
+//    alternative -- head 0 + l2-norm deferred beside mod_conv6 on the side stream: chain 450 -> 264 us, step 7.22 -> 7.37 ms,
+//    profiles/r04_g_ab_schedule_bf16.txt; re-measured in round 5: 6.864 -> 6.885 ms.  The bookkeeping (bw_need / bw_sync /
+//    bw_final_lo) serves any valid order.)
 void Net::build_orders() {
     const int n = (int)ops_.size();
     fwd_order_.clear();
@@ -242,6 +242,29 @@ void Net::build_orders() {
     }
     bwd_order_.clear();
     for (int i = n - 1; i >= 0; --i) bwd_order_.push_back(i);
+    // Round 5, bf16: the two BIG heads (38x38, 19x19) and the l2-norm go BEHIND the chain conv11_2 ... conv8_2, and the main stream
+    // waits for the chain's end before it starts them.  In graph order their data gradients (1456 / 1444 workgroups) fill every CU
+    // while the chain's first links are due, and those are launches of 4 - 52 workgroups that need an EMPTY CU (16 waves, 128 KB of
+    // LDS: pick_tile_h): the chain's second link started when the big kernels had no workgroup left to place, 140 us late
+    // (gpurun_out r05p timeline).  Behind the chain they run at full rate and nothing waits for them: step 6.864 -> 6.810 ms
+    // (profiles/r05_r_ab_bw_defer_bf16.txt; on the side stream beside mod_conv6 instead: 6.885).  fp32 keeps graph order: its big
+    // heads are 0.74 ms of kernels against a 0.3 ms chain that fits beside them (256-thread tiles), deferring measured +0.5 %.
+    // SSD_BW_BIG_HEADS_LAST=0 / 1 overrides.
+    bw_defer_first_ = -1;
+    if (env_i("SSD_BW_BIG_HEADS_LAST", bf16_ ? 1 : 0) && tail_first_ + 1 < n && heads_.nmaps >= 3) {
+        std::vector<int> moved, rest;
+        for (int i : bwd_order_) {
+            const Op& op = ops_[i];
+            if ((op.kind == OP_CONV && (op.head == 0 || op.head == 1)) || op.kind == OP_L2NORM) moved.push_back(i);
+            else rest.push_back(i);
+        }
+        bwd_order_.clear();
+        for (int i : rest) {
+            bwd_order_.push_back(i);
+            if (i == tail_first_ + 1) bwd_order_.insert(bwd_order_.end(), moved.begin(), moved.end());
+        }
+        bw_defer_first_ = moved.front();
+    }
 }
 
 // stream class of an op's data gradient in backward: 0 = main stream, 1 = side stream (see build_orders)
@@ -271,11 +294,11 @@ void Net::bw_need(int x, const Tensor& t) {
     else bw_sync(x, t.gstream);
 }
 
-void Net::bw_wrote(int x, Tensor& t) {
+void Net::bw_wrote(int x, Tensor& t, bool carried) {
     t.gstream = x;
     t.gseq = ++bw_issued_[x];
     if (t.gev) {
-        HIP_OK(hipEventRecord(t.gev, x == 1 ? hstream_ : stream_));
+        if (!carried) HIP_OK(hipEventRecord(t.gev, x == 1 ? hstream_ : stream_));      // (carried: the kernel's own stop event, common.h)
         t.gev_set = true;
     }
 }
@@ -531,9 +554,13 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
         HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     }
     plan_pool_fusion();
+    // Round 5: an event per gradient tensor (round 4: the small heads' feature maps only).  The data-gradient kernel that writes it
+    // CARRIES the event (g_stop_event), and the weight-gradient stream / the other class wait for exactly that kernel: no event
+    // packet between two data gradients on the main stream, none inside the side chain.  SSD_STOP_EVENTS=0: round 4's records.
+    stop_events_ = env_i("SSD_STOP_EVENTS", 1) != 0;
     if (training_)
         for (const Op& op : ops_)
-            if (op.kind == OP_CONV && op.head >= 2 && !tensors_[op.in].gev)
+            if ((stop_events_ ? op.in != input_t_ : (op.kind == OP_CONV && op.head >= 2)) && !tensors_[op.in].gev)
                 HIP_OK(hipEventCreateWithFlags(&tensors_[op.in].gev, hipEventDisableTiming));
 }
 
@@ -859,6 +886,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         // or accumulates into a gradient that the other class wrote last (bw_need): conv8_1 joins the chain.
         const int cls = bw_class(op, op_index);
         hipStream_t ds = cls == 1 ? hstream_ : stream_;
+        if (op_index == bw_defer_first_ && hstream_ && overlap_) bw_sync(0, 1);      // the main stream's big kernels start behind the chain
         if (op_ablated(op.name, op.kind, op.head, op.k)) {
             if (op.kind == OP_CONV) { bw_conv_done_[op_index] = 1; lo = bw_final_lo(); }
             in.done++;
@@ -880,9 +908,13 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
             if (side && !on_main) {
                 // (dy written on the main stream but already waited for by the side stream, and this op lives there: the
                 // side stream is the one that is less far ahead -- a small head's weight gradient need not wait for mod_conv7)
-                const bool from_side = out.gstream == 1 || (cls == 1 && bw_seen_[1][0] >= out.gseq);
-                HIP_OK(hipEventRecord(ev_dy_, from_side ? hstream_ : stream_));
-                HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+                if (stop_events_ && out.gev && out.gev_set) {
+                    HIP_OK(hipStreamWaitEvent(wstream_, out.gev, 0));      // the kernel that wrote dy last (it waited for the earlier writers)
+                } else {
+                    const bool from_side = out.gstream == 1 || (cls == 1 && bw_seen_[1][0] >= out.gseq);
+                    HIP_OK(hipEventRecord(ev_dy_, from_side ? hstream_ : stream_));
+                    HIP_OK(hipStreamWaitEvent(wstream_, ev_dy_, 0));
+                }
                 side_used = true;
             } else {
                 bw_need(0, out);
@@ -918,6 +950,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                     lo = bw_final_lo();
                     break;
                 }
+                g_stop_event = stop_events_ ? dst.gev : nullptr;      // the launch carries dst's event (taken by the gather launchers)
                 if (!bf16_) {
                     if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
@@ -925,7 +958,9 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                     if (up) conv_dgrad_unpool_bf16(d, out.gh(), wq_io_ + op.w_off, dst.gh(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
                 }
-                bw_wrote(cls, dst);
+                const bool carried = stop_events_ && dst.gev && g_stop_event == nullptr;
+                g_stop_event = nullptr;
+                bw_wrote(cls, dst, carried);
             }
             bw_conv_done_[op_index] = 1;
             lo = bw_final_lo();
