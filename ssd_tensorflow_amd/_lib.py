@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libssdvgg_hip.so')
+# (SSD_LIB: a build of the SAME sources with other compile-time definitions, for same-box A/Bs -- csrc/Makefile VARIANT)
+LIB_PATH = os.environ.get('SSD_LIB') or os.path.join(_HERE, 'libssdvgg_hip.so')
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -435,8 +435,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_gather_bf16_kernel
             const int later = nk - 1 - k;
             wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < NS - 2 ? later : NS - 2);      // tile k visible; stage st_i is free
             if (k + NS - 1 < nk) issue(k + NS - 1, st_i);
-            compute(st_c);
-            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+                compute(st_c);
+                st_c = st_c + 1 == NS ? 0 : st_c + 1;
             st_i = st_i + 1 == NS ? 0 : st_i + 1;
         }
         __syncthreads();
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_gather_bf16_kernel
             const int later = nkg - 1 - j;
             wait_tiles_and_sync<A_N + B_N, (NS - 2 > 4 ? 4 : (NS - 2 < 2 ? 2 : NS - 2))>(later < 0 ? 0 : (later < NS - 2 ? later : NS - 2));
             if (j + NS - 1 < nkg) issue(grp + (j + NS - 1) * KSPLIT, st_i);
-            if (j < nkg) compute(st_c);
-            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+                if (j < nkg) compute(st_c);
+                st_c = st_c + 1 == NS ? 0 : st_c + 1;
             st_i = st_i + 1 == NS ? 0 : st_i + 1;
         }
         __syncthreads();
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                 for (int ni = 0; ni < 2; ++ni)
                     b[ks & 1][ni] = *reinterpret_cast<const bf16x8*>(smem + (kr * 3 + kc) * B_TAP + (b_addr[ni] ^ (st * 32)));
             };
-            frags(0);
+                frags(0);
 #pragma unroll
             for (int ks = 0; ks < 12; ++ks) {
                 if (ks + 1 < 12) frags(ks + 1);
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(512) void conv_gather_bf16_c64_kernel(GatherArgsH p
                 for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][ni], a[ks & 1], acc[ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+            }
         // ---- results: pixel m, channels 32 ni + 8 g + 4 lh + (0..3)
         {
             // Through LDS, so that rows leave (and the mask arrives) as whole 128-byte lines: written straight from the
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(512) void conv_fwd_pool_bf16_c64_kernel(GatherArgsH
                 for (int ni = 0; ni < 2; ++ni)
                     bfr[ks & 1][ni] = *reinterpret_cast<const bf16x8*>(smem + (kr * 3 + kc) * B_TAP + (b_addr[ni] ^ (st * 32)));
             };
-            frags(0);
+                frags(0);
 #pragma unroll
             for (int ks = 0; ks < 12; ++ks) {
                 if (ks + 1 < 12) frags(ks + 1);
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(512) void conv_fwd_pool_bf16_c64_kernel(GatherArgsH
                 for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][ni], a[ks & 1], acc[ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+            }
         // ---- results: the whole tile (bias + relu, rounded to bf16) parked in the activation buffer the last unit has just
         // consumed -- row = tile row, 16-byte chunk c at chunk c ^ sw(row & 31) --, then one pooled pixel x 8 channels per thread
         lds_barrier();                                    // every wave has read its fragments of that buffer

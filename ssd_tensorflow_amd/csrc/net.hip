@@ -626,8 +626,15 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         hipEvent_t ev_h;
         int b0, nb;
         bool heads_on_side, cast_pending;
-    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false},
-                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false}};
+        bool fmap_carried[MAX_MAPS];      // the feature map's producer carried ev_fmap[head] itself (g_stop_event)
+    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false, {}},
+                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false, {}}};
+    // feature map tensor -> the head that reads it (-1: none), for the carried events
+    auto head_of = [&](int tensor) {
+        for (const Op& o : ops_)
+            if (o.kind == OP_CONV && o.head >= 0 && o.in == tensor) return o.head;
+        return -1;
+    };
     auto at = [](const Tensor& t, int b0, bool grad = false) -> char* {      // first element of sample b0
         return static_cast<char*>(grad ? t.grad : t.data) + (size_t)b0 * t.per_image() * ((grad ? t.grad_f32 : t.data_f32) ? 4 : 2);
     };
@@ -697,7 +704,8 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 if (op.head >= 0 && side) {
                     // the multibox heads hang off the trunk: they run on a side stream behind their feature
                     // map and fill the CUs the trunk's kernels leave idle between waves of workgroups
-                    HIP_OK(hipEventRecord(ln.ev_fmap[op.head], ln.s));
+                    if (!ln.fmap_carried[op.head]) HIP_OK(hipEventRecord(ln.ev_fmap[op.head], ln.s));
+                    ln.fmap_carried[op.head] = false;
                     if (heads_full) {
                         // ONE launch over the whole batch on lane 0's side stream, behind both lanes' feature maps: half the
                         // launches, twice the workgroups each, and lane 1's trunk (whose own "side" stream is its main
@@ -740,6 +748,13 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                                            reinterpret_cast<bf16_t*>(at(pt, run_b0)), rec, cs);
                     break;
                 }
+                // a feature map's producer carries the event its head waits for (common.h g_stop_event; backward_step does the same)
+                const int fh = (stop_events_ && side && op.head < 0 && cs == ln.s) ? head_of(op.out) : -1;
+                if (fh >= 0) g_stop_event = ln.ev_fmap[fh];
+                struct CarryScope {
+                    bool* flag;
+                    ~CarryScope() { if (flag) *flag = g_stop_event == nullptr; g_stop_event = nullptr; }
+                } carry_scope{fh >= 0 ? &ln.fmap_carried[fh] : nullptr};
                 if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
                 else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
