@@ -92,13 +92,13 @@ def test_augmented_shapes_training_makes_progress(tmp_path):
 
 
 def test_first_training_steps_track_the_oracle_on_shapes():
-    """fp32, batch 4, momentum 0.9, lr 1e-4: the HIP losses against oracle.RefModel.train_step on the same batches, twelve
-    optimizer steps in a row.  The two trajectories are separate computations of a chaotic system (tests/test_gpu_model.py
+    """fp32, batch 4, momentum 0.9, lr 1e-4: the HIP losses against oracle.RefModel.train_step on the same batches, nine
+    optimizer steps in a row (twelve through round 4: the CPU oracle is 4 - 7 s per step on the pool's slower hosts).  The two trajectories are separate computations of a chaotic system (tests/test_gpu_model.py
     header: a relu mask or pool argmax flips wherever two fp32 values agree to ~1e-6), so the agreement decays with the step
     count -- measured 1e-7, 9e-6, 8e-5, 5e-4, 8e-4, 8e-4, then 7e-4 .. 7e-3 (at lr 1e-3, where the loss itself jumps 22 -> 60 ->
-    21 in the first three steps, 5e-2 by step 3).  Asserted: 1e-3 on every loss for the first six steps, 1e-2 for all twelve."""
+    21 in the first three steps, 5e-2 by step 3).  Asserted: 1e-3 on every loss for the first six steps, 1e-2 for all nine."""
     import os
-    b, steps, exact = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 12)), 6
+    b, steps, exact = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 9)), 6
     preset = ob.get_preset('vgg300')
     td = TrainingData('shapes', 'vgg300', num_train=b * steps, num_valid=b, seed=5, device_tensors=False)
     w = ref.init_params(preset, 20, seed=11, alive=True)
