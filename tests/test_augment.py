@@ -231,3 +231,36 @@ def test_what_is_not_a_composition_is_refused():
     for steps in cu.REFUSED_LISTS:
         with pytest.raises(NotImplementedError):
             cu.compose_mirror(steps, cu.test_image(1), 1)
+
+
+def test_random_transform_lists_are_composed_or_refused():
+    """300 random lists over the whole transform vocabulary (resize last): a list the mirror ACCEPTS must give, executed as a plan,
+    exactly the pixels of its free composition; a list it REFUSES must contain one of the documented non-compositions (a
+    photometric step behind an expand, hue / saturation behind a crop, an expand behind a crop, more than 8 steps beyond the
+    canonical slots).  Nothing is silently approximated and nothing composable is refused for another reason."""
+    import compose_util as cu
+    rng = random.Random(77)
+    vocab = [('brightness', {}), ('contrast', {}), ('saturation', {}), ('hue', {}), ('reorder', {}), ('expand', dict(max_ratio=1.6)),
+             ('crop', cu.WIN), ('crop', dict(window=(0.0, 0.8, 0.1, 1.0))), ('flip', {})]
+    accepted = refused = 0
+    for case in range(300):
+        steps = [rng.choice(vocab) for _ in range(rng.randint(1, 9))] + [cu.RS]
+        names = [n for n, _ in steps]
+        img = cu.test_image(1000 + case, (90, 70))
+        seed = 5000 + case
+        try:
+            plan, _ = cu.compose_mirror(steps, img, seed)
+        except NotImplementedError:
+            refused += 1
+            photometric = {'brightness', 'contrast', 'saturation', 'hue', 'reorder'}
+            after_expand = any(n in photometric for i, n in enumerate(names) if 'expand' in names[:i])
+            rows_after_crop = any(n in ('hue', 'saturation') for i, n in enumerate(names) if 'crop' in names[:i])
+            expand_after_crop = any(n == 'expand' for i, n in enumerate(names) if 'crop' in names[:i])
+            many = sum(n in photometric for n in names) > 5        # (the canonical slots hold at most five)
+            assert after_expand or rows_after_crop or expand_after_crop or many, f'case {case}: refused without a reason: {names}'
+            continue
+        accepted += 1
+        want = cu.compose_pixels(steps, img, seed)
+        got = cu.run_plan(plan)
+        assert got.shape == want.shape and np.array_equal(got, want), f'case {case}: {names} (max diff {np.abs(got - want).max()})'
+    assert accepted >= 60 and refused >= 60, (accepted, refused)
