@@ -966,6 +966,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                     break;
                 }
                 g_stop_event = stop_events_ ? dst.gev : nullptr;      // the launch carries dst's event (taken by the gather launchers)
+                struct Disarm { ~Disarm() { g_stop_event = nullptr; } } disarm;      // (also when the launch throws)
                 if (!bf16_) {
                     if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
@@ -974,7 +975,6 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                     else conv_dgrad_bf16(d, out.gh(), wq_io_ + op.w_off, in.gh(), mask ? in.h() : nullptr, in.done > 0, ds);
                 }
                 const bool carried = stop_events_ && dst.gev && g_stop_event == nullptr;
-                g_stop_event = nullptr;
                 bw_wrote(cls, dst, carried);
             }
             bw_conv_done_[op_index] = 1;
