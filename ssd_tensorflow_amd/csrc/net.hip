@@ -793,6 +793,14 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
     prof_.layer = "loss";
     const int A = preset_->num_anchors, nv = C_ + 5;
+    // the head kernel leaves the decode pass its candidates when a threshold is armed (set_detect_threshold): detect_last_dev
+    cand_valid_ = false;
+    HeadCand hc{};
+    const HeadCand* cand = nullptr;
+    if (cand_thr_ >= 0.f && cand_keys_) {
+        hc = HeadCand{cand_keys_, cand_count_, cand_thr_, 0};
+        cand = &hc;
+    }
     // The lanes' loss launches share a self-resetting completion ticket (ops.hip): if a launch fails after another
     // lane's has been enqueued, the count never reaches the step's total and the ticket would stay non-zero for the life
     // of the handle -- drain the device and clear it before the error leaves.
@@ -802,8 +810,8 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
-        if (train_mode) multibox_loss(heads_, b, 0, b, result_, y, lw_, wd_, loss_bnorm_, stream_);
-        else heads_result(heads_, b, result_, stream_);
+        if (train_mode) multibox_loss(heads_, b, 0, b, result_, y, lw_, wd_, loss_bnorm_, stream_, cand);
+        else heads_result(heads_, b, result_, stream_, cand);
     }
     for (int li = 0; li < nl && !heads_full; ++li) {
         Lane& ln = lane[li];
@@ -814,11 +822,13 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HeadLayout hl = heads_;
         for (int i = 0; i < hl.nmaps; ++i) hl.buf[i] = heads_.buf[i] + (size_t)ln.b0 * hl.hw[i] * hl.ld[i];
         float* res = result_ + (size_t)ln.b0 * A * nv;
+        HeadCand lc = hc;
+        lc.b_off = ln.b0;
         if (train_mode) {
             if (li == 1) HIP_OK(hipStreamWaitEvent(ln.s, ev_l2_, 0));      // the final reduction may fall to this lane
-            multibox_loss(hl, ln.nb, ln.b0, b, res, y + (size_t)ln.b0 * A * nv, lw_, wd_, loss_bnorm_, ln.s);
+            multibox_loss(hl, ln.nb, ln.b0, b, res, y + (size_t)ln.b0 * A * nv, lw_, wd_, loss_bnorm_, ln.s, cand ? &lc : nullptr);
         } else {
-            heads_result(hl, ln.nb, res, ln.s);
+            heads_result(hl, ln.nb, res, ln.s, cand ? &lc : nullptr);
         }
     }
     } catch (...) {
@@ -833,6 +843,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
+    if (cand) { cand_valid_ = true; cand_valid_thr_ = cand_thr_; cand_valid_b_ = b; }
     if (train_mode) HIP_OK(hipEventRecord(ev_loss_[loss_seq_ % LOSS_RING], stream_));
     fwd_guard.done = true;
 }
@@ -1253,6 +1264,25 @@ void Net::detect_slot_carve(const DetectSlot& sl, DetectOut& d, char* base) cons
     d.box = d.idx + n;
 }
 
+// Arm (thr >= 0) or disarm (thr < 0) the hand-over of decode candidates from the head kernel: every forward pass from now on
+// leaves, beside `result`, the anchors whose best foreground confidence reaches thr, and a detect_last* call with exactly this
+// threshold on that pass skips its scan over `result` (ssdutils.py:192-229 decode_boxes; bit-identical output, tests/test_gpu_boxes.py).
+// Any other threshold, or a pass made before arming, takes the scan as before.
+void Net::set_detect_threshold(float thr) {
+    cand_valid_ = false;
+    cand_thr_ = thr >= 0.f ? thr : -1.f;
+    if (cand_thr_ < 0.f) return;
+    cand_nb_ = heads_blocks_per_image(heads_);
+    if (cand_nb_ > detect_max_candidate_segments()) {      // (no preset of the reference comes near: vgg512 has 173)
+        cand_thr_ = -1.f;
+        return;
+    }
+    if (!cand_keys_) {
+        cand_keys_ = (unsigned long long*)dalloc((size_t)Bmax_ * cand_nb_ * HEAD_CAND_CAP * sizeof(unsigned long long));
+        cand_count_ = (int*)dalloc((size_t)Bmax_ * cand_nb_ * sizeof(int));
+    }
+}
+
 const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
     SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
@@ -1296,7 +1326,11 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     prof_.layer = "detect";
     DetectOut d;
     detect_slot_carve(sl, d, sl.dev);
-    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
+    // the head kernel of the pass that wrote result_ left this threshold's candidates: no scan over result_
+    const bool handed = cand_valid_ && cand_valid_thr_ == thr && cand_valid_b_ == b;
+    cand_used_ = handed;
+    const DetectCandidates dc{cand_keys_, cand_count_, cand_nb_, HEAD_CAND_CAP};
+    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_, handed ? &dc : nullptr);
     if (!sl.mapped) HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipEventRecord(sl.ready, stream_));
     if (dev_out) *dev_out = d;
