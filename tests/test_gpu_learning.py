@@ -100,7 +100,7 @@ def test_first_training_steps_track_the_oracle_on_shapes():
     import os
     b, steps, exact = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 9)), 6
     preset = ob.get_preset('vgg300')
-    td = TrainingData('shapes', 'vgg300', num_train=b * steps, num_valid=b, seed=5, device_tensors=False)
+    td = TrainingData('shapes', 'vgg300', num_train=b * 12, num_valid=b, seed=5, device_tensors=False)      # (the set the bounds were measured on: its first `steps` batches)
     w = ref.init_params(preset, 20, seed=11, alive=True)
     m = ref.RefModel('vgg300', params=w)
     lr = LearningRate([float(os.environ.get('SSD_TEST_TRACK_LR', 1e-4))], [])
@@ -111,6 +111,8 @@ def test_first_training_steps_track_the_oracle_on_shapes():
         net.build_from_vgg(None, 20, max_batch=b, weights=w)
         net.build_optimizer(learning_rate=lr, weight_decay=0.0005, momentum=0.9)
         for k, (x, y, gt) in enumerate(td.train_generator(b)):
+            if k >= steps:
+                break
             x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
             _, L_ref = m.train_step(x, y)
             L, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
