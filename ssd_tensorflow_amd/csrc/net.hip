@@ -265,6 +265,9 @@ void Net::build_orders() {
         }
         bw_defer_first_ = moved.front();
     }
+    // every op exactly once: an op the rewrite above failed to re-insert would silently never run backward
+    SSD_REQUIRE((int)bwd_order_.size() == n && (int)fwd_order_.size() == n, "issue orders lost an op (%zu forward, %zu backward of %d)",
+                fwd_order_.size(), bwd_order_.size(), n);
 }
 
 // stream class of an op's data gradient in backward: 0 = main stream, 1 = side stream (see build_orders)
@@ -1163,6 +1166,7 @@ void Net::get_losses_step(int steps_back, float out[4]) {
 
 void Net::set_result(const float* pred_dev, int b) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
+    cand_valid_ = false;      // the head kernel's decode candidates describe the pass that wrote the OLD result_
     HIP_OK(hipMemcpyAsync(result_, pred_dev, (size_t)b * preset_->num_anchors * (C_ + 5) * sizeof(float), hipMemcpyDeviceToDevice, stream_));
 }
 

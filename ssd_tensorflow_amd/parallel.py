@@ -19,8 +19,34 @@ def reserve_hw_queues():
     own, and a stream that has to SHARE a queue with another is time-multiplexed.  Measured on one MI355X, bf16 step,
     single-rank group (profiles/r05_g_dp_hw_queues.txt): no group 6.92 ms; group initialised -- even if never used -- 7.15-7.19 ms
     (+3.5 %); the same with 8 queues 6.95-6.99 ms.  The variable is read when the HIP runtime starts, so this must run before
-    the first torch.cuda call (train.py and bench.py call it first thing; a value the user set wins)."""
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    the first torch.cuda call (train.py and bench.py call it first thing; a value the user set wins).
+
+    Returns True when the reservation can still take effect.  It cannot -- and says so on stderr -- when the HIP runtime of
+    this process is already up (torch.cuda initialised, or a handle / stream created through the C ABI: the variable was read
+    then) or when the user pinned fewer than 8 queues: the data-parallel step then runs on shared queues, the measured
+    +3.5 ... 4.7 % path.  (Set GPU_MAX_HW_QUEUES=8 in the environment of a C consumer: INTEGRATION.md section 5.)  A process
+    that never creates a communicator should NOT set it: with one queue per stream the three-stream executor measured the
+    same, but a five-stream one 25 % slower (csrc/net.hip, constructor)."""
+    import sys
+    have = os.environ.get('GPU_MAX_HW_QUEUES')
+    late = torch.cuda.is_initialized()
+    if have is None and not late:
+        os.environ['GPU_MAX_HW_QUEUES'] = '8'
+        return True
+    ok = True
+    try:
+        ok = int(have) >= 8 if have is not None else False
+    except ValueError:
+        ok = False
+    if late and have is None:
+        print('[ssd_tensorflow_amd.parallel] WARNING: the HIP runtime was initialised before reserve_hw_queues(): '
+              'GPU_MAX_HW_QUEUES cannot be raised to 8 any more; the data-parallel step will share hardware queues with '
+              'RCCL (+3.5 ... 4.7 % per step, DESIGN.md section 6).  Call parallel.init() / reserve_hw_queues() before the first '
+              'torch.cuda call, or export GPU_MAX_HW_QUEUES=8.', file=sys.stderr, flush=True)
+    elif not ok:
+        print(f'[ssd_tensorflow_amd.parallel] WARNING: GPU_MAX_HW_QUEUES={have!r} (< 8): executor and RCCL streams will share '
+              'hardware queues (+3.5 ... 4.7 % per data-parallel step, DESIGN.md section 6).', file=sys.stderr, flush=True)
+    return ok and not (late and have is None)
 
 
 def env():
