@@ -98,8 +98,6 @@ SIGNATURES = {
     'ssd_set_result_dev': (i32, [handle, vp, i32]),
     'ssd_arenas': (i32, [handle, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
     'ssd_detect_last': (i32, [handle, i32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
-    'ssd_set_detect_threshold': (i32, [handle, f32]),
-    'ssd_detect_candidates_valid': (i32, [handle, C.POINTER(i32)]),
     'ssd_detect_last_dev': (i32, [handle, i32, f32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     'ssd_detect_fetch': (i32, [handle, i32, vp, vp, vp, vp, vp]),
     'ssd_detect_host': (i32, [handle, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), p_i32, p_i32]),

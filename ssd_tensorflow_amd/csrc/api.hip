@@ -651,19 +651,6 @@ int ssd_detect_last(ssd_handle h, int b, float conf_thr, int cap, int max_out, i
     API_END
 }
 
-int ssd_set_detect_threshold(ssd_handle h, float conf_thr) {
-    API_BEGIN_NET(h)
-    n.set_detect_threshold(conf_thr);
-    API_END
-}
-
-int ssd_detect_candidates_valid(ssd_handle h, int* valid) {
-    API_BEGIN_NET(h)
-    SSD_REQUIRE(valid != nullptr, "null output");
-    *valid = (n.detect_candidates_valid() ? 1 : 0) | (n.detect_used_candidates() ? 2 : 0);
-    API_END
-}
-
 int ssd_detect_last_dev(ssd_handle h, int b, float conf_thr, int cap, int max_out, int out_cap, int nms, int** count_dev,
                         float** conf_dev, int** cls_dev, int** idx_dev, int** box_dev) {
     API_BEGIN_NET(h)

@@ -50,17 +50,8 @@ struct DetectOut {
 };
 size_t detect_ws_bytes(int B, int A);
 // nms = false: decode_boxes only (confidence order, nothing suppressed)
-// Candidates handed over by the kernel that wrote `pred` (ops.h HeadCand: the multibox head kernel of the same pass): the scan over
-// pred is skipped.  nseg segments of `cap` keys per image; the keys must be the scan's (same threshold).
-struct DetectCandidates {
-    const unsigned long long* keys;   // [B][nseg][cap]
-    const int* count;                 // [B][nseg]
-    int nseg, cap;
-};
-int detect_max_candidate_segments();
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap,
-            int max_out, int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s,
-            const DetectCandidates* cand = nullptr);
+            int max_out, int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s);
 
 // non_maximum_suppression / suppress_overlaps on an arbitrary list: boxes [n][4] i32 (xmin,xmax,ymin,ymax),
 // conf [n], group [n] (0..ngroups-1); keep [n+1]: keep[0] = count, then the selected input indices in output order.

@@ -470,7 +470,7 @@ constexpr int DET_WAVES = DET_THREADS / 64;
 constexpr int DET_FAST = 1024;           // up to this many candidates the whole image is handled in LDS
 constexpr int DET_LDS_KEYS = 2048;       // general path: sort in LDS up to this many keys, else in (L2-resident) global
 constexpr int DET_MAX_ALIVE = 32768;
-constexpr int DET_MAX_SEGS = (DET_MAX_ALIVE / SCAN_ROWS + 2) > 256 ? (DET_MAX_ALIVE / SCAN_ROWS + 2) : 256;      // scan workgroups touching one image | head workgroups per image
+constexpr int DET_MAX_SEGS = DET_MAX_ALIVE / SCAN_ROWS + 2;      // scan workgroups touching one image
 constexpr int DET_SMEM = 50 * 1024;      // carved per path (general: 16 KB keys + 32 KB flags; fast: 49 KB)
 static_assert(DET_SMEM >= DET_FAST * (8 + 8 + 16 + 16 + 1) && DET_SMEM >= DET_LDS_KEYS * 8 + DET_MAX_ALIVE, "LDS carve");
 
@@ -481,9 +481,6 @@ struct DetectArgs {
     int cap, max_out, out_cap, do_nms;
     const int* bcount;  // [scan workgroups][2] candidates per (workgroup, image) segment
     const u64* dense;   // [B*A] the segments' keys, compacted at each segment's first row
-    const u64* hkeys;   // or (boxes.h DetectCandidates) [B][hseg][hcap] keys of the head kernel's workgroups ...
-    const int* hcount;  // ... and their numbers [B][hseg]
-    int hseg, hcap;
     u64* keys1;         // [B][A2] general path: the image's candidates gathered for the sort
     u64* keys2;
     int* box;       // [B][A][4]
@@ -541,33 +538,29 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
     __shared__ int seg_off[DET_MAX_SEGS + 1], seg_base[DET_MAX_SEGS];
     __shared__ int s_pos[DET_FAST], s_cpos[DET_FAST];
     const int row_lo = b * p.A, row_hi = row_lo + p.A;
-    const int first_blk = row_lo / SCAN_ROWS, nseg = p.hkeys ? p.hseg : (row_hi - 1) / SCAN_ROWS - first_blk + 1;
-    const u64* const cand_keys = p.hkeys ? p.hkeys : p.dense;
-    if (p.hkeys) {
-        if (tid < nseg) {
-            seg_base[tid] = (b * p.hseg + tid) * p.hcap;
-            seg_off[tid + 1] = p.hcount[b * p.hseg + tid];
-        }
-    } else if (tid < nseg) {
+    const int first_blk = row_lo / SCAN_ROWS, nseg = (row_hi - 1) / SCAN_ROWS - first_blk + 1;
+    if (tid < nseg) {
         const int blk = first_blk + tid;
         const bool tail_of_prev = blk * SCAN_ROWS < row_lo;      // the workgroup started in the previous image
         seg_base[tid] = tail_of_prev ? row_lo : blk * SCAN_ROWS;
         seg_off[tid + 1] = __hip_atomic_load(p.bcount + blk * 2 + (tail_of_prev ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    {                                       // inclusive scan of the segment counts (nseg <= DET_THREADS): per wave, then the waves' totals
-        int v = tid < nseg ? seg_off[tid + 1] : 0;
+    if (nseg <= 64) {                       // inclusive scan of the segment counts by one wave
+        if (tid < 64) {
+            int v = tid < nseg ? seg_off[tid + 1] : 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(v, o, 64);
-            if (lane >= o) v += t;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o, 64);
+                if (lane >= o) v += t;
+            }
+            if (tid < nseg) seg_off[tid + 1] = v;
+            if (tid == 0) seg_off[0] = 0;
         }
-        if (lane == 63) s_wtot[wave] = v;
-        __syncthreads();
-        int add = 0;
-        for (int w = 0; w < wave; ++w) add += s_wtot[w];
-        if (tid < nseg) seg_off[tid + 1] = v + add;
-        if (tid == 0) seg_off[0] = 0;
+    } else if (tid == 0) {
+        int acc = 0;
+        seg_off[0] = 0;
+        for (int i = 1; i <= nseg; ++i) { acc += seg_off[i]; seg_off[i] = acc; }
     }
     __syncthreads();
     const int n = seg_off[nseg];
@@ -577,7 +570,7 @@ __device__ __forceinline__ void detect_image_body(const DetectArgs& p, const int
             const int mid = (lo + hi + 1) >> 1;
             if (seg_off[mid] <= f) lo = mid; else hi = mid - 1;
         }
-        return __hip_atomic_load(cand_keys + (size_t)seg_base[lo] + (f - seg_off[lo]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(p.dense + (size_t)seg_base[lo] + (f - seg_off[lo]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     if (n <= DET_FAST) {
@@ -880,13 +873,8 @@ size_t detect_ws_bytes(int B, int A) {
     return det_head_bytes(B, A) + ((size_t)B * A * 8 + 255) / 256 * 256 + 2 * (size_t)B * A2 * 8 + 2 * (size_t)B * A * 16;
 }
 
-int detect_max_candidate_segments() { return DET_MAX_SEGS < DET_THREADS ? DET_MAX_SEGS : DET_THREADS; }
-
 void detect(int A, int num_classes, const double* anchors, const float* pred, int B, float conf_thr, int cap, int max_out,
-            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s, const DetectCandidates* cand) {
-    SSD_REQUIRE(!cand || (cand->keys && cand->count && cand->nseg >= 1 && cand->nseg <= detect_max_candidate_segments() &&
-                          (long long)B * cand->nseg * cand->cap < (1LL << 31)),
-                "detect: candidate segments out of range");
+            int out_cap, bool nms, const DetectOut& out, void* ws, hipStream_t s) {
     SSD_REQUIRE(A <= 32767 && A <= DET_MAX_ALIVE, "detect: at most 32767 anchors (got %d)", A);
     SSD_REQUIRE(num_classes >= 1 && num_classes <= 27, "detect: 1..27 classes");
     SSD_REQUIRE(A >= SCAN_ROWS, "detect: at least %d anchors", SCAN_ROWS);
@@ -904,13 +892,12 @@ void detect(int A, int num_classes, const double* anchors, const float* pred, in
     int* nbox = (int*)base;
     const size_t rows = (size_t)B * A;
     const int blocks = (int)((rows + SCAN_ROWS - 1) / SCAN_ROWS);
-    if (!cand) {
+    {
         ProfScope prof("detect_scan", 0.0, (double)rows * nv * 4.0, s);
         hipLaunchKernelGGL(detect_scan_kernel, dim3(blocks), dim3(256), (size_t)SCAN_ROWS * nv * sizeof(float), s, A, nv, B, pred,
                            conf_thr, dense, bcount);
     }
     DetectArgs a{};
-    if (cand) { a.hkeys = cand->keys; a.hcount = cand->count; a.hseg = cand->nseg; a.hcap = cand->cap; }
     a.A = A; a.A2 = A2; a.nv = nv; a.B = B; a.anchors = anchors; a.pred = pred;
     a.cap = cap; a.max_out = max_out; a.out_cap = out_cap; a.do_nms = nms ? 1 : 0; a.bcount = bcount; a.dense = dense;
     a.keys1 = keys1; a.keys2 = keys2; a.box = box; a.nbox = nbox; a.out = out;

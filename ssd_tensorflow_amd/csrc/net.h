@@ -123,9 +123,6 @@ public:
     void activation_shape(const char* name, int* H, int* W, int* C) const;
     void pool_fusion(int* out, int cap, int* count) const;      // per 2x2 stride-2 pool in graph order: bit 0 fused forward, bit 1 fused backward
 
-    void set_detect_threshold(float thr);
-    bool detect_candidates_valid() const { return cand_valid_; }
-    bool detect_used_candidates() const { return cand_used_; }      // the last detect_last* call took them instead of the scan
     void detect_last(int b, float thr, int cap, int max_out, int out_cap, bool nms, int* count, float* conf, int* cls, int* idx, int* box);
     // asynchronous form: kernels + one device-to-host copy enqueued; dev_out (optional) = the HBM arrays of the slot
     const DetectSlot& detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out);
@@ -229,15 +226,6 @@ private:
     double* anchors_dev_ = nullptr;
     int* anchors_abs_dev_ = nullptr;
     void* detect_ws_ = nullptr;
-    // Decode candidates out of the head kernel (ops.h HeadCand, set_detect_threshold): armed threshold (< 0: off), the buffers,
-    // and what the LAST forward pass left in them
-    float cand_thr_ = -1.f;
-    unsigned long long* cand_keys_ = nullptr;
-    int* cand_count_ = nullptr;
-    int cand_nb_ = 0;                    // head workgroups per image
-    bool cand_valid_ = false, cand_used_ = false;
-    float cand_valid_thr_ = 0.f;
-    int cand_valid_b_ = 0;
     DetectSlot det_slot_[2];
     int det_cur_ = 0;
     void detect_slot_carve(const DetectSlot& sl, DetectOut& d, char* base) const;

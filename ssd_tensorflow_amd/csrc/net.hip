@@ -796,14 +796,6 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     }
     prof_.layer = "loss";
     const int A = preset_->num_anchors, nv = C_ + 5;
-    // the head kernel leaves the decode pass its candidates when a threshold is armed (set_detect_threshold): detect_last_dev
-    cand_valid_ = false;
-    HeadCand hc{};
-    const HeadCand* cand = nullptr;
-    if (cand_thr_ >= 0.f && cand_keys_) {
-        hc = HeadCand{cand_keys_, cand_count_, cand_thr_, 0};
-        cand = &hc;
-    }
     // The lanes' loss launches share a self-resetting completion ticket (ops.hip): if a launch fails after another
     // lane's has been enqueued, the count never reaches the step's total and the ticket would stay non-zero for the life
     // of the handle -- drain the device and clear it before the error leaves.
@@ -813,8 +805,8 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipStreamWaitEvent(stream_, ev_h_, 0));
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
-        if (train_mode) multibox_loss(heads_, b, 0, b, result_, y, lw_, wd_, loss_bnorm_, stream_, cand);
-        else heads_result(heads_, b, result_, stream_, cand);
+        if (train_mode) multibox_loss(heads_, b, 0, b, result_, y, lw_, wd_, loss_bnorm_, stream_);
+        else heads_result(heads_, b, result_, stream_);
     }
     for (int li = 0; li < nl && !heads_full; ++li) {
         Lane& ln = lane[li];
@@ -825,13 +817,11 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HeadLayout hl = heads_;
         for (int i = 0; i < hl.nmaps; ++i) hl.buf[i] = heads_.buf[i] + (size_t)ln.b0 * hl.hw[i] * hl.ld[i];
         float* res = result_ + (size_t)ln.b0 * A * nv;
-        HeadCand lc = hc;
-        lc.b_off = ln.b0;
         if (train_mode) {
             if (li == 1) HIP_OK(hipStreamWaitEvent(ln.s, ev_l2_, 0));      // the final reduction may fall to this lane
-            multibox_loss(hl, ln.nb, ln.b0, b, res, y + (size_t)ln.b0 * A * nv, lw_, wd_, loss_bnorm_, ln.s, cand ? &lc : nullptr);
+            multibox_loss(hl, ln.nb, ln.b0, b, res, y + (size_t)ln.b0 * A * nv, lw_, wd_, loss_bnorm_, ln.s);
         } else {
-            heads_result(hl, ln.nb, res, ln.s, cand ? &lc : nullptr);
+            heads_result(hl, ln.nb, res, ln.s);
         }
     }
     } catch (...) {
@@ -846,7 +836,6 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipEventRecord(ev_join_, s2_));
         HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
-    if (cand) { cand_valid_ = true; cand_valid_thr_ = cand_thr_; cand_valid_b_ = b; }
     if (train_mode) HIP_OK(hipEventRecord(ev_loss_[loss_seq_ % LOSS_RING], stream_));
     fwd_guard.done = true;
 }
@@ -1166,7 +1155,6 @@ void Net::get_losses_step(int steps_back, float out[4]) {
 
 void Net::set_result(const float* pred_dev, int b) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
-    cand_valid_ = false;      // the head kernel's decode candidates describe the pass that wrote the OLD result_
     HIP_OK(hipMemcpyAsync(result_, pred_dev, (size_t)b * preset_->num_anchors * (C_ + 5) * sizeof(float), hipMemcpyDeviceToDevice, stream_));
 }
 
@@ -1268,25 +1256,6 @@ void Net::detect_slot_carve(const DetectSlot& sl, DetectOut& d, char* base) cons
     d.box = d.idx + n;
 }
 
-// Arm (thr >= 0) or disarm (thr < 0) the hand-over of decode candidates from the head kernel: every forward pass from now on
-// leaves, beside `result`, the anchors whose best foreground confidence reaches thr, and a detect_last* call with exactly this
-// threshold on that pass skips its scan over `result` (ssdutils.py:192-229 decode_boxes; bit-identical output, tests/test_gpu_boxes.py).
-// Any other threshold, or a pass made before arming, takes the scan as before.
-void Net::set_detect_threshold(float thr) {
-    cand_valid_ = false;
-    cand_thr_ = thr >= 0.f ? thr : -1.f;
-    if (cand_thr_ < 0.f) return;
-    cand_nb_ = heads_blocks_per_image(heads_);
-    if (cand_nb_ > detect_max_candidate_segments()) {      // (no preset of the reference comes near: vgg512 has 173)
-        cand_thr_ = -1.f;
-        return;
-    }
-    if (!cand_keys_) {
-        cand_keys_ = (unsigned long long*)dalloc((size_t)Bmax_ * cand_nb_ * HEAD_CAND_CAP * sizeof(unsigned long long));
-        cand_count_ = (int*)dalloc((size_t)Bmax_ * cand_nb_ * sizeof(int));
-    }
-}
-
 const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, int out_cap, bool nms, DetectOut* dev_out) {
     SSD_REQUIRE(b >= 1 && b <= Bmax_, "batch %d outside 1..%d", b, Bmax_);
     SSD_REQUIRE(out_cap >= 1, "out_cap must be >= 1");
@@ -1330,11 +1299,7 @@ const DetectSlot& Net::detect_last_dev(int b, float thr, int cap, int max_out, i
     prof_.layer = "detect";
     DetectOut d;
     detect_slot_carve(sl, d, sl.dev);
-    // the head kernel of the pass that wrote result_ left this threshold's candidates: no scan over result_
-    const bool handed = cand_valid_ && cand_valid_thr_ == thr && cand_valid_b_ == b;
-    cand_used_ = handed;
-    const DetectCandidates dc{cand_keys_, cand_count_, cand_nb_, HEAD_CAND_CAP};
-    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_, handed ? &dc : nullptr);
+    detect(A, C_, anchors_dev_, result_, b, thr, cap, max_out, out_cap, nms, d, detect_ws_, stream_);
     if (!sl.mapped) HIP_OK(hipMemcpyAsync(sl.host, sl.dev, need, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipEventRecord(sl.ready, stream_));
     if (dev_out) *dev_out = d;

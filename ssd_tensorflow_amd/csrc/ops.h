@@ -64,20 +64,7 @@ struct HeadLayout {
 };
 // result[b][a][:] = (softmax(logits), loc) in the reference's anchor order
 // (map -> box type -> row -> col, ssdvgg.py:63,365 == ssdutils.py:104-116).
-// Round 5: the head kernel can hand the decode pass (boxes.h detect) its CANDIDATES, so that pass need not scan `result` again
-// (111.8 MB at batch 128): every anchor whose best foreground confidence reaches thr becomes the scan's 64-bit key
-//   conf bits << 32 | (32767 - anchor) << 8 | 0x80 | class
-// from the very floats the kernel stores in `result`, compacted per workgroup (ballots, no atomics, deterministic): workgroup g of
-// image b (heads_blocks_per_image of them, in launch order) owns keys[(b * nb + g) * HEAD_CAND_CAP ...] and count[b * nb + g].
-constexpr int HEAD_CAND_CAP = 256;          // = 32 cells x 8 box types: a workgroup's anchors
-struct HeadCand {
-    unsigned long long* keys;
-    int* count;
-    float thr;
-    int b_off;                              // image index of this launch's first image in the two arrays
-};
-int heads_blocks_per_image(const HeadLayout& L);
-void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s, const HeadCand* cand = nullptr);
+void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s);
 
 struct LossWork {                    // per-step scratch, all device
     float* ce;                       // [B][A] cross entropy
@@ -97,7 +84,7 @@ void loss_work_carve(LossWork& w, void* base, int B, int A);
 // A step may compute its loss in several launches over disjoint sample ranges (forward lanes): L.buf, result and labels
 // point at the range's first sample, B = samples of this launch, b_off = index of its first sample, B_total = the step's.
 void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const float* result, const float* labels, LossWork& w,
-                   float weight_decay, float bnorm, hipStream_t s, const HeadCand* cand = nullptr);
+                   float weight_decay, float bnorm, hipStream_t s);
 // sum of squares of the filter region into w.partial (the l2 term of multibox_loss, which must follow it in stream
 // order): 4 bytes per parameter, independent of the forward pass, so the step runs it beside the first layers
 void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t s);

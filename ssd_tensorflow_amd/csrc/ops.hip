@@ -839,7 +839,6 @@ constexpr int HTHREADS = 256;               // 32 cells x 8 type slots (nj <= 8)
 struct HeadGrid {
     int blk_off[MAX_MAPS + 1];              // first workgroup of each map
     int nchunk[MAX_MAPS];                   // cell chunks per image
-    int img_off[MAX_MAPS + 1];              // a map's first workgroup among the workgroups of ONE image (candidate segments)
     int ldp_max, nj_max;
 };
 static HeadGrid head_grid(const HeadLayout& L, int B) {
@@ -848,20 +847,13 @@ static HeadGrid head_grid(const HeadLayout& L, int B) {
     for (int i = 0; i < L.nmaps; ++i) {
         g.blk_off[i] = off;
         g.nchunk[i] = (L.hw[i] + HCH - 1) / HCH;
-        g.img_off[i + 1] = g.img_off[i] + g.nchunk[i];
         off += g.nchunk[i] * B;
         g.ldp_max = std::max(g.ldp_max, L.ld[i] + 1);
         g.nj_max = std::max(g.nj_max, L.nj[i]);
     }
     for (int i = L.nmaps; i <= MAX_MAPS; ++i) g.blk_off[i] = off;
-    for (int i = L.nmaps; i < MAX_MAPS; ++i) g.img_off[i + 1] = g.img_off[L.nmaps];
     SSD_REQUIRE(g.nj_max <= HTHREADS / HCH, "heads: at most %d box types per map", HTHREADS / HCH);
     return g;
-}
-int heads_blocks_per_image(const HeadLayout& L) {
-    int n = 0;
-    for (int i = 0; i < L.nmaps; ++i) n += (L.hw[i] + HCH - 1) / HCH;
-    return n;
 }
 struct HeadBlock {
     int map, b, cell0, ncell;
@@ -908,10 +900,8 @@ __device__ __forceinline__ void lds_to_run(float* __restrict__ dst, const float*
 template <bool TRAIN>
 __global__ __launch_bounds__(HTHREADS) void heads_kernel(HeadLayout L, HeadGrid G, int B, float* __restrict__ result,
                                                          const float* __restrict__ labels, float* __restrict__ ce_out,
-                                                         float* __restrict__ sl1_out, unsigned char* __restrict__ pos_out, HeadCand cand) {
+                                                         float* __restrict__ sl1_out, unsigned char* __restrict__ pos_out) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
-    __shared__ int s_cand[HTHREADS / 64];
-    unsigned long long ckey = 0ull;          // this thread's anchor as a decode candidate (ops.h HeadCand)
     const HeadBlock k = head_block(L, G);
     const int nv = L.nvars, nc = nv - 4;
     const int ld = L.ld[k.map], ldp = ld + 1, nj = L.nj[k.map], hw = L.hw[k.map];
@@ -989,16 +979,6 @@ __global__ __launch_bounds__(HTHREADS) void heads_kernel(HeadLayout L, HeadGrid 
 #pragma unroll
         for (int c = 0; c < MAXV; ++c)
             if (c < nv) r[c] = c < nc ? e[c] * inv : z[c];
-        if (cand.keys) {      // the scan's key (boxes.hip detect_scan_block) from the floats just stored: first maximum over the foreground classes
-            float conf = e[0] * inv;
-            int best = 0;
-#pragma unroll
-            for (int c = 1; c < MAXV; ++c)
-                if (c < nc - 1 && e[c] * inv > conf) { conf = e[c] * inv; best = c; }
-            const int a = L.off[k.map] + j * hw + k.cell0 + cell;
-            if (!(conf < cand.thr))
-                ckey = ((unsigned long long)__float_as_uint(conf) << 32) | ((unsigned long long)(32767 - a) << 8) | (unsigned long long)best | (1ull << 7);
-        }
         if constexpr (TRAIN) {
             float ce = 0.f, sl = 0.f;
             const bool pos = y[nc - 1] == 0.f;
@@ -1018,21 +998,7 @@ __global__ __launch_bounds__(HTHREADS) void heads_kernel(HeadLayout L, HeadGrid 
             pos_out[idx] = pos ? 1 : 0;
         }
     }
-    const unsigned long long cbal = __ballot(ckey != 0ull);
-    if (cand.keys && (threadIdx.x & 63) == 0) s_cand[threadIdx.x >> 6] = __popcll(cbal);
     __syncthreads();
-    if (cand.keys) {      // compact the workgroup's candidates into ITS segment: ballot prefix per wave, wave totals through LDS
-        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        int base = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < HTHREADS / 64; ++w) {
-            if (w < wv) base += s_cand[w];
-            tot += s_cand[w];
-        }
-        const size_t seg = (size_t)(k.b + cand.b_off) * G.img_off[MAX_MAPS] + G.img_off[k.map] + k.cell0 / HCH;
-        if (ckey != 0ull) cand.keys[seg * HEAD_CAND_CAP + base + __popcll(cbal & ((1ull << lane) - 1ull))] = ckey;
-        if (threadIdx.x == 0) cand.count[seg] = tot;
-    }
     // result: per box type one contiguous run of [nv] records; dword stores, 256 B per wave
 #pragma unroll
     for (int jj = 0; jj < HTHREADS / HCH; ++jj) {
@@ -1049,13 +1015,13 @@ static size_t heads_lds_bytes(const HeadLayout& L, const HeadGrid& G) {
     return ((size_t)HCH * G.ldp_max + (size_t)G.nj_max * HCH * L.nvars) * sizeof(float);
 }
 
-void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s, const HeadCand* cand) {
+void heads_result(const HeadLayout& L, int B, float* result, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     const int total = B * L.A;
     const HeadGrid G = head_grid(L, B);
     ProfScope prof("heads_result", 0.0, 8.0 * total * L.nvars, s);
     hipLaunchKernelGGL(heads_kernel<false>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B, result,
-                       nullptr, nullptr, nullptr, nullptr, cand ? *cand : HeadCand{});
+                       nullptr, nullptr, nullptr, nullptr);
     HIP_OK(hipGetLastError());
 }
 
@@ -1332,7 +1298,7 @@ void l2_partials(const float* filters, size_t nfilters, LossWork& w, hipStream_t
 }
 
 void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const float* result, const float* labels, LossWork& w,
-                   float weight_decay, float bnorm, hipStream_t s, const HeadCand* cand) {
+                   float weight_decay, float bnorm, hipStream_t s) {
     SSD_REQUIRE(L.nvars <= MAXV, "heads: num_classes + 5 must be <= %d", MAXV);
     SSD_REQUIRE(L.A <= 32 * LS_THREADS, "loss: at most %d anchors", 32 * LS_THREADS);
     SSD_REQUIRE(B_total <= LS_THREADS / 2, "loss: at most %d images per step", LS_THREADS / 2);
@@ -1342,7 +1308,7 @@ void multibox_loss(const HeadLayout& L, int B, int b_off, int B_total, const flo
     const size_t o = (size_t)b_off * L.A;                // this launch's slice of the per-anchor work arrays
     ProfScope prof("multibox_loss", 0.0, 12.0 * total * L.nvars, s);
     hipLaunchKernelGGL(heads_kernel<true>, dim3(G.blk_off[MAX_MAPS]), dim3(HTHREADS), heads_lds_bytes(L, G), s, L, G, B,
-                       const_cast<float*>(result), labels, w.ce + o, w.sl1 + o, w.pos + o, cand ? *cand : HeadCand{});
+                       const_cast<float*>(result), labels, w.ce + o, w.sl1 + o, w.pos + o);
     const int pt = (L.A + LS_THREADS - 1) / LS_THREADS;
     if (pt <= 9)
         hipLaunchKernelGGL(loss_sample_kernel<9>, dim3(B), dim3(LS_THREADS), 0, s, B_total, b_off, L.A, bnorm, w.ce, w.sl1, w.pos, w.sel, w.sample,

@@ -180,7 +180,6 @@ def main(argv=None):
                     pascal_summary.add_detections(name_of(idxs[i]), boxes, img_size=sizes[i])
 
         pending = None
-        net.set_detect_threshold(args.threshold)      # the head kernel of every pass hands decode + NMS its candidates
         for x, idxs, sizes in sample_generator(files, size, args.batch_size):
             net.infer_dev(x)                                                                 # infer.py:225-227
             ticket = net.detect_last_launch(x.shape[0], args.threshold, None, 200)

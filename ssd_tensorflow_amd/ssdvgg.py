@@ -500,24 +500,6 @@ class SSDVGG:
             out_cap = max(min(out_cap, mo), 1)
         return cap, mo, out_cap
 
-    def set_detect_threshold(self, confidence_threshold):
-        """Arm the hand-over of decode candidates (ssd_set_detect_threshold): every pass from now on leaves, beside `result`, the
-        anchors that reach this threshold, and detect_last* with exactly this threshold skips its scan over `result`.  None or a
-        negative value disarms.  The detections are the same either way."""
-        check(lib.ssd_set_detect_threshold(self._h, -1.0 if confidence_threshold is None else float(confidence_threshold)))
-
-    def detect_candidates_valid(self):
-        """the last pass left candidates (armed before it ran)"""
-        v = C.c_int(0)
-        check(lib.ssd_detect_candidates_valid(self._h, C.byref(v)))
-        return bool(v.value & 1)
-
-    def detect_used_candidates(self):
-        """the last detect_last* call took the head kernel's candidates instead of scanning `result`"""
-        v = C.c_int(0)
-        check(lib.ssd_detect_candidates_valid(self._h, C.byref(v)))
-        return bool(v.value & 2)
-
     def detect_last_launch(self, b, confidence_threshold=0.5, detections_cap=200, max_out=None, nms=True):
         """Enqueue decode + NMS of the last step's result and the copy of its (small) output; returns a
         ticket whose get() yields what detect_last returns.  Two output slots alternate in the handle, so a

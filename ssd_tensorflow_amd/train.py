@@ -77,7 +77,6 @@ class StepLoop:
         net, sess, td, world = self.net, self.sess, self.td, self.world
         pending_det = None
         pending_loss = None                     # sample count of the launched step whose losses are not booked yet
-        net.set_detect_threshold(0.5 if with_ap else None)      # the step's head kernel hands decode + NMS its candidates
         for x, y, gt_boxes in generator(self.batch_size, self.num_workers):
             n = len(gt_boxes)
             count = td.global_count if world > 1 else n

@@ -270,54 +270,6 @@ def test_infer_and_detect_last_matches_oracle_boxes():
     sess.close()
 
 
-@pytest.mark.parametrize('pname,b,dtype', [('vgg300', 3, 'f32'), ('vgg300', 8, 'bf16'), ('vgg512', 2, 'f32')])
-def test_head_kernel_hands_decode_its_candidates(pname, b, dtype):
-    """Round 5 (ssd_set_detect_threshold): while a threshold is armed, the kernel that writes `result` also leaves decode_boxes'
-    candidates (ssdutils.py:192-229), and detect_last with that threshold skips its scan over `result`.  The detections must be
-    the scan's, bit for bit: inference and training passes, one and two forward lanes (b = 8), few and > 1024 candidates per image
-    (the LDS and the general path of the per-image kernel), both presets; another threshold falls back to the scan."""
-    preset = ob.get_preset(pname)
-    sess = Session(0)
-    net = SSDVGG(sess, pname)
-    net.build_from_vgg(None, 20, max_batch=b, seed=5, dtype=dtype)
-    net.build_optimizer(learning_rate=0.0)
-    rng = np.random.default_rng(12)
-    x, y, _ = ref.synth_batch(rng, b, preset)
-    r = sess.run(net.result, feed_dict={net.image_input: x, net.keep_prob: 1})
-    best = r[:, :, :20].max(-1)
-    thrs = [float(np.quantile(best, q)) for q in (0.999, 0.97, 0.5)]      # ~9, ~260 and ~4400 (vgg300) candidates per image
-
-    def same(a, bb):
-        return all(np.array_equal(a[i][k], bb[i][k]) for i in range(b) for k in ('conf', 'cls', 'idx', 'box'))
-
-    assert not net.detect_candidates_valid()
-    want = {t: net.detect_last(b, t, None, 200) for t in thrs}
-    want_cap = net.detect_last(b, thrs[1], 200, None)                  # training's form: the 200 best candidates, no [:max_out]
-    assert sum(len(d['idx']) for d in want[thrs[0]]) > 0 and max(len(d['idx']) for d in want[thrs[2]]) > 10
-    for t in thrs:
-        net.set_detect_threshold(t)
-        r2 = sess.run(net.result, feed_dict={net.image_input: x, net.keep_prob: 1})
-        assert np.array_equal(r, r2) and net.detect_candidates_valid()
-        assert same(net.detect_last(b, t, None, 200), want[t]), f'handed-over candidates differ from the scan at threshold {t}'
-        assert net.detect_used_candidates()
-        other = thrs[0] if t != thrs[0] else thrs[1]
-        assert same(net.detect_last(b, other, None, 200), want[other])          # not the armed threshold: the scan
-        assert not net.detect_used_candidates()
-    net.set_detect_threshold(thrs[1])
-    # a training step's head kernel (the loss form) hands them over as well
-    rt, _ = sess.run([net.result, net.losses], feed_dict={net.image_input: x, net.labels: y})
-    assert net.detect_candidates_valid()
-    got = net.detect_last(b, thrs[1], 200, None)
-    assert net.detect_used_candidates()
-    if np.array_equal(rt, r):
-        assert same(got, want_cap)
-    net.set_detect_threshold(None)
-    assert same(net.detect_last(b, thrs[1], 200, None), got)                    # the same pass through the scan
-    sess.run(net.result, feed_dict={net.image_input: x, net.keep_prob: 1})
-    assert not net.detect_candidates_valid()
-    sess.close()
-
-
 def test_checkpoint_roundtrip(tmp_path):
     preset, m, sess, net = make_pair('vgg300', 1)
     net.build_optimizer(learning_rate=LearningRate([0.001, 0.0001], [5]), weight_decay=WD, momentum=0.9)
