@@ -114,6 +114,9 @@ SIGNATURES = {
     'ssd_op_cast_filter': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'ssd_op_conv2d_fwd_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),
     'ssd_op_conv2d_dgrad_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_fwd_bf16_chain': (i32, [vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),
+    'ssd_op_conv2d_dgrad_bf16_chain': (i32, [vp, vp, vp, vp, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_wgrad_bf16_direct': (i32, [vp, vp, vp, vp, vp, f32] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_wgrad_bf16_ws_floats': (sz, [i32] * 13),
     'ssd_op_conv2d_wgrad_bf16': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_first_fwd_bf16': (i32, [vp, vp, vp, vp] + [i32] * 14 + [vp]),

@@ -792,6 +792,53 @@ int ssd_op_conv2d_wgrad_bf16(const void* x, const void* dy, float* dw, float* db
                     dbias, w, weight_decay, ws, (hipStream_t)stream);
     API_END
 }
+namespace {
+struct TailPacked {      // a filter mirror packed for the chain kernel into a temporary buffer
+    void* p = nullptr;
+    TailPacked(const ConvDesc& d, bool dgrad, const void* mirror, hipStream_t s) {
+        HIP_OK(hipMalloc(&p, tail_chain_packed_elems(d, dgrad) * 2));
+        const TailPackItem it{d, dgrad, mirror, p};
+        tail_chain_pack_filters(&it, 1, s);
+    }
+    ~TailPacked() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+int ssd_op_conv2d_fwd_bf16_chain(const void* x, const void* w_oi, const float* bias, void* y, int y_f32, int b, int hi, int wi, int ci,
+                                 int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, int relu,
+                                 void* stream) {
+    API_BEGIN
+    TailStage t{};
+    t.d = mk(1, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    t.dgrad = false; t.src = x; t.bias = bias; t.dst = y; t.relu = relu != 0; t.out_f32 = y_f32 != 0;
+    TailPacked tmp(t.d, false, w_oi, (hipStream_t)stream);      // (unit-parity entry point: the step packs once per weight update)
+    t.wgt_packed = tmp.p;
+    tail_chain_bf16(&t, 1, b, "tail_fwd_bf16", (hipStream_t)stream);
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    API_END
+}
+int ssd_op_conv2d_dgrad_bf16_chain(const void* dy, const void* w_io, void* dx, const void* mask, int accumulate, int b, int hi, int wi,
+                                   int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w,
+                                   void* stream) {
+    API_BEGIN
+    TailStage t{};
+    t.d = mk(1, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    t.dgrad = true; t.src = dy; t.mask = mask; t.dst = dx; t.accum = accumulate != 0;
+    TailPacked tmp(t.d, true, w_io, (hipStream_t)stream);
+    t.wgt_packed = tmp.p;
+    tail_chain_bf16(&t, 1, b, "tail_dgrad_bf16", (hipStream_t)stream);
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    API_END
+}
+int ssd_op_conv2d_wgrad_bf16_direct(const void* x, const void* dy, float* dw, float* dbias, const float* w, float weight_decay, int b,
+                                    int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h,
+                                    int pad_w, void* stream) {
+    API_BEGIN
+    WgradGroupItem it{};
+    it.d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    it.x = (const bf16_t*)x; it.dy = (const bf16_t*)dy; it.dw = dw; it.dbias = dbias; it.w = w;
+    conv_wgrad_group_bf16(&it, 1, weight_decay, (hipStream_t)stream);
+    API_END
+}
 int ssd_op_conv2d_first_fwd_bf16(const float* x, const float* w, const float* bias, void* y, int b, int hi, int wi, int ci, int ho,
                                  int wo, int co, int kh, int kw, int stride, int dil, int pad_h, int pad_w, int relu,
                                  void* stream) {

@@ -106,4 +106,43 @@ size_t conv_wgrad_bf16_ws_floats(const ConvDesc& d);
 void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float* dw, float* dbias, const float* w,
                      float weight_decay, float* ws, hipStream_t s);
 
+// ---- Round 6: the latency-bound tail (conv9_1 ... conv11_2 / conv12_2 and the small maps' heads) as one launch per direction ----
+// tail_bf16.hip: a chain of convolution stages (forward, or data gradients in backward order), each image's chain walked by ONE
+// workgroup with workgroup barriers between the stages -- nothing below the 10x10 map couples two images.  Pointers are those of
+// the FIRST image of the launch; d.B is ignored (nimg images, [nimg][H][W][C] tensors).
+struct TailStage {
+    ConvDesc d;             // the convolution's geometry (forward sense), as conv_fwd_bf16 / conv_dgrad_bf16 take it
+    bool dgrad;             // false: dst = relu?(conv(src) + bias);  true: dst (+)= conv^T(src), masked by `mask` > 0
+    const void* src;        // forward: x [.][Hi][Wi][Ci];  data gradient: dy [.][Ho][Wo][Co]   (bf16)
+    const void* wgt_packed; // the stage's filter in the chain kernel's fragment order: tail_chain_pack_filter of the [tap][Co][Ci] mirror
+                            // (forward) or of the [tap][Ci][Co] mirror (data gradient); tail_chain_packed_elems bf16 elements
+    const float* bias;      // forward
+    const void* mask;       // data gradient: the relu mask tensor (dx's shape, bf16) or nullptr
+    void* dst;              // forward: y (bf16, or fp32 when out_f32);  data gradient: dx (bf16)
+    bool relu, accum, out_f32;
+};
+int tail_chain_max_stages();
+bool tail_chain_stage_supported(const ConvDesc& d);
+size_t tail_chain_packed_elems(const ConvDesc& d, bool dgrad);
+struct TailPackItem {
+    ConvDesc d;
+    bool dgrad;             // false: `mirror` is the [tap][Co][Ci] image (forward stage); true: the [tap][Ci][Co] image (data-gradient stage)
+    const void* mirror;
+    void* packed;
+};
+void tail_chain_pack_filters(const TailPackItem* items, int n, hipStream_t s);      // one launch
+void tail_chain_bf16(const TailStage* stages, int nstages, int nimg, const char* label, hipStream_t s);
+// the weight gradients of several small layers in ONE launch, each with a single pixel split and the direct epilogue
+// (dw = x^T dy + weight_decay * w, dbias = column sums of dy): no slabs, no reduce launches
+struct WgradGroupItem {
+    ConvDesc d;
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* dw;
+    float* dbias;
+    const float* w;
+};
+int conv_wgrad_group_bf16_max();
+void conv_wgrad_group_bf16(const WgradGroupItem* items, int n, float weight_decay, hipStream_t s);
+
 }  // namespace ssd

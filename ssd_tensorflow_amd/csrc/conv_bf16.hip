@@ -1343,10 +1343,17 @@ struct WgradArgsH {
     int CT, NT;
     int mchunk, nsplit;
     int tap_dh[9], tap_dw[9];
+    // direct epilogue (nsplit == 1, the grouped launch of the tail's layers): dw = sum + wd * w, db = column sums -- no slab, no reduce
+    float* dw;
+    float* db;
+    const float* w;
+    float wd;
 };
 
-template <int WM, int WN, int TM, int TN, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
+// The body of the per-tap weight gradient for workgroup `wg_index` of `wg_count` of ONE layer: called by the single-layer kernel
+// and by the grouped one (conv_wgrad_group_bf16_kernel), whose grid enumerates the workgroups of several layers.
+template <int WM, int WN, int TM, int TN, int NS, bool XCD = true>
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WgradArgsH& p, const int wg_index, const int wg_count, unsigned char* smem) {
     constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN, BP = 64;
     constexpr int XCPR = BKT / 8, YCPR = BNT / 8;               // 16-byte chunks per pixel row
     constexpr int XRPP = 256 / XCPR, YRPP = 256 / YCPR;         // pixel rows per DMA pass of the workgroup
@@ -1357,11 +1364,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     static_assert(XCPR == 8 || XCPR == 16 || XCPR == 32, "channel tile 64, 128 or 256");
     static_assert(YCPR == 8 || YCPR == 16, "n tile 64 or 128");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // scalar: LDS-DMA bases stay in SGPRs
-    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wgid = XCD ? xcd_remap(wg_index, wg_count) : wg_index;
     const int ntiles = p.ntaps * p.CT * p.NT;
     const int split = wgid / ntiles;
     int tile = wgid - split * ntiles;
@@ -1539,6 +1544,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
     }
 
     const size_t wcount = (size_t)p.ntaps * p.Ci * p.Co;
+    if (p.dw) {      // direct: this workgroup holds the layer's whole pixel range (nsplit == 1)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * 32 * TN + ni * 32 + li;
+                if (n >= p.Co) continue;
+                float wv[16];
+                size_t o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    o[r] = ((size_t)tap * p.Ci + (c0 + kl < p.Ci ? c0 + kl : 0)) * p.Co + n;
+                    wv[r] = p.wd != 0.f ? p.w[o[r]] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (c0 + kl >= p.Ci) continue;
+                    p.dw[o[r]] = p.wd != 0.f ? acc[mi][ni][r] + p.wd * wv[r] : acc[mi][ni][r];      // (the reduce kernels' order: sum, then + wd * w)
+                }
+            }
+        }
+        if (bias_wave && lh == 0 && p.db) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * 32 * TN + ni * 32 + li;
+                if (n < p.Co) p.db[n] = accb[ni][0];
+            }
+        }
+        return;
+    }
     float* slab = p.ws + (size_t)split * (wcount + p.Co);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -1561,6 +1598,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
             if (n < p.Co) slab[wcount + n] = accb[ni][0];
         }
     }
+}
+
+template <int WM, int WN, int TM, int TN, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv_wgrad_bf16_body<WM, WN, TM, TN, NS>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several layers' weight gradients in ONE launch (the tail's layers: a handful of tiles each, every one of them a launch of
+// 6-25 us plus a reduce of 6 us today): workgroup -> (layer, workgroup of the layer) through a prefix table; every layer has a
+// single pixel split and takes the direct epilogue.  64 input x 128 output channels per workgroup, two stages.
+constexpr int WGRAD_GROUP_MAX = 12;
+struct WgradGroupArgs {
+    int n;
+    int wg0[WGRAD_GROUP_MAX + 1];
+    WgradArgsH L[WGRAD_GROUP_MAX];
+};
+static_assert(sizeof(WgradGroupArgs) <= 4000, "kernel argument segment");
+__global__ __launch_bounds__(256) void conv_wgrad_group_bf16_kernel(WgradGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int l = 0;
+    for (int k = 1; k < g.n; ++k)
+        if ((int)blockIdx.x >= g.wg0[k]) l = k;
+    conv_wgrad_bf16_body<2, 2, 1, 2, 2, false>(g.L[l], (int)blockIdx.x - g.wg0[l], g.wg0[l + 1] - g.wg0[l], smem);
 }
 
 // =================================================================================
@@ -2956,6 +3017,40 @@ void conv_wgrad_bf16(const ConvDesc& d, const bf16_t* x, const bf16_t* dy, float
     else if (pl.cfg == 5) launch_wgrad_h<2, 2, 4, 2, 3>(a, pl, "conv_wgrad_bf16_256x128x3", fl, by, s);
     else launch_wgrad_h<2, 2, 2, 2, 2>(a, pl, "conv_wgrad_bf16_128x128", fl, by, s);
     wgrad_reduce(ws, pl.nsplit, (size_t)a.ntaps * d.Ci * d.Co, d.Co, dw, dbias, w, weight_decay, s);
+}
+
+// ---- the tail's weight gradients as one launch (conv_wgrad_group_bf16_kernel) --------------------------------------------
+int conv_wgrad_group_bf16_max() { return WGRAD_GROUP_MAX; }
+void conv_wgrad_group_bf16(const WgradGroupItem* items, int n, float weight_decay, hipStream_t s) {
+    SSD_REQUIRE(n >= 1 && n <= WGRAD_GROUP_MAX, "grouped weight gradient: 1..%d layers (got %d)", WGRAD_GROUP_MAX, n);
+    WgradGroupArgs g{};
+    g.n = n;
+    double fl = 0.0, by = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const ConvDesc& d = items[i].d;
+        check_desc_h(d);
+        WgradArgsH& a = g.L[i];
+        a.x = items[i].x; a.dy = items[i].dy; a.ws = nullptr;
+        a.M = d.B * d.Ho * d.Wo; a.Hi = d.Hi; a.Wi = d.Wi; a.Ci = d.Ci; a.Ho = d.Ho; a.Wo = d.Wo; a.Co = d.Co;
+        a.ntaps = d.KH * d.KW; a.stride = d.stride; a.CT = cdiv(d.Ci, 64); a.NT = cdiv(d.Co, 128);
+        a.mchunk = cdiv(a.M, 64) * 64; a.nsplit = 1;
+        for (int kh = 0; kh < d.KH; ++kh)
+            for (int kw = 0; kw < d.KW; ++kw) {
+                a.tap_dh[kh * d.KW + kw] = kh * d.dil - d.pad_h;
+                a.tap_dw[kh * d.KW + kw] = kw * d.dil - d.pad_w;
+            }
+        a.dw = items[i].dw; a.db = items[i].dbias; a.w = items[i].w; a.wd = weight_decay;
+        SSD_REQUIRE(a.dw != nullptr && a.w != nullptr, "grouped weight gradient: null gradient / filter pointer");
+        g.wg0[i + 1] = g.wg0[i] + a.ntaps * a.CT * a.NT;
+        fl += conv_flops(d);
+        by += 2.0 * conv_elems(d);
+    }
+    constexpr size_t lds = 2 * (size_t)64 * (64 + 128) * 2;
+    static bool once = (set_lds(conv_wgrad_group_bf16_kernel, lds), true);
+    (void)once;
+    ProfScope prof("conv_wgrad_group_bf16_64x128", fl, by, s);
+    SSD_LAUNCH_STOP(conv_wgrad_group_bf16_kernel, dim3(g.wg0[n]), dim3(256), lds, s, g);
+    HIP_OK(hipGetLastError());
 }
 
 }  // namespace ssd

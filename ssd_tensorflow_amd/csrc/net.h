@@ -187,6 +187,19 @@ private:
     bool bw_first_fused_ = false;        // ... and this backward pass took it
     int fused_first_out_ = -1;           // the tensor whose gradient that pass did not materialise (conv1_1's output)
     void launch_wgrad(int op_index, int b, hipStream_t ws);
+    // Round 6 (bf16): the latency-bound tail as one launch per direction (conv.h TailStage; net.hip plan_tail_chain).  chain_first_ =
+    // op index of the first 1x1 layer below the 10x10 map (vgg300: conv9_1, vgg512: conv10_1), -1: off; in_chain_[op] marks the
+    // extra layers from there on and the multibox heads that read them.
+    int chain_first_ = -1;
+    std::vector<char> in_chain_;
+    bf16_t* wq_tail_ = nullptr;                          // the chain layers' filters in the chain kernel's fragment order (conv.h tail_chain_pack_filters) ...
+    std::vector<long long> tail_fwd_off_, tail_bwd_off_; // ... element offsets per op of the forward / data-gradient form (-1: none)
+    void pack_tail_filters(hipStream_t s);               // from the fresh bf16 mirrors, one launch (forward, behind cast_filters)
+    bool chain_fwd_ = false, chain_bwd_ = false;      // SSD_TAIL_FUSE bit 0 / bit 1: the chain in forward / in backward
+    bool bw_chain_done_ = false;         // this backward pass has issued the chain's data gradients and grouped weight gradients
+    void plan_tail_chain();
+    void launch_tail_forward(int b0, int nb, hipStream_t s);
+    void launch_tail_backward(int b, bool* side_used);
     void build_orders();
     void plan_pool_fusion();
     int bw_class(const Op& op, int op_index) const;

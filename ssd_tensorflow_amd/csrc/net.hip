@@ -354,6 +354,167 @@ void Net::plan_pool_fusion() {
     }
 }
 
+// Round 6, the tail as one launch per direction (bf16; conv.h TailStage, tail_bf16.hip).  The chain starts at the first 1x1
+// "convN_1" layer behind conv8_2 whose input map is at most 10 x 10 -- below that a layer is a tile or two per image and nothing
+// couples two images -- and holds every extra layer from there on plus the multibox heads that read their outputs:
+//   forward   conv9_1, conv9_2, head3, conv10_1, conv10_2, head4, conv11_1, conv11_2, head5                    (vgg300)
+//   backward  data gradients of head5, head4, head3, conv11_2, conv11_1, conv10_2, conv10_1, conv9_2 in ONE launch (the first
+//             layer's own data gradient accumulates into a tensor the 10x10 head also writes: it stays a launch), then the
+//             weight gradients of all nine layers in ONE grouped launch with a direct epilogue (no slabs, no reduces).
+// 27 launches of round 5 (9 forward, 8 + 10 backward, not counting 9 reduces) become 3 (+ one that packs the filters).
+// SSD_TAIL_FUSE: bit 0 forward, bit 1 backward; default 3; 0 = the per-layer launches.
+void Net::plan_tail_chain() {
+    chain_first_ = -1;
+    in_chain_.assign(ops_.size(), 0);
+    const int mode = env_i("SSD_TAIL_FUSE", 3);      // (read per handle) bit 0: forward, bit 1: backward
+    chain_fwd_ = chain_bwd_ = false;
+    if (!bf16_ || (mode & 3) == 0) return;
+    const int n = (int)ops_.size();
+    for (int i = tail_first_ + 1; i < n; ++i) {
+        const Op& op = ops_[i];
+        if (op.kind != OP_CONV || op.head >= 0) continue;
+        const Tensor& in = tensors_[op.in];
+        if (op.KH == 1 && op.KW == 1 && in.H * in.W <= 100) { chain_first_ = i; break; }
+    }
+    if (chain_first_ < 0) return;
+    std::vector<char> produced(tensors_.size(), 0);
+    int count = 0;
+    for (int i = chain_first_; i < n; ++i) {
+        const Op& op = ops_[i];
+        if (op.kind != OP_CONV) continue;
+        const bool member = op.head < 0 ? true : produced[op.in] != 0;      // the extra layers; the heads that read one of them
+        if (!member) continue;
+        if (!tail_chain_stage_supported(conv_desc(op, 1)) || tensors_[op.in].data_f32) { count = -1; break; }
+        in_chain_[i] = 1;
+        if (op.head < 0) produced[op.out] = 1;
+        ++count;
+    }
+    if (count < 2 || count > tail_chain_max_stages() || count > conv_wgrad_group_bf16_max()) {
+        chain_first_ = -1;
+        in_chain_.assign(ops_.size(), 0);
+        return;
+    }
+    // the chain kernel reads its filters in fragment order (one contiguous KB per wave and k step): a third image of these few
+    // layers' filters, refreshed with the bf16 mirrors every forward pass
+    tail_fwd_off_.assign(ops_.size(), -1);
+    tail_bwd_off_.assign(ops_.size(), -1);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!in_chain_[i]) continue;
+        const ConvDesc d = conv_desc(ops_[i], 1);
+        tail_fwd_off_[i] = (long long)total;
+        total += tail_chain_packed_elems(d, false);
+        if (training_ && i != chain_first_) {
+            tail_bwd_off_[i] = (long long)total;
+            total += tail_chain_packed_elems(d, true);
+        }
+    }
+    wq_tail_ = (bf16_t*)dalloc(total * 2);
+    chain_fwd_ = (mode & 1) != 0;
+    chain_bwd_ = (mode & 2) != 0 && training_;
+}
+
+void Net::pack_tail_filters(hipStream_t s) {
+    std::vector<TailPackItem> items;
+    for (int i = 0; i < (int)ops_.size(); ++i) {
+        if (!in_chain_[i]) continue;
+        const ConvDesc d = conv_desc(ops_[i], 1);
+        items.push_back(TailPackItem{d, false, wq_oi_ + ops_[i].w_off, wq_tail_ + tail_fwd_off_[i]});
+        if (tail_bwd_off_[i] >= 0) items.push_back(TailPackItem{d, true, wq_io_ + ops_[i].w_off, wq_tail_ + tail_bwd_off_[i]});
+    }
+    tail_chain_pack_filters(items.data(), (int)items.size(), s);
+}
+
+void Net::launch_tail_forward(int b0, int nb, hipStream_t s) {
+    std::vector<TailStage> st;
+    for (const int oi : fwd_order_) {
+        if (!in_chain_[oi]) continue;
+        const Op& op = ops_[oi];
+        const Tensor& in = tensors_[op.in];
+        const Tensor& out = tensors_[op.out];
+        TailStage t{};
+        t.d = conv_desc(op, 1);
+        t.dgrad = false;
+        t.src = static_cast<const char*>(in.data) + (size_t)b0 * in.per_image() * 2;
+        t.wgt_packed = wq_tail_ + tail_fwd_off_[oi];
+        t.bias = params_ + op.b_off;
+        t.dst = static_cast<char*>(out.data) + (size_t)b0 * out.per_image() * (out.data_f32 ? 4 : 2);
+        t.relu = op.relu; t.accum = false; t.out_f32 = out.data_f32;
+        st.push_back(t);
+    }
+    prof_.layer = "tail";
+    tail_chain_bf16(st.data(), (int)st.size(), nb, "tail_fwd_bf16", s);
+}
+
+// The chain's part of backward (see plan_tail_chain): called when backward_step meets the chain's first op in its order.
+void Net::launch_tail_backward(int b, bool* side_used) {
+    const bool side = hstream_ && overlap_;
+    const int cls = side ? 1 : 0;
+    hipStream_t ds = cls == 1 ? hstream_ : stream_;
+    std::vector<TailStage> st;
+    std::vector<Tensor*> written;
+    Tensor* first_out = &tensors_[ops_[chain_first_].out];      // the gradient the first layer's own data gradient (a launch) reads
+    for (const int oi : bwd_order_) {
+        if (!in_chain_[oi] || oi == chain_first_) continue;
+        const Op& op = ops_[oi];
+        Tensor& in = tensors_[op.in];
+        const Tensor& out = tensors_[op.out];
+        bw_need(cls, out);                                      // (the loss gradient of the heads: main stream)
+        const bool last = in.done + 1 == in.consumers;
+        TailStage t{};
+        t.d = conv_desc(op, 1);
+        t.dgrad = true;
+        t.src = out.grad;
+        t.wgt_packed = wq_tail_ + tail_bwd_off_[oi];
+        t.mask = (last && in.relu_out) ? in.data : nullptr;
+        t.dst = in.grad;
+        t.accum = in.done > 0;
+        st.push_back(t);
+        in.done++;
+        if (std::find(written.begin(), written.end(), &in) == written.end()) written.push_back(&in);
+    }
+    prof_.layer = "tail";
+    const bool carry = stop_events_ && first_out->gev != nullptr;
+    g_stop_event = carry ? first_out->gev : nullptr;
+    {
+        struct Disarm { ~Disarm() { g_stop_event = nullptr; } } disarm;
+        tail_chain_bf16(st.data(), (int)st.size(), b, "tail_dgrad_bf16", ds);
+    }
+    for (Tensor* t : written) {      // one kernel wrote them all: the carried event (if any) stands for every one of them
+        t->gstream = cls;
+        t->gseq = ++bw_issued_[cls];
+        t->gev_set = false;
+    }
+    if (carry) first_out->gev_set = true;
+    // ---- the weight gradients of every layer of the chain, one launch behind the data gradients
+    const bool wside = wstream_ && overlap_;
+    hipStream_t ws = wside ? wstream_ : stream_;
+    if (wside || cls == 1) {
+        if (carry) {
+            HIP_OK(hipStreamWaitEvent(ws, first_out->gev, 0));
+        } else {
+            HIP_OK(hipEventRecord(ev_dy_, ds));
+            HIP_OK(hipStreamWaitEvent(ws, ev_dy_, 0));
+        }
+        if (!wside) bw_seen_[0][1] = bw_issued_[1];      // (the main stream has now waited for the side stream's chain)
+    }
+    std::vector<WgradGroupItem> items;
+    for (int oi = 0; oi < (int)ops_.size(); ++oi) {
+        if (!in_chain_[oi]) continue;
+        const Op& op = ops_[oi];
+        const Tensor& in = tensors_[op.in];
+        const Tensor& out = tensors_[op.out];
+        WgradGroupItem it{};
+        it.d = conv_desc(op, b);
+        it.x = in.h(); it.dy = out.gh();
+        it.dw = grads_ + op.w_off; it.dbias = grads_ + op.b_off; it.w = params_ + op.w_off;
+        items.push_back(it);
+        bw_conv_done_[oi] = 1;
+    }
+    conv_wgrad_group_bf16(items.data(), (int)items.size(), wd_, ws);
+    if (wside) *side_used = true;
+}
+
 void Net::pool_fusion(int* out, int cap, int* count) const {
     int k = 0;
     for (const Op& op : ops_)
@@ -557,6 +718,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
         HIP_OK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     }
     plan_pool_fusion();
+    plan_tail_chain();
     // Round 5: an event per gradient tensor (round 4: the small heads' feature maps only).  The data-gradient kernel that writes it
     // CARRIES the event (g_stop_event), and the weight-gradient stream / the other class wait for exactly that kernel: no event
     // packet between two data gradients on the main stream, none inside the side chain.  SSD_STOP_EVENTS=0: round 4's records.
@@ -653,6 +815,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         // the fp32 master itself); the first layer that reads a mirror waits for it
         prof_.layer = "filters";
         cast_filters(cast_plan_, params_, wq_io_, wq_oi_, side ? hstream_ : stream_);
+        if (chain_first_ >= 0) pack_tail_filters(side ? hstream_ : stream_);
         if (side) {
             HIP_OK(hipEventRecord(ev_cast_, hstream_));
             lane[0].cast_pending = lane[1].cast_pending = true;
@@ -691,6 +854,18 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         const Tensor& out = tensors_[op.out];
         prof_.layer = op.name.c_str();
         if (op_ablated(op.name, op.kind, op.head, op.k)) continue;
+        if (chain_fwd_ && in_chain_[op_index]) {      // Round 6 (plan_tail_chain): the chain's layers and heads run as ONE launch per lane, issued at its first op
+            if (op_index == chain_first_)
+                for (int li = 0; li < nl_cur; ++li) {
+                    Lane& ln = lane[li];
+                    if (ln.cast_pending) {
+                        HIP_OK(hipStreamWaitEvent(ln.s, ev_cast_, 0));
+                        ln.cast_pending = false;
+                    }
+                    launch_tail_forward(ln.b0, ln.nb, ln.s);
+                }
+            continue;
+        }
         if (nl_cur == 2 && merge_tail && heads_full && op_index == tail_first_) {
             HIP_OK(hipEventRecord(ev_join_, s2_));
             HIP_OK(hipStreamWaitEvent(stream_, ev_join_, 0));
@@ -880,6 +1055,7 @@ void Net::backward_begin(int b, const float* y) {
     bw_conv_done_.assign(ops_.size(), 0);
     bw_first_on_main_ = false;
     bw_first_fused_ = false;
+    bw_chain_done_ = false;
     bw_pos_ = 0;
     bw_b_ = b;
     bw_done_off_ = nfilters_;
@@ -905,6 +1081,18 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         const int cls = bw_class(op, op_index);
         hipStream_t ds = cls == 1 ? hstream_ : stream_;
         if (op_index == bw_defer_first_ && hstream_ && overlap_) bw_sync(0, 1);      // the main stream's big kernels start behind the chain
+        if (chain_bwd_ && in_chain_[op_index] && !op_ablated(op.name, op.kind, op.head, op.k)) {
+            // Round 6 (plan_tail_chain): the first chain op met issues the chain's data gradients (one launch) and every chain layer's
+            // weight gradient (one grouped launch); the other members are skipped when their turn comes -- all but the chain's first
+            // layer, whose data gradient is an ordinary launch below (its weight gradient came out of the group)
+            if (!bw_chain_done_) {
+                launch_tail_backward(b, &side_used);
+                bw_chain_done_ = true;
+                lo = bw_final_lo();
+                prof_.layer = op.name.c_str();
+            }
+            if (op_index != chain_first_) continue;
+        }
         if (op_ablated(op.name, op.kind, op.head, op.k)) {
             if (op.kind == OP_CONV) { bw_conv_done_[op_index] = 1; lo = bw_final_lo(); }
             in.done++;
@@ -938,7 +1126,8 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 bw_need(0, out);
                 if (on_main) bw_first_on_main_ = true;
             }
-            if (!(bw_first_fused_ && !need_dx)) launch_wgrad(op_index, b, ws);      // (conv1_1's came out of conv1_2's data gradient: below)
+            if (!(bw_first_fused_ && !need_dx) && !(chain_bwd_ && in_chain_[op_index] && bw_chain_done_))      // (conv1_1's came out of conv1_2's data gradient: below; the chain's first layer's out of the grouped launch)
+                launch_wgrad(op_index, b, ws);
             if (need_dx) {
                 bw_need(cls, out);
                 // Pool fusion (round 5): when this conv reads a recorded 2x2 pool's output, its data gradient routes every
@@ -1052,11 +1241,22 @@ std::vector<std::pair<size_t, size_t>> Net::backward_ranges(size_t min_floats) c
         return lo;
     };
     size_t hi = nfilters_, pos = 0;
+    bool chain_seen = false;
     while (pos < bwd_order_.size()) {
         size_t lo = hi;
         while (pos < bwd_order_.size() && hi - lo < min_floats) {      // exactly backward_step's loop
             const int i = bwd_order_[pos++];
             if (ops_[i].kind != OP_CONV) continue;
+            if (chain_bwd_ && in_chain_[i]) {      // the chain's layers finish together, when its first member is met (backward_step)
+                if (chain_seen && i != chain_first_) continue;
+                if (!chain_seen) {
+                    for (size_t j = 0; j < ops_.size(); ++j)
+                        if (in_chain_[j]) done[j] = 1;
+                    chain_seen = true;
+                    lo = final_lo();
+                    if (i != chain_first_) continue;
+                }
+            }
             done[i] = 1;
             lo = final_lo();
         }

@@ -74,6 +74,12 @@ CONV_CASES = [
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_bf16_fwd_dgrad_wgrad(case):
+    conv_case_check(case, chain=False)
+
+
+def conv_case_check(case, chain):
+    """One layer's three passes against the oracle.  chain: through the forms the step uses for the latency-bound tail (round 6:
+    one workgroup per image, csrc/tail_bf16.hip; the weight gradient with a single pixel split and the direct epilogue)."""
     name, b, hi, wi, ci, co, k, stride, dil, padding, relu, y_f32 = case
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     ph, pw, ho, wo = conv_geom(hi, wi, k, stride, dil, padding)
@@ -104,7 +110,9 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
 
     geom = (b, hi, wi, ci, ho, wo, co, k, k, stride, dil, ph, pw)
     y_ = torch.full((b, ho, wo, co), 9.0, dtype=torch.float32 if y_f32 else torch.bfloat16, device='cuda')
-    check(lib.ssd_op_conv2d_fwd_bf16(ptr(x_), ptr(woi_), ptr(b_), ptr(y_), int(y_f32), *geom, int(relu), None))
+    fwd = lib.ssd_op_conv2d_fwd_bf16_chain if chain else lib.ssd_op_conv2d_fwd_bf16
+    dgrad = lib.ssd_op_conv2d_dgrad_bf16_chain if chain else lib.ssd_op_conv2d_dgrad_bf16
+    check(fwd(ptr(x_), ptr(woi_), ptr(b_), ptr(y_), int(y_f32), *geom, int(relu), None))
     yr = y_ref.detach().permute(0, 2, 3, 1).numpy()
     e = max_rel(bhost(y_), yr)
     assert e < (TOL if y_f32 else TOL_BF), f'{name}: forward max-rel {e:.3e}'
@@ -118,19 +126,22 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     gdy_ = bdev(dy_pre)
     gw_ = torch.full((k, k, ci, co), 7.0, dtype=torch.float32, device='cuda')
     gb_ = torch.full((co,), 7.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wgrad_bf16(ptr(x_), ptr(gdy_), ptr(gw_), ptr(gb_), ptr(w_), wd, ptr(ws_), *geom, None))
+    if chain:
+        check(lib.ssd_op_conv2d_wgrad_bf16_direct(ptr(x_), ptr(gdy_), ptr(gw_), ptr(gb_), ptr(w_), wd, *geom, None))
+    else:
+        check(lib.ssd_op_conv2d_wgrad_bf16(ptr(x_), ptr(gdy_), ptr(gw_), ptr(gb_), ptr(w_), wd, ptr(ws_), *geom, None))
     e = max_rel(host(gw_), dw_ref + wd * w)
     assert e < TOL, f'{name}: wgrad max-rel {e:.3e}'
     e = max_rel(host(gb_), db_ref)
     assert e < TOL, f'{name}: bias-grad max-rel {e:.3e}'
 
     gx_ = torch.full((b, hi, wi, ci), 3.0, dtype=torch.bfloat16, device='cuda')
-    check(lib.ssd_op_conv2d_dgrad_bf16(ptr(gdy_), ptr(wio_), ptr(gx_), None, 0, *geom, None))
+    check(dgrad(ptr(gdy_), ptr(wio_), ptr(gx_), None, 0, *geom, None))
     e = max_rel(bhost(gx_), dx_ref)
     assert e < TOL_BF, f'{name}: dgrad max-rel {e:.3e}'
     prev = q(rng.normal(0, 1, x.shape))
     gx_ = bdev(prev)
-    check(lib.ssd_op_conv2d_dgrad_bf16(ptr(gdy_), ptr(wio_), ptr(gx_), ptr(x_), 1, *geom, None))
+    check(dgrad(ptr(gdy_), ptr(wio_), ptr(gx_), ptr(x_), 1, *geom, None))
     expect = (dx_ref + prev) * (x > 0)
     e = max_rel(bhost(gx_), expect)
     assert e < TOL_BF, f'{name}: dgrad accumulate+mask max-rel {e:.3e}'
