@@ -196,6 +196,7 @@ private:
     std::vector<long long> tail_fwd_off_, tail_bwd_off_; // ... element offsets per op of the forward / data-gradient form (-1: none)
     void pack_tail_filters(hipStream_t s);               // from the fresh bf16 mirrors, one launch (forward, behind cast_filters)
     bool chain_fwd_ = false, chain_bwd_ = false;      // SSD_TAIL_FUSE bit 0 / bit 1: the chain in forward / in backward
+    std::vector<char> in_wgroup_;        // ops whose weight gradient came out of this backward pass' grouped launch
     bool bw_chain_done_ = false;         // this backward pass has issued the chain's data gradients and grouped weight gradients
     void plan_tail_chain();
     void launch_tail_forward(int b0, int nb, hipStream_t s);

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
+#include <mutex>
 
 namespace ssd {
 
@@ -186,15 +188,23 @@ void Net::build_graph() {
 // to stderr whenever the set changes).  Tokens: pool, tail (conv8_2 ... conv11_2 and the small maps' heads), heads01, conv1,
 // conv5, l2norm, reduce (conv_igemm.hip).
 static std::string g_ablate;
+static std::mutex g_ablate_mu;                     // (set from one thread while another runs a step: the string is never read unlocked)
+static std::atomic<bool> g_ablate_on{false};       // the fast path of every launch site: one relaxed load
 void set_ablate(const char* tokens) {
+    std::lock_guard<std::mutex> lock(g_ablate_mu);
     g_ablate = tokens ? tokens : "";
+    g_ablate_on.store(!g_ablate.empty(), std::memory_order_release);
     if (!g_ablate.empty())
         fprintf(stderr, "[ssdvgg_hip] WARNING: ablation '%s' is active: the step SKIPS launches, every result is WRONG (timing aid only)\n",
                 g_ablate.c_str());
 }
-bool ablated(const char* token) { return !g_ablate.empty() && g_ablate.find(token) != std::string::npos; }
+bool ablated(const char* token) {
+    if (!g_ablate_on.load(std::memory_order_acquire)) return false;
+    std::lock_guard<std::mutex> lock(g_ablate_mu);
+    return g_ablate.find(token) != std::string::npos;
+}
 static bool op_ablated(const std::string& name, int kind, int head, int k) {
-    if (g_ablate.empty()) return false;
+    if (!g_ablate_on.load(std::memory_order_acquire)) return false;
     if (kind == 1) return k == 2 && ablated("pool");
     if (kind == 2) return ablated("l2norm");
     if (head >= 2) return ablated("tail");
@@ -498,7 +508,10 @@ void Net::launch_tail_backward(int b, bool* side_used) {
         }
         if (!wside) bw_seen_[0][1] = bw_issued_[1];      // (the main stream has now waited for the side stream's chain)
     }
+    // (the chain's first layer, on the 10x10 map -- 3200 pixels at batch 32 -- would be the group's straggler with its single pixel
+    // split: 50 iterations on 8 workgroups; it keeps its own launch and slab reduce, issued when its turn comes)
     std::vector<WgradGroupItem> items;
+    in_wgroup_.assign(ops_.size(), 0);
     for (int oi = 0; oi < (int)ops_.size(); ++oi) {
         if (!in_chain_[oi]) continue;
         const Op& op = ops_[oi];
@@ -506,6 +519,8 @@ void Net::launch_tail_backward(int b, bool* side_used) {
         const Tensor& out = tensors_[op.out];
         WgradGroupItem it{};
         it.d = conv_desc(op, b);
+        if (oi == chain_first_) continue;      // (whatever the batch: backward_ranges, which knows no batch, mirrors this)
+        in_wgroup_[oi] = 1;
         it.x = in.h(); it.dy = out.gh();
         it.dw = grads_ + op.w_off; it.dbias = grads_ + op.b_off; it.w = params_ + op.w_off;
         items.push_back(it);
@@ -1056,6 +1071,7 @@ void Net::backward_begin(int b, const float* y) {
     bw_first_on_main_ = false;
     bw_first_fused_ = false;
     bw_chain_done_ = false;
+    in_wgroup_.assign(ops_.size(), 0);
     bw_pos_ = 0;
     bw_b_ = b;
     bw_done_off_ = nfilters_;
@@ -1126,7 +1142,7 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 bw_need(0, out);
                 if (on_main) bw_first_on_main_ = true;
             }
-            if (!(bw_first_fused_ && !need_dx) && !(chain_bwd_ && in_chain_[op_index] && bw_chain_done_))      // (conv1_1's came out of conv1_2's data gradient: below; the chain's first layer's out of the grouped launch)
+            if (!(bw_first_fused_ && !need_dx) && !(chain_bwd_ && bw_chain_done_ && in_wgroup_[op_index]))      // (conv1_1's came out of conv1_2's data gradient: below; the chain's first layer's out of the grouped launch)
                 launch_wgrad(op_index, b, ws);
             if (need_dx) {
                 bw_need(cls, out);
@@ -1251,7 +1267,7 @@ std::vector<std::pair<size_t, size_t>> Net::backward_ranges(size_t min_floats) c
                 if (chain_seen && i != chain_first_) continue;
                 if (!chain_seen) {
                     for (size_t j = 0; j < ops_.size(); ++j)
-                        if (in_chain_[j]) done[j] = 1;
+                        if (in_chain_[j] && (int)j != chain_first_) done[j] = 1;
                     chain_seen = true;
                     lo = final_lo();
                     if (i != chain_first_) continue;

@@ -33,8 +33,14 @@ def bench_inputs(pname, b, seed=1234):
     return preset, x, y
 
 
-def oracle_forward_chunked(m, x, y, chunk=4):
-    """result and the four losses at batch b from chunks (the loss is a mean of per-sample terms)."""
+_ORACLE_FWD = {}      # (preset, batch) -> (result, losses): the fp32 oracle's forward pass at the benchmarked batch costs the CPU 15-20 s
+
+
+def oracle_forward_chunked(m, x, y, chunk=4, key=None):
+    """result and the four losses at batch b from chunks (the loss is a mean of per-sample terms).  key: cache the pass for the other
+    tests of this module that evaluate the same model on the same inputs (seed-42 weights, bench.py's batch)."""
+    if key is not None and key in _ORACLE_FWD:
+        return _ORACLE_FWD[key]
     b = x.shape[0]
     res, L = [], {'localization': 0.0, 'confidence': 0.0}
     for i0 in range(0, b, chunk):
@@ -45,7 +51,10 @@ def oracle_forward_chunked(m, x, y, chunk=4):
             L[k] += Lc[k] * n / b
         L['l2'] = Lc['l2']
     L['total'] = L['localization'] + L['confidence'] + L['l2']
-    return np.concatenate(res), L
+    out = (np.concatenate(res), L)
+    if key is not None:
+        _ORACLE_FWD[key] = out
+    return out
 
 
 BENCH_LAYERS = {'vgg300': ['conv1_2', 'conv2_2', 'conv3_2', 'conv4_2', 'mod_conv6', 'heads/map0', 'heads/map1', 'conv8_2', 'pool1', 'mod_pool5'],
@@ -67,7 +76,7 @@ def test_benchmarked_batch_forward_loss_and_layer_local_backward(pname, b):
     net.forward_dev(xt, yt)
     L = net.get_losses()
     r = net._dev_result(b, True)
-    r_ref, L_ref = oracle_forward_chunked(m, x, y)
+    r_ref, L_ref = oracle_forward_chunked(m, x, y, key=(pname, b))
     assert report(f'{pname} b={b} result', max_rel(r, r_ref)) < TOL
     for k in L_ref:
         assert abs(L[k] - L_ref[k]) < TOL * abs(L_ref[k]), (k, L[k], L_ref[k])
@@ -115,12 +124,64 @@ def test_benchmarked_batch_bf16_layer_local(pname, b):
     sm = torch.softmax(torch.from_numpy(out_gpu[..., :21]), -1).numpy()
     assert max_rel(r[..., :21], sm) < TOL and np.array_equal(r[..., 21:], out_gpu[..., 21:])
     # distance to the fp32 oracle at this batch (what bench.py's step-0 guard looks at), reported
-    _, L_ref = oracle_forward_chunked(m, x, y)
+    _, L_ref = oracle_forward_chunked(m, x, y, key=(pname, b))
     print('    bf16 vs fp32 oracle losses', {k: (round(L[k], 5), round(float(L_ref[k]), 5)) for k in L})
     net.forward_backward_dev(xt, yt)
     torch.cuda.synchronize()
     worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y, wq=qt, tol_dout=TOL_BF, only=layers)
     print('    worst layer-local weight-gradient error', worst_w, ' data-gradient error', worst_x)
+    assert worst_w < TOL and worst_x < TOL_BF2
+    sess.close()
+
+
+def test_default_handle_bf16_against_the_oracle():
+    """The handle bench.py times (defaults: pools fused into their neighbours, conv1_1's weight gradient inside conv1_2's data
+    gradient, the tail as one launch per direction) against the oracle directly, not through its bit-identity with the unfused
+    handle: (1) conv1_1's filter / bias gradient -- the one gradient the default bf16 step computes in another summation order
+    (csrc/conv_bf16.hip conv_gather_bf16_c64_kernel<MODE_DGRAD, FIRSTW>) -- recomputed from the GPU's own d(conv1_2 pre-activation),
+    conv1_1 output and image with the product's roundings (bf16 filter, bf16 dx): 1e-3; (2) layer_local_backward_check on the
+    tensors a default handle materialises, incl. layers of the tail chain (ssdvgg.py:195-207, 300-332)."""
+    from test_gpu_bf16 import qt, TOL_BF, TOL_BF2
+    from test_gpu_model import nchw
+    import torch.nn.functional as F
+    pname, b = 'vgg300', 32
+    preset, x, y = bench_inputs(pname, b)
+    w = ref.init_params(preset, 20, seed=42, alive=True)
+    m = ref.RefModel(pname, params=w)
+    sess = Session(0)
+    net = SSDVGG(sess, pname)
+    net.build_from_vgg(None, 20, max_batch=b, weights=w, dtype='bf16')
+    net.build_optimizer(learning_rate=0.00075, weight_decay=WD, momentum=0.9)
+    assert net.pool_fusion()[:2] == [(True, True), (True, True)], 'this test is about the DEFAULT (fused) handle'
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    net.forward_backward_dev(xt, yt)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='not materialised'):
+        net.activation('grad:conv1_1', b)          # the fused path ran: conv1_1's output gradient never existed
+    g = net.save_gradients()
+    # (1) dx = conv1_2^T(dy) masked by conv1_1's relu, ONE rounding to bf16 (the operand of the weight-gradient MFMAs), then conv1_1's
+    # weight gradient from the image; in chunks of 4 images
+    dy = net.activation('grad:conv1_2', b)
+    a1 = net.activation('conv1_1', b)
+    w12 = qt(m.params['conv1_2/filter'].detach())
+    w11 = m.params['conv1_1/filter'].detach()
+    dw = torch.zeros_like(w11); db = torch.zeros(64)
+    for i0 in range(0, b, 4):
+        a = nchw(a1[i0:i0 + 4]).clone().requires_grad_(True)
+        ref.conv2d_tf(a, w12, 1, 'SAME', 1).backward(nchw(dy[i0:i0 + 4]))
+        dx = qt(a.grad * (a.detach() > 0).float())
+        wv = qt(w11).clone().requires_grad_(True)
+        bias = torch.zeros(64, requires_grad=True)
+        (ref.conv2d_tf(nchw(x[i0:i0 + 4]), wv, 1, 'SAME', 1) + bias.view(1, -1, 1, 1)).backward(dx)
+        dw += wv.grad; db += bias.grad
+    e_w = rel_err(g['conv1_1/filter'], dw.numpy() + WD * w11.numpy())
+    e_b = rel_err(g['conv1_1/biases'], db.numpy())
+    print(f'    default handle, conv1_1 weight gradient inside conv1_2 data gradient vs the oracle: filter {e_w:.2e}, biases {e_b:.2e}')
+    assert e_w < TOL and e_b < TOL
+    # (2) what a default handle materialises
+    layers = ['conv4_2', 'mod_conv6', 'heads/map0', 'heads/map2', 'conv8_2', 'conv9_2', 'conv10_1', 'conv10_2', 'heads/map3', 'heads/map4', 'l2_norm_conv4_3']
+    worst_w, worst_x = layer_local_backward_check(net, m, preset, b, x, y, wq=qt, tol_dout=TOL_BF, only=layers)
+    print('    default handle: worst layer-local weight-gradient error', worst_w, ' data-gradient error', worst_x)
     assert worst_w < TOL and worst_x < TOL_BF2
     sess.close()
 

@@ -92,33 +92,41 @@ def test_augmented_shapes_training_makes_progress(tmp_path):
 
 
 def test_first_training_steps_track_the_oracle_on_shapes():
-    """fp32, batch 4, momentum 0.9, lr 1e-4: the HIP losses against oracle.RefModel.train_step on the same batches, nine
-    optimizer steps in a row (twelve through round 4: the CPU oracle is 4 - 7 s per step on the pool's slower hosts).  The two trajectories are separate computations of a chaotic system (tests/test_gpu_model.py
-    header: a relu mask or pool argmax flips wherever two fp32 values agree to ~1e-6), so the agreement decays with the step
-    count -- measured 1e-7, 9e-6, 8e-5, 5e-4, 8e-4, 8e-4, then 7e-4 .. 7e-3 (at lr 1e-3, where the loss itself jumps 22 -> 60 ->
-    21 in the first three steps, 5e-2 by step 3).  Asserted: 1e-3 on every loss for the first six steps, 1e-2 for all nine."""
+    """fp32, batch 4, momentum 0.9, lr 1e-4: the HIP losses against oracle.RefModel.train_step on the same batches, optimizer step
+    after optimizer step.  The two trajectories are separate computations of a chaotic system (tests/test_gpu_model.py header: a
+    relu mask, a pool argmax or a hard-negative pick flips wherever two fp32 values agree to ~1e-6), so the agreement decays with
+    the step count and HOW fast depends on the batches: on round 4's data set 1e-7, 9e-6, 8e-5, 5e-4, 8e-4, 8e-4 for steps 0-5, on
+    another 7.7e-3 by step 5 (one mined negative swapped; profiles/r05_zz_gpu_tests.log).  A bound tuned on one set proves that set,
+    so the claim is asserted as a distribution: THREE data sets and weight seeds, four optimizer steps each (twelve oracle steps in
+    all, 3-7 s each on the pool's hosts) -- every set within 1e-3 for steps 0-2 (measured <= 1e-4 there), every set within 1e-2 at
+    step 3, and the median of the three within 2e-3 at step 3.  SSD_TEST_TRACK_STEPS lengthens the runs (no bound past step 3 but
+    3e-2)."""
     import os
-    b, steps, exact = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 9)), 6
+    b, steps = 4, int(os.environ.get('SSD_TEST_TRACK_STEPS', 4))
     preset = ob.get_preset('vgg300')
-    td = TrainingData('shapes', 'vgg300', num_train=b * 12, num_valid=b, seed=5, device_tensors=False)      # (the set the bounds were measured on: its first `steps` batches)
-    w = ref.init_params(preset, 20, seed=11, alive=True)
-    m = ref.RefModel('vgg300', params=w)
     lr = LearningRate([float(os.environ.get('SSD_TEST_TRACK_LR', 1e-4))], [])
-    m.set_optimizer(lr.values, lr.boundaries, 0.9, 0.0005)
-    errs = []
-    with Session(0) as sess:
-        net = SSDVGG(sess, 'vgg300')
-        net.build_from_vgg(None, 20, max_batch=b, weights=w)
-        net.build_optimizer(learning_rate=lr, weight_decay=0.0005, momentum=0.9)
-        for k, (x, y, gt) in enumerate(td.train_generator(b)):
-            if k >= steps:
-                break
-            x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
-            _, L_ref = m.train_step(x, y)
-            L, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
-            e = max(abs(L[n] - L_ref[n]) / abs(L_ref[n]) for n in ('total', 'localization', 'confidence', 'l2'))
-            errs.append(e)
-            print(f'    step {k}: total {L["total"]:.5f} (oracle {L_ref["total"]:.5f}), worst relative loss error {e:.2e}')
-    assert len(errs) == steps
-    assert max(errs[:exact]) < 1e-3
-    assert max(errs) < 1e-2
+    table = []
+    for data_seed, weight_seed in ((5, 11), (6, 12), (7, 13)):
+        td = TrainingData('shapes', 'vgg300', num_train=b * steps, num_valid=b, seed=data_seed, device_tensors=False)
+        w = ref.init_params(preset, 20, seed=weight_seed, alive=True)
+        m = ref.RefModel('vgg300', params=w)
+        m.set_optimizer(lr.values, lr.boundaries, 0.9, 0.0005)
+        errs = []
+        with Session(0) as sess:
+            net = SSDVGG(sess, 'vgg300')
+            net.build_from_vgg(None, 20, max_batch=b, weights=w)
+            net.build_optimizer(learning_rate=lr, weight_decay=0.0005, momentum=0.9)
+            for k, (x, y, gt) in enumerate(td.train_generator(b)):
+                if k >= steps:
+                    break
+                x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+                _, L_ref = m.train_step(x, y)
+                L, _ = sess.run([net.losses, net.optimizer], feed_dict={net.image_input: x, net.labels: y})
+                errs.append(max(abs(L[n] - L_ref[n]) / abs(L_ref[n]) for n in ('total', 'localization', 'confidence', 'l2')))
+        assert len(errs) == steps
+        print(f'    data set {data_seed}, weights {weight_seed}: worst relative loss error per step', ' '.join(f'{e:.1e}' for e in errs))
+        table.append(errs)
+    t = np.array(table)
+    assert t[:, :3].max() < 1e-3, 'steps 0-2 must agree to 1e-3 on every data set'
+    assert t[:, 3].max() < 1e-2 and np.median(t[:, 3]) < 2e-3, 'step 3: every set within 1e-2, the median within 2e-3'
+    assert t.max() < 3e-2

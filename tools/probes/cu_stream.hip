@@ -64,5 +64,22 @@ int main() {
             }
         }
     }
+    // does an XCD's L2 keep the span across a kernel boundary?  one pass per launch, three launches back to back after one sweep
+    for (unsigned span : {590u * 1024u, 3700u * 1024u}) {
+        for (int grid : {32, 256}) {
+            hipLaunchKernelGGL(sweep_kernel, dim3(2048), dim3(256), 0, 0, big, BIG / 4, sink);
+            printf("span %5u KB  grid %3d  one pass per LAUNCH:", span / 1024, grid);
+            for (int l = 0; l < 3; ++l) {
+                hipLaunchKernelGGL(stream_kernel<8>, dim3(grid), dim3(1024), 0, 0, src, span, 1, ticks, sink);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(h.data(), ticks, grid * 8, hipMemcpyDeviceToHost));
+                unsigned long long mx = 0;
+                for (int g = 0; g < grid; ++g) mx = h[g] > mx ? h[g] : mx;
+                printf("  launch %d: %.1f us (%.0f GB/s/CU)", l, mx / 100.0, span / (mx / 100.0) / 1e3);
+            }
+            printf("\n");
+        }
+    }
+    // ... and when the FIRST launch is a 256-workgroup toucher (one load per 128-byte line) and the second the 32 streaming workgroups?
     return 0;
 }
