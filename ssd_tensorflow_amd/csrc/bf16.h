@@ -16,8 +16,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-// two floats -> one dword (lo = a, hi = b)
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+// two floats -> one dword (lo = a, hi = b): ONE v_cvt_pk_bf16_f32 (the scalar form compiles to two of them plus and / shift / or)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 __device__ __forceinline__ float lo2f(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float hi2f(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
 

@@ -230,17 +230,27 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgsH& p, unsigned c
                 const bool okq[4] = {true, 2 * ow + 1 < p.UW, 2 * oh + 1 < p.UH, 2 * ow + 1 < p.UW && 2 * oh + 1 < p.UH};
                 const unsigned rw = pre_rec[ps];
                 bf16_t* d0 = reinterpret_cast<bf16_t*>(p.dst) + ((size_t)(b * p.UH + 2 * oh) * p.UW + 2 * ow) * p.DN + n;
+                // Rounded ONCE, then routed as packed pairs: an entry re = sign << 2 | cell becomes a one-hot nibble over the four
+                // cells (0 when the maximum was not positive) through a 32-bit table, a pair's two nibbles sit 16 bits apart, and
+                // cell q's store mask of the pair is (bit q, bit 16 + q) x 0xFFFF -- four VALU operations per pair and cell where
+                // eight selects on floats + a conversion per cell cost ~13 (the 256 x 64 tile of conv2_1 spent more issue slots
+                // in this epilogue than in its 18 k steps: profiles/r06_b_tail_chain_v1_per_layer_bf16.txt, 572 TFLOP/s).
+                unsigned pk[4], oh2[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    pk[e2] = pack2(v[2 * e2], v[2 * e2 + 1]);
+                    const int s0 = 16 * (e2 / 2) + 6 * (e2 & 1), s1 = s0 + 3;      // bit offsets of the pair's two entries
+                    const unsigned i0 = s0 >= 2 ? (rw >> (s0 - 2)) & 0x1Cu : (rw << 2) & 0x1Cu;      // 4 x entry
+                    const unsigned i1 = (rw >> (s1 - 2)) & 0x1Cu;
+                    oh2[e2] = ((0x84210000u >> i0) & 0xFu) | ((0x84210000u >> i1) << 16);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!okq[q]) continue;
-                    float g[8];
+                    u32x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const unsigned re = (rw >> (16 * (e / 4) + 3 * (e & 3))) & 7u;
-                        g[e] = ((re & 3u) == (unsigned)q && (re & 4u)) ? v[e] : 0.f;
-                    }
-                    *reinterpret_cast<u32x4*>(d0 + ((size_t)(q >> 1) * p.UW + (q & 1)) * p.DN) =
-                        u32x4{pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7])};
+                    for (int e2 = 0; e2 < 4; ++e2) o4[e2] = pk[e2] & (((oh2[e2] >> q) & 0x00010001u) * 0xFFFFu);
+                    *reinterpret_cast<u32x4*>(d0 + ((size_t)(q >> 1) * p.UW + (q & 1)) * p.DN) = o4;
                 }
                 continue;
             }
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void conv_gather_bf16_kernel
 template <int MODE, int TM, int TN = 2>
 __global__ __launch_bounds__(256) void conv_gather_bf16_rows_kernel(GatherArgsH p, int dil) {
     constexpr int WM = 2, WN = 2, BM = 64 * TM, BN = 32 * TN * WN;
-    static_assert(TN == 2 || (TN == 1 && TM == 2), "128-wide tiles, or 128 x 64");
+    static_assert(TN == 2 || TN == 1, "128- or 64-wide tiles");
     constexpr int AROWS = TM == 2 ? 160 : 256;         // 128 + 2 * dil rows in whole 32-row staging passes | 256 rows = 253 + 2 (dil = 1) + 1 empty
     constexpr int A_N = AROWS / 32, B_N = BN / 32;
     constexpr int ZROW = (AROWS - 1) * 128;            // a tile row that is always zero (past the halo)
@@ -2648,6 +2658,16 @@ static void conv_dgrad_bf16_any(const ConvDesc& d, const bf16_t* dy, const bf16_
     }
     if (!unpool && gather_c64_applicable(d, false)) {      // (the persistent 64 -> 64 kernel has its own write-out: no un-pool there)
         launch_gather_c64<MODE_DGRAD>(a, "conv_dgrad_bf16_c64", fl, by, s);
+        return;
+    }
+    // 64-channel data gradients (conv2_1: 128 -> 64) on the kernel-row gather, 128 x 64 tiles: the per-tap 256 x 64 tile stages
+    // 40 KB per 8 MFMAs per wave (52 FLOP per staged byte -- more than a CU's L2 -> LDS path feeds), a kernel row 44 KB per 24
+    // (71).  conv2_1 with the fused un-pool 0.180 -> 0.160 ms; 256 x 64 kernel-row tiles 0.185 (two workgroups per CU instead of
+    // three).  profiles/r06_y_*.  SSD_DGRAD_ROWS_C64: 0 per-tap, 1 (default) 128 x 64, 2 256 x 64.
+    static const int rows_c64 = env_int("SSD_DGRAD_ROWS_C64", 1);
+    if (gather_rows_applicable(d, true) && d.Ci == 64 && rows_c64) {
+        if (rows_c64 == 2 && d.dil == 1) launch_gather_rows<MODE_DGRAD, 4, 1>(a, d.dil, unpool ? "conv_dgrad_unpool_bf16_rows_256x64" : "conv_dgrad_bf16_rows_256x64", fl, by, s);
+        else launch_gather_rows<MODE_DGRAD, 2, 1>(a, d.dil, unpool ? "conv_dgrad_unpool_bf16_rows_128x64" : "conv_dgrad_bf16_rows_128x64", fl, by, s);
         return;
     }
     if (gather_rows_applicable(d, true) && d.Ci >= 128) {

@@ -1,22 +1,11 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06u
-O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12 -s > "$O/pytest_all.log" 2>&1
-echo "rc=$?" >> "$O/pytest_all.log"
-grep -v amdgpu.ids "$O/pytest_all.log" | grep -E "passed|failed|FAILED|rc=|data set|default handle|chain vs|s call" | tail -40
-timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.stderr"; echo "bench rc=$?"
-python - "$O/bench.json" <<'PY'
-import json, sys
-try:
-    d = json.load(open(sys.argv[1]))
-except Exception as e:
-    print('no bench line:', e); sys.exit(0)
-print('HEADLINE', d['value'], d['unit'], d['ms_per_step'], 'ms', 'roofline', d['roofline'] and (d['roofline']['kernel'], d['roofline']['frac']))
-for k in ('bf16', 'vgg512_b16', 'vgg512_b16_bf16', 'infer_b128', 'infer_b128_bf16', 'decode_b128', 'train_e2e', 'train_e2e_bf16'):
-    s = d.get(k)
-    if s:
-        print(k, s.get('value'), s.get('ms_per_step'), s.get('error'))
-print('cpu', d.get('cpu_baseline'))
-PY
+TAG=r06aa
+O=$R/gpurun_out/$TAG; mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o e -- \
+    python "$R/bench.py" --mode train_e2e --dtype bf16 --e2e-workers 8 --e2e-serial-steps 0 > "$O/e2e_under_rocprof.json" 2>/dev/null
+cp /tmp/pe/e_kernel_stats.csv "$O/rocprofv3_kernel_stats_e2e_bf16.csv"
+head -30 "$O/rocprofv3_kernel_stats_e2e_bf16.csv" | cut -c1-200
+tail -c 600 "$O/e2e_under_rocprof.json"
