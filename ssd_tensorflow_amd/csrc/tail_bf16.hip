@@ -208,22 +208,6 @@ __global__ __launch_bounds__(256) void tail_pack_kernel(TailPackK t) {
     *reinterpret_cast<u32x4*>(L.out + (size_t)frag * 512 + lane * 8) = v;
 }
 
-// Every XCD reads every stage's packed filter once (one dword per 128-byte line, its own workgroups each a slice): launched ahead of
-// the chain kernel, it leaves the filters in all eight L2s (they survive the kernel boundary: profiles/r06_p_cu_stream_launches.txt).
-__global__ __launch_bounds__(256) void tail_prefetch_kernel(const TailStageK* __restrict__ tab_, int nstages, int* sink) {
-    const auto tab = TAIL_CONST(tab_);
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = ((int)gridDim.x - xcd + 7) >> 3;
-    unsigned fold = 0;
-    for (int s = 0; s < nstages; ++s) {
-        const unsigned lines = (unsigned)(cdiv_dev(tab[s].DN, 16) * tab[s].ngroups) * 32u;
-        const unsigned per = (lines + nslots - 1) / nslots;
-        const unsigned l0 = slot * per, l1 = min(lines, l0 + per);
-        const unsigned* w = reinterpret_cast<const unsigned*>(tab[s].wgt);
-        for (unsigned l = l0 + threadIdx.x; l < l1; l += 256) fold ^= w[(size_t)l * 32];
-    }
-    if (fold == 0x9E3779B9u && nstages < 0) sink[0] = (int)fold;      // (never: keeps the loads)
-}
-
 __global__ __launch_bounds__(TAIL_THREADS) void tail_chain_bf16_kernel(const TailStageK* __restrict__ tab_, int nstages, int nimg, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const auto tab = TAIL_CONST(tab_);
@@ -689,8 +673,8 @@ void tail_chain_bf16(const TailStage* stages, int nstages, int nimg, const char*
         HIP_OK(hipMemsetAsync(stamps_dev, 0, STAMP_WORDS * 8, s));
     }
     static const int helpers = env_int("SSD_TAIL_HELPERS", 64);      // A/B switch: 0 = no L2 warm-up workgroups
-    static const int prefetch = env_int("SSD_TAIL_PREFETCH", 0);     // experiment: a prefetch launch right in front of the chain
-    if (prefetch) hipLaunchKernelGGL(tail_prefetch_kernel, dim3(prefetch), dim3(256), 0, s, tab_dev, nstages, (int*)nullptr);
+    // (a separate prefetch LAUNCH in front of the chain -- every XCD reads every packed filter once -- measured like the helper
+    // workgroups, 75 vs 75 us forward, and is gone: profiles/r06_q_tail_chain_prefetch_bf16.txt)
     SSD_LAUNCH_STOP(tail_chain_bf16_kernel, dim3(nimg + (helpers > 0 ? helpers : 0)), dim3(TAIL_THREADS), (size_t)lds_total, s, tab_dev, nstages, nimg,
                     stamps_on ? stamps_dev : nullptr);
     HIP_OK(hipGetLastError());
