@@ -213,6 +213,7 @@ __device__ static void photometric_step(int kind, float val, int row, float* px)
 }
 
 // the whole chain: brightness -> distort chain -> channel reorder (the reference's recipe order) -> the extra steps of a second pass
+// (round 6: an extra step's Hue / Saturation rows are rows of the array the step was handed -- source row extra_r0[i] is its row 0)
 __device__ static void photometric(const ssd_augment_params& p, int row, float* px) {
     if (p.brightness_on) photometric_step(3, (float)p.brightness_delta, row, px);
     for (int i = 0; i < p.n_distort; ++i) photometric_step(p.distort_kind[i], p.distort_val[i], row, px);
@@ -220,7 +221,14 @@ __device__ static void photometric(const ssd_augment_params& p, int row, float* 
         const float q[3] = {px[0], px[1], px[2]};
         for (int c = 0; c < 3; ++c) px[c] = p.reorder[c] == 0 ? q[0] : (p.reorder[c] == 1 ? q[1] : q[2]);
     }
-    for (int i = 0; i < p.n_extra; ++i) photometric_step(p.extra_kind[i], p.extra_val[i], row, px);
+    for (int i = 0; i < p.n_extra; ++i) photometric_step(p.extra_kind[i], p.extra_val[i], row - p.extra_r0[i], px);
+}
+// a canvas pixel (ExpandTransform's mean value) at source-frame row `row`: the steps taken behind the expand
+__device__ static void photometric_fill(const ssd_augment_params& p, int row, double* px) {
+    if (p.fill_from >= p.n_extra) return;
+    float f[3] = {(float)px[0], (float)px[1], (float)px[2]};      // (astype(float32) of the float64 canvas, transforms.py:168,182)
+    for (int i = p.fill_from; i < p.n_extra; ++i) photometric_step(p.extra_kind[i], p.extra_val[i], row - p.extra_r0[i], f);
+    for (int c = 0; c < 3; ++c) px[c] = (double)f[c];
 }
 
 // Pass 0 (round 3): the photometric chain depends on the SOURCE pixel only, yet the gather evaluated it per tap -- up to 64
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
     const bool from_pre = aug_uses_pre(p);                 // the chain has been applied by pass 0
     const bool per_tap = aug_has_photometric(p) && !from_pre;
     const unsigned char* src = from_pre ? pre + (size_t)img * AUG_PRE_BYTES : images + p.src_off;
-    const double mean[3] = {104.0, 117.0, 123.0};
+    const bool fill_steps = p.fill_from < p.n_extra;
     double acc[3] = {0, 0, 0};
     for (int j = 0; j < ny; ++j) {
         const int sy = yi[(size_t)j * pitch] + p.crop_y0;                  // row in the (expanded) frame
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
             sx += p.crop_x0;
             const double wx = xw[(size_t)i * pitch];
             const int y0 = sy - p.exp_hoff, x0 = sx - p.exp_woff;         // position in the loaded image (offsets are 0 when not expanded)
-            float px[3];
-            if ((unsigned)y0 < (unsigned)p.src_h && (unsigned)x0 < (unsigned)p.src_w) {
+            double px[3];
+            if ((unsigned)(y0 - p.clip_y0) < (unsigned)(p.clip_y1 - p.clip_y0) && (unsigned)(x0 - p.clip_x0) < (unsigned)(p.clip_x1 - p.clip_x0)) {
                 const unsigned char* q = src + ((size_t)y0 * p.src_w + x0) * 3;
                 // one (unaligned) dword instead of three byte loads -- except for the image's very last pixel, whose fourth
                 // byte may lie outside the caller's buffer
@@ -300,21 +308,27 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
                 if (per_tap || from_pre) { px[0] = raw[0]; px[1] = raw[1]; px[2] = raw[2]; }
                 else for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
             } else {
-                for (int c = 0; c < 3; ++c) px[c] = (float)mean[c];
+                for (int c = 0; c < 3; ++c) px[c] = p.mean[c];
+                if (fill_steps) photometric_fill(p, y0, px);
             }
-            for (int c = 0; c < 3; ++c) rowacc[c] += wx * (double)px[c];
+            for (int c = 0; c < 3; ++c) rowacc[c] += wx * px[c];
         }
         for (int c = 0; c < 3; ++c) acc[c] += wy * rowacc[c];
     }
-    float* o = out + gid * 3;
+    float res[3];
     for (int c = 0; c < 3; ++c) {
         double v = acc[c];
-        if (!p.expand_on) {                   // the image is still uint8 in the reference: cv2.resize saturates to uint8
+        if (!p.is_float) {                    // the image is still uint8 in the reference: cv2.resize saturates to uint8
             v = floor(v + 0.5);
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
-        o[c] = (float)v;
+        res[c] = (float)v;
     }
+    // steps behind ResizeTransform act on the resized array (its rows 0 / 1), a flip behind it mirrors the output columns
+    for (int i = 0; i < p.n_post; ++i) photometric_step(p.post_kind[i], p.post_val[i], oy, res);
+    const size_t og = p.out_flip ? gid - ox + (out_w - 1 - ox) : gid;
+    float* o = out + og * 3;
+    for (int c = 0; c < 3; ++c) o[c] = res[c];
 }
 
 size_t augment_ws_bytes(int b, int out_w, int out_h) {
@@ -331,7 +345,12 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
         SSD_REQUIRE(p.src_w >= 1 && p.src_h >= 1 && p.crop_w >= 1 && p.crop_h >= 1, "augment: image %d has an empty source or crop window", i);
         SSD_REQUIRE(p.resize_alg >= 0 && p.resize_alg <= 4, "augment: image %d: unknown resize algorithm %d", i, p.resize_alg);
         SSD_REQUIRE(p.n_distort >= 0 && p.n_distort <= 3, "augment: image %d: distort chain length %d", i, p.n_distort);
-        SSD_REQUIRE(p.n_extra >= 0 && p.n_extra <= 8, "augment: image %d: %d extra photometric steps", i, p.n_extra);
+        SSD_REQUIRE(p.n_extra >= 0 && p.n_extra <= 16, "augment: image %d: %d extra photometric steps", i, p.n_extra);
+        SSD_REQUIRE(p.n_post >= 0 && p.n_post <= 4, "augment: image %d: %d steps behind the resize", i, p.n_post);
+        for (int k = 0; k < p.n_post; ++k) SSD_REQUIRE(p.post_kind[k] >= 0 && p.post_kind[k] <= 4, "augment: image %d: post step kind %d", i, p.post_kind[k]);
+        SSD_REQUIRE(p.fill_from >= 0 && p.fill_from <= p.n_extra, "augment: image %d: fill_from %d of %d extra steps", i, p.fill_from, p.n_extra);
+        SSD_REQUIRE(p.clip_x0 >= 0 && p.clip_y0 >= 0 && p.clip_x1 <= p.src_w && p.clip_y1 <= p.src_h && p.clip_x0 <= p.clip_x1 && p.clip_y0 <= p.clip_y1,
+                    "augment: image %d: visible window %d..%d x %d..%d outside the %d x %d image", i, p.clip_x0, p.clip_x1, p.clip_y0, p.clip_y1, p.src_w, p.src_h);
         for (int k = 0; k < p.n_extra; ++k) SSD_REQUIRE(p.extra_kind[k] >= 0 && p.extra_kind[k] <= 4, "augment: image %d: extra step kind %d", i, p.extra_kind[k]);
         for (int c = 0; c < 3; ++c) SSD_REQUIRE(p.reorder[c] >= 0 && p.reorder[c] <= 2, "augment: image %d: channel permutation", i);
         const double sx = (double)p.crop_w / out_w, sy = (double)p.crop_h / out_h;

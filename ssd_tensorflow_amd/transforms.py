@@ -16,10 +16,18 @@ form wherever the composition is one (tests/test_augment.py runs them against th
 operations): a second photometric pass -- any brightness / contrast / saturation / hue / reorder after the canonical slots
 are taken -- becomes a list of up to 8 extra pointwise steps the kernel runs behind the canonical chain; photometric steps
 after a flip commute with it; a crop, an expand or another flip after a flip are mirrored index maps; a second expand adds
-its offsets.  What is NOT a composition of this form still raises NotImplementedError rather than silently producing
-something else: a photometric step after an expand or a crop (the image is floating point from the expand on, and Hue /
-Saturation index image ROWS 0 / 1 of the current array), an expand after a crop (the canvas would show source pixels the
-crop had removed), anything after ResizeTransform, another fill value than 104, 117, 123.
+its offsets.
+
+Round 6: the rest of the orders a user can write.  A pointwise step behind an expand acts on the image AND on the canvas: it
+joins the extra steps, and the plan remembers from which extra step on the canvas's mean value is transformed too (a Brightness /
+Contrast there turns the float64 canvas back into uint8, transforms.py:168-175, so the resize rounds again).  Hue / Saturation
+behind a crop or an expand index ROWS 0 / 1 of the array they are handed: the step carries the source row that is that array's
+row 0.  An expand behind a crop shows canvas where the crop cut: the plan keeps the window of the source image that is still
+visible.  ExpandTransform's mean_value travels with the plan.  Pointwise steps behind ResizeTransform run on the resized pixel,
+a flip behind it mirrors the output columns.  What still raises: Hue / Saturation on a floating-point array (cv2.cvtColor has no
+CV_64F path: the reference raises cv2.error there, this mirror RuntimeError); a crop, an expand or a second resize behind
+ResizeTransform, a second expand behind steps that followed the first, two expands with different mean values, more than 16
+extra / 4 post steps (NotImplementedError: the batch kernel has no intermediate image to run them on).
 """
 import ctypes as C
 import os
@@ -33,7 +41,8 @@ from ._lib import lib, check
 from .ssdutils import encode_labels_batch
 from .utils import Size, Sample, Point, Box, abs2prop, prop2abs
 
-MAX_EXTRA = 8        # ssd_augment_params.extra_kind / extra_val
+MAX_EXTRA = 16       # ssd_augment_params.extra_kind / extra_val
+MAX_POST = 4         # ssd_augment_params.post_kind / post_val
 
 # cv2's interpolation enum values (the mirror does not import cv2)
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
@@ -53,10 +62,19 @@ class ImagePlan:
         self.reorder = [0, 1, 2]
         self.extra = []                # further pointwise steps behind the canonical chain, in order: (kind, value) with kind
                                        # 0..2 as above, 3 brightness (value = delta), 4 reorder (value = [c0, c1, c2])
-        self.expand = None             # (Size new, h_off, w_off)
+        self.extra_r0 = []             # per extra step: the source row that was row 0 of the array the step was handed (Hue / Saturation)
+        self.expand = None             # (Size new, h_off, w_off); offsets of the SOURCE image in the canvas (negative behind a crop)
         self.crop = None               # (x0, y0, w, h) in the (expanded) frame, before the flip
         self.flip = False
         self.resize = None             # (width, height, algorithm)
+        # round 6 (any order of the reference's transforms):
+        self.fill_from = None          # canvas pixels exist (an expand happened) and receive the extra steps [fill_from:]
+        self.mean = [104, 117, 123]    # ExpandTransform.mean_value
+        self.is_float = False          # the array is float64 at this point of the chain (expand; Brightness / Contrast make it uint8 again)
+        self.is_float_at_resize = None     # ... when cv2.resize was handed it: a uint8 array is rounded and saturated (None: a plan built by hand -- float iff expanded)
+        self.clip = None               # (x0, y0, x1, y1): the window of the source image still visible (an expand behind a crop)
+        self.post = []                 # pointwise steps behind the resize
+        self.out_flip = False          # a flip behind the resize
 
     # the frame the next geometric transform sees
     @property
@@ -70,21 +88,43 @@ class ImagePlan:
         s = Size(self.resize[0], self.resize[1]) if self.resize is not None else self.size
         return (s.h, s.w, 3)
 
-    def _photometric_ok(self, what, per_pixel=False):
-        # (a flip is a pure permutation of columns and the Hue / Saturation row quirk indexes ROWS: pointwise steps commute with it)
-        # per_pixel: brightness, contrast and the channel order act on every pixel alike, so they commute with a crop as well;
-        # hue / saturation act on image ROWS 0 / 1 (the reference's quirk, transforms.py:201-203,218-220), which a crop moves.
-        if self.expand is not None or self.resize is not None or (self.crop is not None and not per_pixel):
-            raise NotImplementedError(what + ' after an expand, a resize' + ('' if per_pixel else ', a crop') + ' is not a composition the batch kernel runs')
+    def _row0(self):
+        """the source row that is row 0 of the array a transform is handed at this point of the chain"""
+        return (self.crop[1] if self.crop is not None else 0) - (self.expand[1] if self.expand is not None else 0)
+
+    def _pointwise(self, kind, value, what):
+        """Route one pointwise step (0 contrast, 1 saturation, 2 hue, 3 brightness, 4 reorder): a canonical slot while the order is
+        the recipe's, the extra list behind it, the post list behind the resize.  Returns True when the caller should fill the
+        canonical slot itself."""
+        if kind in (1, 2) and self.is_float:
+            # cv2.cvtColor(float64 image, COLOR_BGR2HSV): "Unsupported depth of input image ... 'depth' is 6 (CV_64F)"
+            raise RuntimeError(what + ' on a floating-point image (behind ExpandTransform): cv2.cvtColor supports CV_8U / CV_16U / CV_32F only, '
+                               'the reference raises cv2.error here')
+        if self.resize is not None:
+            if len(self.post) >= MAX_POST:
+                raise NotImplementedError(what + ': the batch kernel runs at most %d steps behind the resize' % MAX_POST)
+            self.post.append((kind, value))
+        else:
+            # (a flip is a pure permutation of columns and the Hue / Saturation row quirk indexes ROWS: pointwise steps commute with it;
+            # brightness, contrast and the channel order act on every pixel alike, so they commute with a crop as well; hue / saturation
+            # act on image ROWS 0 / 1 of the current array, transforms.py:201-203,218-220, which a crop or an expand moves)
+            canonical = self.expand is None and (kind in (0, 3, 4) or self.crop is None)
+            if canonical:
+                return True
+            self._extra_step(kind, value, what)
+        if kind in (0, 3):
+            self.is_float = False          # data.astype(np.uint8), transforms.py:172,186
+        return False
 
     def _extra_step(self, kind, value, what):
         if len(self.extra) >= MAX_EXTRA:
             raise NotImplementedError(what + ': the batch kernel runs at most %d photometric steps behind the canonical chain' % MAX_EXTRA)
         self.extra.append((kind, value))
+        self.extra_r0.append(self._row0() if kind in (1, 2) else 0)
 
     def _geometric_ok(self, what):
         if self.resize is not None:
-            raise NotImplementedError(what + ' after ResizeTransform is outside the order the batch kernel runs')
+            raise NotImplementedError(what + ' after ResizeTransform is outside the order the batch kernel runs (it has no intermediate image)')
 
 
 class Transform:
@@ -135,8 +175,10 @@ class ResizeTransform(Transform):
     """Parameters: width, height, algorithms (transforms.py:117-126)"""
     def __call__(self, data, label, gt):
         alg = random.choice(self.algorithms)
-        data._geometric_ok('ResizeTransform')
+        data._geometric_ok('a second ResizeTransform')
+        data = _copy_plan(data)
         data.resize = (int(self.width), int(self.height), int(alg))
+        data.is_float_at_resize = data.is_float
         return data, label, gt
 
 
@@ -169,41 +211,41 @@ class BrightnessTransform(Transform):
     """Parameters: delta (transforms.py:164-176)"""
     def __call__(self, data, label, gt):
         delta = random.randint(-self.delta, self.delta)
-        data._photometric_ok('BrightnessTransform', per_pixel=True)
-        if data.brightness is not None or data.distort or data.reorder != [0, 1, 2] or data.extra:
-            data._extra_step(3, int(delta), 'BrightnessTransform')      # the canonical slot is taken or behind us
-        else:
-            data.brightness = int(delta)
+        data = _copy_plan(data)
+        if data._pointwise(3, int(delta), 'BrightnessTransform'):
+            if data.brightness is not None or data.distort or data.reorder != [0, 1, 2] or data.extra:
+                data._extra_step(3, int(delta), 'BrightnessTransform')      # the canonical slot is taken or behind us
+            else:
+                data.brightness = int(delta)
         return data, label, gt
 
 
 def _distort(data, kind, value, what):
-    data._photometric_ok(what, per_pixel=(kind == 0))
-    if data.reorder != [0, 1, 2] or data.extra or len(data.distort) >= 3:
-        data._extra_step(kind, float(value), what)
-    else:
-        data.distort.append((kind, float(value)))
+    data = _copy_plan(data)
+    if data._pointwise(kind, float(value), what):
+        if data.reorder != [0, 1, 2] or data.extra or len(data.distort) >= 3:
+            data._extra_step(kind, float(value), what)
+        else:
+            data.distort.append((kind, float(value)))
+    return data
 
 
 class ContrastTransform(Transform):
     """Parameters: lower, upper (transforms.py:179-191)"""
     def __call__(self, data, label, gt):
-        _distort(data, 0, random.uniform(self.lower, self.upper), 'ContrastTransform')
-        return data, label, gt
+        return _distort(data, 0, random.uniform(self.lower, self.upper), 'ContrastTransform'), label, gt
 
 
 class HueTransform(Transform):
     """Parameters: delta (transforms.py:194-208; shifts image ROW 0 of the HSV image, as the reference does)"""
     def __call__(self, data, label, gt):
-        _distort(data, 2, random.randint(-self.delta, self.delta), 'HueTransform')
-        return data, label, gt
+        return _distort(data, 2, random.randint(-self.delta, self.delta), 'HueTransform'), label, gt
 
 
 class SaturationTransform(Transform):
     """Parameters: lower, upper (transforms.py:211-225; scales image ROW 1 of the HSV image, as the reference does)"""
     def __call__(self, data, label, gt):
-        _distort(data, 1, random.uniform(self.lower, self.upper), 'SaturationTransform')
-        return data, label, gt
+        return _distort(data, 1, random.uniform(self.lower, self.upper), 'SaturationTransform'), label, gt
 
 
 class ReorderChannelsTransform(Transform):
@@ -211,11 +253,12 @@ class ReorderChannelsTransform(Transform):
     def __call__(self, data, label, gt):
         channels = [0, 1, 2]
         random.shuffle(channels)
-        data._photometric_ok('ReorderChannelsTransform', per_pixel=True)
-        if data.extra:
-            data._extra_step(4, list(channels), 'ReorderChannelsTransform')
-        else:
-            data.reorder = [data.reorder[c] for c in channels]
+        data = _copy_plan(data)
+        if data._pointwise(4, list(channels), 'ReorderChannelsTransform'):
+            if data.extra:
+                data._extra_step(4, list(channels), 'ReorderChannelsTransform')
+            else:
+                data.reorder = [data.reorder[c] for c in channels]
         return data, label, gt
 
 
@@ -246,17 +289,32 @@ class ExpandTransform(Transform):
         h_off = random.randint(0, new_size.h - orig_size.h)
         w_off = random.randint(0, new_size.w - orig_size.w)
         data._geometric_ok('ExpandTransform')
-        if data.crop is not None:
-            raise NotImplementedError('an expand after a crop is not a composition the batch kernel runs (the canvas would show what the crop removed)')
-        if list(getattr(self, 'mean_value', [104, 117, 123])) != [104, 117, 123]:
-            raise NotImplementedError('the batch kernel fills with the mean value 104, 117, 123')
+        data = _copy_plan(data)
+        mean = [float(v) for v in getattr(self, 'mean_value', [104, 117, 123])]
         if (orig_size.w, orig_size.h) != tuple(data.size):
             raise ValueError('gt.imgsize %s does not match the image at this point of the chain %s' % (orig_size, data.size))
-        # the plan expands BEFORE it flips: an expand behind a flip places the image at the mirrored column offset; a second
-        # expand adds its offsets to the first one's (the same fill value surrounds both canvases)
+        if data.fill_from is not None:      # a canvas exists already
+            if len(data.extra) > data.fill_from:
+                raise NotImplementedError('a second expand behind photometric steps that followed the first: two canvases with different histories')
+            if mean != [float(v) for v in data.mean]:
+                raise NotImplementedError('two expands with different mean values')
+        else:
+            data.fill_from = len(data.extra)
+        data.mean = mean
+        # the plan expands BEFORE it crops and flips: an expand behind a flip places the image at the mirrored column offset; behind
+        # another expand it adds its offsets (the same fill value surrounds both canvases); behind a crop the offsets are taken
+        # relative to the crop's origin and only the cropped window of the source stays visible
         w_plan = new_size.w - orig_size.w - w_off if data.flip else w_off
-        h0, w0 = (data.expand[1], data.expand[2]) if data.expand is not None else (0, 0)
-        data.expand = (new_size, h0 + int(h_off), w0 + int(w_plan))
+        eh, ew = (data.expand[1], data.expand[2]) if data.expand is not None else (0, 0)
+        cx0, cy0 = (data.crop[0], data.crop[1]) if data.crop is not None else (0, 0)
+        if data.crop is not None:
+            win = (cx0 - ew, cy0 - eh, cx0 - ew + data.crop[2], cy0 - eh + data.crop[3])       # the crop window in source coordinates
+            old = data.clip if data.clip is not None else (0, 0, data.src.w, data.src.h)
+            x0, y0, x1, y1 = max(old[0], win[0]), max(old[1], win[1]), min(old[2], win[2]), min(old[3], win[3])
+            data.clip = (x0, y0, max(x0, x1), max(y0, y1))
+            data.crop = None
+        data.expand = (new_size, eh - cy0 + int(h_off), ew - cx0 + int(w_plan))
+        data.is_float = True           # np.zeros(...) canvas: float64 (transforms.py:290)
         gt = transform_gt(gt, new_size, h_off, w_off)
         return data, label, gt
 
@@ -321,6 +379,9 @@ def _copy_plan(p):
     q.distort = list(p.distort)
     q.reorder = list(p.reorder)
     q.extra = list(p.extra)
+    q.extra_r0 = list(p.extra_r0)
+    q.post = list(p.post)
+    q.mean = list(p.mean)
     return q
 
 
@@ -378,8 +439,10 @@ class HorizontalFlipTransform(Transform):
     """transforms.py:379-392"""
     def __call__(self, data, label, gt):
         data = _copy_plan(data)
-        data._geometric_ok('HorizontalFlipTransform')
-        data.flip = not data.flip
+        if data.resize is not None:
+            data.out_flip = not data.out_flip      # behind the resize: the output's columns
+        else:
+            data.flip = not data.flip
         boxes = []
         for box in gt.boxes:
             center = Point(1 - box.center.x, box.center.y)
@@ -399,7 +462,14 @@ class _Params(C.Structure):
                 ('expand_on', C.c_int), ('exp_w', C.c_int), ('exp_h', C.c_int), ('exp_hoff', C.c_int), ('exp_woff', C.c_int),
                 ('crop_x0', C.c_int), ('crop_y0', C.c_int), ('crop_w', C.c_int), ('crop_h', C.c_int),
                 ('flip', C.c_int), ('resize_alg', C.c_int),
-                ('n_extra', C.c_int), ('extra_kind', C.c_int * MAX_EXTRA), ('extra_val', C.c_float * MAX_EXTRA)]
+                ('n_extra', C.c_int), ('extra_kind', C.c_int * MAX_EXTRA), ('extra_val', C.c_float * MAX_EXTRA),
+                ('extra_r0', C.c_int * MAX_EXTRA), ('fill_from', C.c_int), ('is_float', C.c_int), ('mean', C.c_double * 3),
+                ('clip_x0', C.c_int), ('clip_y0', C.c_int), ('clip_x1', C.c_int), ('clip_y1', C.c_int),
+                ('n_post', C.c_int), ('post_kind', C.c_int * MAX_POST), ('post_val', C.c_float * MAX_POST), ('out_flip', C.c_int)]
+
+
+def _step_val(kind, val):
+    return float(val[0] + 4 * val[1] + 16 * val[2]) if kind == 4 else float(val)      # a permutation travels as a base-4 code
 
 
 def plan_params(plans, width, height):
@@ -432,7 +502,18 @@ def plan_params(plans, width, height):
         q.n_extra = len(p.extra)
         for k, (kind, val) in enumerate(p.extra):
             q.extra_kind[k] = kind
-            q.extra_val[k] = float(val[0] + 4 * val[1] + 16 * val[2]) if kind == 4 else float(val)      # a permutation travels as a base-4 code
+            q.extra_val[k] = _step_val(kind, val)
+            q.extra_r0[k] = p.extra_r0[k]
+        q.fill_from = len(p.extra) if p.fill_from is None else p.fill_from
+        q.is_float = int(p.expand is not None if p.is_float_at_resize is None else p.is_float_at_resize)
+        for c in range(3):
+            q.mean[c] = float(p.mean[c])
+        q.clip_x0, q.clip_y0, q.clip_x1, q.clip_y1 = p.clip if p.clip is not None else (0, 0, p.src.w, p.src.h)
+        q.n_post = len(p.post)
+        for k, (kind, val) in enumerate(p.post):
+            q.post_kind[k] = kind
+            q.post_val[k] = _step_val(kind, val)
+        q.out_flip = int(p.out_flip)
         n = p.image.size
         packed[offs[i]:offs[i] + n] = p.image.reshape(-1)
         packed[offs[i] + n:offs[i] + (n + 15) // 16 * 16] = 0

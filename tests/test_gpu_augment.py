@@ -191,3 +191,57 @@ def test_free_compositions_on_the_batch_kernel():
     assert any(p.extra for p in plans) and any(expanded) and not all(expanded)
     for i, (w, e) in enumerate(zip(wants, expanded)):
         _compare(got[i], w, e, f'free list {i // 2} rep {i % 2}')
+
+
+def _compare_any(got, want, plan, tag):
+    """A plan whose array is float64 to the end is compared as such; one that ends in uint8 (never expanded, or made uint8 again by a
+    Brightness / Contrast) within the uint8 path's bounds -- and when steps run BEHIND the resize, the few values the resize rounds
+    the other way (< 0.1 %) may come out of those steps further apart than one level (a hue rotation is not 1-Lipschitz)."""
+    ends_float = plan.is_float
+    if ends_float:
+        err = np.abs(got - want).max() / 255.0
+        assert err < 1e-5, f'{tag}: float path max err {err:.3e} (of 255)'
+        return
+    diff = np.abs(got - want)
+    assert (diff > 0).mean() < 2e-3, f'{tag}: uint8 path {100 * (diff > 0).mean():.3f}% of values differ'
+    if not plan.post:
+        assert diff.max() <= 1.0, f'{tag}: uint8 path max diff {diff.max()}'
+    assert np.array_equal(got, np.floor(got)) and got.min() >= 0 and got.max() <= 255
+
+
+def test_round6_compositions_on_the_batch_kernel():
+    """Round 6 (transforms.py:117-391 are independent callables): the orders rounds 1-5 refused -- pointwise steps behind an expand
+    (image AND canvas), Hue / Saturation behind a crop / on the canvas's rows, an expand behind a crop (visible window), another
+    mean value, steps and a flip behind the resize -- through the batch kernel against the FREE composition of the oracle's pixel
+    operations in the user's order; then 80 random lists the mirror accepts."""
+    import random
+    import compose_util as cu
+    plans, wants, tags = [], [], []
+    for li, steps in enumerate(cu.ROUND6_LISTS):
+        for rep in range(2):
+            img = cu.test_image(700 + 10 * li + rep)
+            seed = 9300 + 10 * li + rep
+            plan, _ = cu.compose_mirror(steps, img, seed)
+            plans.append(plan); wants.append(cu.compose_pixels(steps, img, seed)); tags.append(f'round-6 list {li} rep {rep}')
+    rng = random.Random(78)
+    vocab = [('brightness', {}), ('contrast', {}), ('saturation', {}), ('hue', {}), ('reorder', {}), ('expand', dict(max_ratio=1.6)),
+             ('expand', dict(max_ratio=1.3, mean_value=[7.25, 99.5, 250.0])), ('crop', cu.WIN), ('crop', dict(window=(0.0, 0.8, 0.1, 1.0))), ('flip', {})]
+    case = 0
+    while len(plans) < 2 * len(cu.ROUND6_LISTS) + 80:
+        case += 1
+        steps = [rng.choice(vocab) for _ in range(rng.randint(1, 9))]
+        steps.insert(rng.randint(max(0, len(steps) - 3), len(steps)), cu.RS)
+        img = cu.test_image(2000 + case, (90, 70))
+        try:
+            plan, _ = cu.compose_mirror(steps, img, 6000 + case)
+        except RuntimeError:
+            continue
+        plans.append(plan); wants.append(cu.compose_pixels(steps, img, 6000 + case)); tags.append('random list %d %s' % (case, [n for n, _ in steps]))
+    got = []
+    for i in range(0, len(plans), 32):
+        got.append(T.augment_batch(plans[i:i + 32], 96, 80).cpu().numpy())
+    got = np.concatenate(got)
+    assert any(p.clip is not None for p in plans) and any(p.post for p in plans) and any(p.out_flip for p in plans)
+    assert any(p.fill_from is not None and len(p.extra) > p.fill_from for p in plans)
+    for g, w, p, tag in zip(got, wants, plans, tags):
+        _compare_any(g, w, p, tag)
