@@ -261,16 +261,18 @@ __global__ __launch_bounds__(256) void augment_photometric_kernel(const unsigned
     }
 }
 
-__global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char* __restrict__ images, const ssd_augment_params* __restrict__ prm,
-                                                             int b, int out_w, int out_h, TapTable t, const unsigned char* __restrict__ pre,
-                                                             float* __restrict__ out) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)b * out_w * out_h;
-    if (gid >= total) return;
-    const int ox = (int)(gid % out_w);
-    const int oy = (int)((gid / out_w) % out_h);
-    const int img = (int)(gid / ((size_t)out_w * out_h));
-    const ssd_augment_params p = prm[img];
+// One output pixel per thread, a workgroup = 256 consecutive pixels of ONE image (blockIdx.y).  Round 6: the x taps of a pixel
+// (source column + weight) do not depend on the row tap, yet the round-3 loop re-read them for every one of the ny rows and walked
+// the nx columns as a dynamic loop of dependent loads (index -> address -> pixel -> convert -> three double FMAs): the kernel's time
+// was the latency of nx * ny such chains.  Here a workgroup looks up its image's tap count once, picks the instantiation with NX =
+// 1, 2, 4, 8 or 16 column taps (INTER_AREA's 3 .. 15 are padded with zero-weight repeats of the last tap: x + 0.0 * v = x), keeps
+// the NX indices and weights in registers and issues the NX pixel loads of a row back to back from clamped addresses -- visibility
+// and the canvas colour are selected afterwards -- before the NX * 3 FMAs in the order the oracle prescribes.  Same sums bit for bit
+// (tests/test_gpu_augment.py).  An image whose photometric chain runs per tap (larger than the pre-pass buffer) keeps the loop form.
+template <int NX>
+__device__ __forceinline__ void augment_gather_body(const unsigned char* __restrict__ images, const ssd_augment_params& p, int img, int ox, int oy,
+                                                    int out_w, int out_h, const TapTable& t, const unsigned char* __restrict__ pre,
+                                                    float* __restrict__ out) {
     const int pitch = out_w > out_h ? out_w : out_h;
     const size_t px_ = (size_t)(img * 2 + 0), py_ = (size_t)(img * 2 + 1);
     const int nx = t.n[px_ * pitch + ox], ny = t.n[py_ * pitch + oy];
@@ -282,38 +284,85 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
     const bool per_tap = aug_has_photometric(p) && !from_pre;
     const unsigned char* src = from_pre ? pre + (size_t)img * AUG_PRE_BYTES : images + p.src_off;
     const bool fill_steps = p.fill_from < p.n_extra;
+    typedef unsigned u32_unaligned __attribute__((aligned(1)));
     double acc[3] = {0, 0, 0};
-    for (int j = 0; j < ny; ++j) {
-        const int sy = yi[(size_t)j * pitch] + p.crop_y0;                  // row in the (expanded) frame
-        const double wy = yw[(size_t)j * pitch];
-        double rowacc[3] = {0, 0, 0};
-        for (int i = 0; i < nx; ++i) {
-            int sx = xi[(size_t)i * pitch];
+    if constexpr (NX > 0) {
+        // column taps: source column in the loaded image (x0), its visibility, the weight -- once per pixel
+        int x0[NX];
+        double wx[NX];
+        bool vx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int ii = i < nx ? i : nx - 1;
+            int sx = xi[(size_t)ii * pitch];
             if (p.flip) sx = p.crop_w - 1 - sx;
-            sx += p.crop_x0;
-            const double wx = xw[(size_t)i * pitch];
-            const int y0 = sy - p.exp_hoff, x0 = sx - p.exp_woff;         // position in the loaded image (offsets are 0 when not expanded)
-            double px[3];
-            if ((unsigned)(y0 - p.clip_y0) < (unsigned)(p.clip_y1 - p.clip_y0) && (unsigned)(x0 - p.clip_x0) < (unsigned)(p.clip_x1 - p.clip_x0)) {
-                const unsigned char* q = src + ((size_t)y0 * p.src_w + x0) * 3;
-                // one (unaligned) dword instead of three byte loads -- except for the image's very last pixel, whose fourth
-                // byte may lie outside the caller's buffer
-                typedef unsigned u32_unaligned __attribute__((aligned(1)));
-                const bool last_px = (y0 == p.src_h - 1) & (x0 == p.src_w - 1);
-                unsigned v;
-                if (last_px) v = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
-                else v = *reinterpret_cast<const u32_unaligned*>(q);
-                float raw[3] = {(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u)};
-                if (per_tap) photometric(p, y0, raw);      // (incl. the reorder)
-                if (per_tap || from_pre) { px[0] = raw[0]; px[1] = raw[1]; px[2] = raw[2]; }
-                else for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
-            } else {
-                for (int c = 0; c < 3; ++c) px[c] = p.mean[c];
-                if (fill_steps) photometric_fill(p, y0, px);
-            }
-            for (int c = 0; c < 3; ++c) rowacc[c] += wx * px[c];
+            x0[i] = sx + p.crop_x0 - p.exp_woff;
+            vx[i] = (unsigned)(x0[i] - p.clip_x0) < (unsigned)(p.clip_x1 - p.clip_x0);
+            wx[i] = i < nx ? (double)xw[(size_t)ii * pitch] : 0.0;
         }
-        for (int c = 0; c < 3; ++c) acc[c] += wy * rowacc[c];
+        const int last_x = p.src_w - 1, last_y = p.src_h - 1;
+        for (int j = 0; j < ny; ++j) {
+            const int y0 = yi[(size_t)j * pitch] + p.crop_y0 - p.exp_hoff;      // row in the loaded image
+            const double wy = yw[(size_t)j * pitch];
+            const bool vy = (unsigned)(y0 - p.clip_y0) < (unsigned)(p.clip_y1 - p.clip_y0);
+            const unsigned char* rowp = src + (size_t)(vy ? y0 : 0) * p.src_w * 3;
+            unsigned v[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int xc = vx[i] ? x0[i] : 0;
+                const unsigned char* q = rowp + (size_t)xc * 3;
+                // one (unaligned) dword instead of three byte loads -- except for the image's very last pixel, whose fourth byte may
+                // lie outside the caller's buffer
+                if (vy && y0 == last_y && xc == last_x) v[i] = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
+                else v[i] = *reinterpret_cast<const u32_unaligned*>(q);
+            }
+            double fillc[3] = {p.mean[0], p.mean[1], p.mean[2]};      // the canvas colour of this row
+            if (fill_steps) photometric_fill(p, y0, fillc);
+            double rowacc[3] = {0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double px[3];
+                if (vy && vx[i]) {
+                    const float raw[3] = {(float)(v[i] & 255u), (float)((v[i] >> 8) & 255u), (float)((v[i] >> 16) & 255u)};
+                    if (from_pre) { px[0] = raw[0]; px[1] = raw[1]; px[2] = raw[2]; }
+                    else for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
+                } else {
+                    px[0] = fillc[0]; px[1] = fillc[1]; px[2] = fillc[2];
+                }
+                for (int c = 0; c < 3; ++c) rowacc[c] += wx[i] * px[c];
+            }
+            for (int c = 0; c < 3; ++c) acc[c] += wy * rowacc[c];
+        }
+    } else {
+        for (int j = 0; j < ny; ++j) {
+            const int sy = yi[(size_t)j * pitch] + p.crop_y0;                  // row in the (expanded) frame
+            const double wy = yw[(size_t)j * pitch];
+            double rowacc[3] = {0, 0, 0};
+            for (int i = 0; i < nx; ++i) {
+                int sx = xi[(size_t)i * pitch];
+                if (p.flip) sx = p.crop_w - 1 - sx;
+                sx += p.crop_x0;
+                const double wx = xw[(size_t)i * pitch];
+                const int y0 = sy - p.exp_hoff, x0 = sx - p.exp_woff;         // position in the loaded image (offsets are 0 when not expanded)
+                double px[3];
+                if ((unsigned)(y0 - p.clip_y0) < (unsigned)(p.clip_y1 - p.clip_y0) && (unsigned)(x0 - p.clip_x0) < (unsigned)(p.clip_x1 - p.clip_x0)) {
+                    const unsigned char* q = src + ((size_t)y0 * p.src_w + x0) * 3;
+                    const bool last_px = (y0 == p.src_h - 1) & (x0 == p.src_w - 1);
+                    unsigned v;
+                    if (last_px) v = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
+                    else v = *reinterpret_cast<const u32_unaligned*>(q);
+                    float raw[3] = {(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u)};
+                    if (per_tap) photometric(p, y0, raw);      // (incl. the reorder)
+                    if (per_tap || from_pre) { px[0] = raw[0]; px[1] = raw[1]; px[2] = raw[2]; }
+                    else for (int c = 0; c < 3; ++c) px[c] = raw[p.reorder[c]];
+                } else {
+                    for (int c = 0; c < 3; ++c) px[c] = p.mean[c];
+                    if (fill_steps) photometric_fill(p, y0, px);
+                }
+                for (int c = 0; c < 3; ++c) rowacc[c] += wx * px[c];
+            }
+            for (int c = 0; c < 3; ++c) acc[c] += wy * rowacc[c];
+        }
     }
     float res[3];
     for (int c = 0; c < 3; ++c) {
@@ -326,9 +375,39 @@ __global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char
     }
     // steps behind ResizeTransform act on the resized array (its rows 0 / 1), a flip behind it mirrors the output columns
     for (int i = 0; i < p.n_post; ++i) photometric_step(p.post_kind[i], p.post_val[i], oy, res);
-    const size_t og = p.out_flip ? gid - ox + (out_w - 1 - ox) : gid;
-    float* o = out + og * 3;
+    const size_t gid = ((size_t)img * out_h + oy) * out_w + (p.out_flip ? out_w - 1 - ox : ox);
+    float* o = out + gid * 3;
     for (int c = 0; c < 3; ++c) o[c] = res[c];
+}
+
+__global__ __launch_bounds__(256) void augment_gather_kernel(const unsigned char* __restrict__ images, const ssd_augment_params* __restrict__ prm,
+                                                             int b, int out_w, int out_h, TapTable t, const unsigned char* __restrict__ pre,
+                                                             float* __restrict__ out) {
+    const int img = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= out_w * out_h) return;
+    const int ox = pix % out_w, oy = pix / out_w;
+    const ssd_augment_params& p = prm[img];
+    // the widest column tap count of the image: uniform per workgroup (nearest 1, linear / enlarging area 2, cubic 4, Lanczos 8,
+    // shrinking area up to 16)
+    int nxmax;
+    const double sx = (double)p.crop_w / (double)out_w;
+    if (p.resize_alg == ALG_NEAREST) nxmax = 1;
+    else if (p.resize_alg == ALG_LINEAR || (p.resize_alg == ALG_AREA && sx < 1.0)) nxmax = 2;
+    else if (p.resize_alg == ALG_CUBIC) nxmax = 4;
+    else if (p.resize_alg == ALG_LANCZOS4) nxmax = 8;
+    else nxmax = AUG_TMAX;
+    if (p.resize_alg == ALG_AREA && sx >= 1.0) nxmax = sx <= 2.0 ? 4 : (sx <= 6.0 ? 8 : 16);      // at most floor(scale) + 2 taps
+    const bool per_tap = aug_has_photometric(p) && !aug_uses_pre(p);
+    const int pitch = out_w > out_h ? out_w : out_h;
+    const int nx = t.n[(size_t)(img * 2) * pitch + ox];
+    // (shrinking by more than 6x -- 16 taps, 2000-pixel sources -- keeps the loop form: its 16 doubles of weights would set the
+    // register allocation, and with it the resident waves, of every other case)
+    if (per_tap || nxmax > 8 || nx > nxmax) augment_gather_body<0>(images, p, img, ox, oy, out_w, out_h, t, pre, out);
+    else if (nxmax == 1) augment_gather_body<1>(images, p, img, ox, oy, out_w, out_h, t, pre, out);
+    else if (nxmax == 2) augment_gather_body<2>(images, p, img, ox, oy, out_w, out_h, t, pre, out);
+    else if (nxmax == 4) augment_gather_body<4>(images, p, img, ox, oy, out_w, out_h, t, pre, out);
+    else augment_gather_body<8>(images, p, img, ox, oy, out_w, out_h, t, pre, out);
 }
 
 size_t augment_ws_bytes(int b, int out_w, int out_h) {
@@ -388,7 +467,7 @@ void augment_batch(const unsigned char* images_dev, const ssd_augment_params* pa
     {
         const size_t total = (size_t)b * out_w * out_h;
         ProfScope prof("augment_gather", 0.0, (double)total * 12, s);
-        hipLaunchKernelGGL(augment_gather_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, s, images_dev, prm, b, out_w, out_h, t, pre, out_dev);
+        hipLaunchKernelGGL(augment_gather_kernel, dim3(cdiv(out_w * out_h, 256), b), dim3(256), 0, s, images_dev, prm, b, out_w, out_h, t, pre, out_dev);
     }
     HIP_OK(hipGetLastError());
 }
