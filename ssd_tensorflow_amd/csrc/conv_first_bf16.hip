@@ -159,6 +159,182 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs p) {
 }
 
 // ---------------------------------------------------------------------------------
+// forward, row-aligned tiles (round 6).  The kernel above turned out ISSUE-bound, not store-bound: ~400 VALU instructions per
+// 32-pixel tile (two integer divisions for the pixel's row and image, nine tap tests, sixteen gathers each with two selects, 32
+// accumulator reads + bias + relu + packing), ~64 us of pure issue per SIMD at batch 32, and more resident waves do not help
+// (profiles/r06_w_*: 176 -> 87 registers, 0.134 -> 0.140 ms) while a kernel that only writes the same 368 MB takes 62-75 us
+// (profiles/r06_x_store_rate_probe.txt).  Here a tile is 32 consecutive pixels of ONE image row:
+//   * the tile's image, row and column segment are wave-uniform: decoded with two scalar multiply-highs (host-made magic
+//     numbers), they go into the gathers' SCALAR offset; a lane's sixteen offsets (pixel li x stride, tap, channel) are constants;
+//   * a tile whose 32 pixels have all taps inside the image (all but the first / last row and column segment) gathers with no
+//     vector instruction at all; the others select the out-of-range offset per gather from a tap-validity word (LDS table);
+//   * the bias is the MFMA's C operand (registers that live for the whole kernel): no zero fill, no add -- the sum starts from
+//     the bias instead of ending with it, a different fp32 rounding order than the kernel above (which the tests keep as the
+//     reference form of this layer, SSD_FIRST_ROWS_BF16=0);
+//   * relu on the packed bf16 pairs (v_pk_max_i16 against zero: a negative bf16 is a negative int16).
+// ---------------------------------------------------------------------------------
+struct FirstRowsArgs {
+    FirstArgs a;
+    int segs;                   // 32-pixel segments per output row
+    unsigned magic_segs, magic_ho;      // ceil(2^32 / segs), ceil(2^32 / Ho)
+    int nrowtiles;              // B * Ho * segs
+};
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_fwd_rows_kernel(FirstRowsArgs pp) {
+    constexpr int ROWB = NT * 64 + 16;                      // LDS row: NT*32 channels bf16 + pad
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * ROWB + 512 * 4];
+    const FirstArgs& p = pp.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned char* T = smem + wave * 32 * ROWB;
+    unsigned* lut = reinterpret_cast<unsigned*>(smem + 4 * 32 * ROWB);      // [1 << ntaps]: tap mask of a pixel -> mask of its valid k's
+    const int K = p.ntaps * p.Ci;
+    for (int e = tid; e < (1 << p.ntaps); e += 256) {
+        unsigned v = 0;
+        for (int k = 0; k < K; ++k) v |= (((unsigned)e >> (k / p.Ci)) & 1u) << k;
+        lut[e] = v;
+    }
+    __syncthreads();
+
+    // filter operand (MFMA rows = output channels): lane (co = nt*32 + li, k = ks*16 + 8*lh + j); bias = the accumulator's start
+    bf16x8 wa[NT][2];
+    f32x16 bias16[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 16 + 8 * lh + j;
+                v[j] = p.w[(size_t)(k < K ? k : K - 1) * p.Co + nt * 32 + li];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (ks * 16 + 8 * lh + j >= K) v[j] = 0.f;
+            wa[nt][ks] = __builtin_bit_cast(bf16x8, pack8(v));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias16[nt][r] = p.bias ? p.bias[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
+    }
+    // this lane's sixteen gather offsets relative to the tile's first pixel (constants), and its tap / k bookkeeping
+    int tap_min = 0;
+    for (int t = 0; t < p.ntaps; ++t) tap_min = min(tap_min, (p.tap_dh[t] * p.Wi + p.tap_dw[t]) * p.Ci);
+    const unsigned tap_bias = (unsigned)(-tap_min) * 4u;
+    unsigned koff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * lh + j;
+            const bool kv = k < K;
+            const int tp = kv ? k / p.Ci : 0, c = kv ? k - tp * p.Ci : 0;
+            koff[ks][j] = kv ? (unsigned)(((p.tap_dh[tp] * p.Wi + p.tap_dw[tp] + li * p.stride) * p.Ci + c) * 4 + (int)tap_bias) : OOBF;
+        }
+    const size_t x_bytes = (size_t)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Ci * 4u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(const_cast<float*>(p.x)) - tap_bias, 0, (unsigned)(x_bytes + tap_bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((size_t)p.M * p.Co * 2u), 0x00020000);
+    // column range of the taps (for the interior test)
+    int dw_min = 0, dw_max = 0, dh_min = 0, dh_max = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+        dw_min = min(dw_min, p.tap_dw[t]); dw_max = max(dw_max, p.tap_dw[t]);
+        dh_min = min(dh_min, p.tap_dh[t]); dh_max = max(dh_max, p.tap_dh[t]);
+    }
+
+    // (b, oh, seg) of a tile: wave-uniform (a divisor of 1 has no 32-bit magic number: its quotient is the dividend)
+    struct TileGeom { int row, ow0, npx; unsigned base; bool interior; int h0, w00; };
+    auto geom = [&](int tile) {
+        TileGeom g;
+        g.row = pp.segs == 1 ? tile : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)tile, pp.magic_segs));      // = b * Ho + oh
+        const int seg = tile - g.row * pp.segs;
+        const int b = p.Ho == 1 ? g.row : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)g.row, pp.magic_ho));
+        const int oh = g.row - b * p.Ho;
+        g.ow0 = seg * 32;
+        g.h0 = oh * p.stride; g.w00 = g.ow0 * p.stride;
+        g.npx = min(32, p.Wo - g.ow0);                                // pixels of this tile inside the row
+        g.base = (unsigned)(((b * p.Hi + g.h0) * p.Wi + g.w00) * p.Ci) * 4u;      // scalar offset of the tile's first pixel
+        g.interior = g.npx == 32 && g.h0 + dh_min >= 0 && g.h0 + dh_max < p.Hi && g.w00 + dw_min >= 0 && g.w00 + 31 * p.stride + dw_max < p.Wi;
+        return g;
+    };
+    // the sixteen image values of this lane's two MFMA operands: issued, not yet looked at
+    auto gather = [&](const TileGeom& g, float (&v)[2][8]) {
+        if (g.interior) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, koff[ks][j], g.base, 0));
+        } else {
+            const int w0 = g.w00 + li * p.stride;
+            unsigned mk = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int sh = g.h0 + p.tap_dh[t], sw = w0 + p.tap_dw[t];
+                if ((unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi) mk |= 1u << t;
+            }
+            if (li >= g.npx) mk = 0;
+            const unsigned kv = lut[mk] >> (8 * lh);            // bit ks*16 + j: this lane's k = ks*16 + 8*lh + j is inside the image
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned ok = 0u - ((kv >> (ks * 16 + j)) & 1u);
+                    v[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (koff[ks][j] & ok) | (OOBF & ~ok), g.base, 0));
+                }
+        }
+    };
+
+    // One tile AHEAD: the next tile's gathers are issued before this tile's results are stored.  Stores count in vmcnt like loads and
+    // retire in order with them: with the gathers issued BEHIND the previous tile's stores, every tile waited for four store
+    // acknowledgements (a round trip to L2 under 368 MB of write traffic) before its own loads could be waited for -- the kernel ran
+    // at 2.6 TB/s of stores whatever its instruction count or occupancy.
+    const int nwaves = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    float raw[2][8];
+    TileGeom g{};
+    if (tile < pp.nrowtiles) { g = geom(tile); gather(g, raw); }
+    for (; tile < pp.nrowtiles; tile += nwaves) {
+        bf16x8 xb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xb[ks] = __builtin_bit_cast(bf16x8, pack8(raw[ks]));
+        const TileGeom gc = g;
+        const int next = tile + nwaves;
+        if (next < pp.nrowtiles) { g = geom(next); gather(g, raw); }
+        const int row = gc.row, ow0 = gc.ow0, npx = gc.npx;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[nt][0], xb[0], bias16[nt], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[nt][1], xb[1], acc, 0, 0, 0);
+            // D rows = channels (r&3) + 8*(r>>2) + 4*lh, D col = pixel li: 4 consecutive channels per register quad
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned q0 = pack2(acc[4 * g], acc[4 * g + 1]), q1 = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+                if (p.relu) {
+                    q0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, q0), s16x2{0, 0}));
+                    q1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, q1), s16x2{0, 0}));
+                }
+                *reinterpret_cast<u32x2*>(T + li * ROWB + (nt * 32 + 8 * g + 4 * lh) * 2) = u32x2{q0, q1};
+            }
+        }
+        // wave-private tile -> global, 16 bytes per lane, whole rows (NT*64 bytes per pixel)
+        constexpr int CPR = NT * 4;                  // 16-byte chunks per pixel row
+        constexpr int PPI = 64 / CPR;                // pixels per store instruction
+        // (buffer stores, an out-of-range offset for the pixels past the row's end: ALWAYS four store instructions per tile, so that the
+        // wait for the next tile's gathers can be a counted one -- vmcnt(4) -- instead of vmcnt(0))
+        const unsigned ybase = (unsigned)(((size_t)row * p.Wo + ow0) * p.Co * 2u);
+#pragma unroll
+        for (int i = 0; i < 32 / PPI; ++i) {
+            const int px = i * PPI + lane / CPR, ch = lane % CPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(T + px * ROWB + ch * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, px < npx ? (unsigned)((px * p.Co + ch * 8) * 2) : OOBF, ybase, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // weight gradient: dW[k][n] = sum_m xcol[m][k] * dy[m][n], k = tap*Ci + c < 32
 // workgroup = one pixel split; waves (kh, nh): pixel half kh of every 64-pixel block, channel tile nh
 // ---------------------------------------------------------------------------------
@@ -295,6 +471,25 @@ void conv_first_fwd_bf16(const ConvDesc& d, const float* x, const float* w, cons
     FirstArgs a{};
     fill_args(a, d);
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.relu = relu;
+    static const int rows = env_int("SSD_FIRST_ROWS_BF16", 1);      // 0: the pixel-raster kernel (bias added behind the sum: the tests' reference form)
+    const int segs = cdiv(d.Wo, 32);
+    const long long nrowtiles = (long long)d.B * d.Ho * segs;
+    if (rows && nrowtiles * segs < (1LL << 32) && (long long)d.B * d.Ho * d.Ho < (1LL << 32)) {
+        FirstRowsArgs r{};
+        r.a = a; r.segs = segs; r.nrowtiles = (int)nrowtiles;
+        r.magic_segs = (unsigned)(((1ULL << 32) + segs - 1) / segs);
+        r.magic_ho = (unsigned)(((1ULL << 32) + d.Ho - 1) / d.Ho);
+        // exactly the workgroups that are resident at once (two per CU at 179 registers): a workgroup's prologue -- the tap table, 32
+        // filter and 32 bias loads per lane -- is paid once per slot; 2048 workgroups: 0.150 ms, 1024: 0.135, 512: 0.122, 256: 0.155
+        // (profiles/r06_ad_*)
+        int blocks = cdiv((int)nrowtiles, 4);
+        static const int cap = env_int("SSD_FIRST_GRID", 256 * 2);
+        if (blocks > cap) blocks = cap;
+        ProfScope prof("conv_first_fwd_rows_bf16", conv_flops(d), 4.0 * d.B * d.Hi * d.Wi * d.Ci + 2.0 * a.M * d.Co, s);
+        hipLaunchKernelGGL(conv_first_fwd_rows_kernel<2>, dim3(blocks), dim3(256), 0, s, r);
+        HIP_OK(hipGetLastError());
+        return;
+    }
     a.ntiles = cdiv(a.M, 32);
     int blocks = cdiv(a.ntiles, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;

@@ -228,6 +228,18 @@ def test_first_layer_bf16(case):
     assert e < TOL, f'{name}: bias-grad max-rel {e:.3e}'
 
 
+def test_first_layer_bf16_raster_form():
+    """SSD_FIRST_ROWS_BF16=0: the pixel-raster conv1_1 forward (bias added behind the sum) that the row-aligned kernel replaced in
+    round 6 stays reachable and under test (the same cases in a process of its own: the switch is read once)."""
+    import os, subprocess, sys
+    if os.environ.get('SSD_FIRST_ROWS_BF16') == '0':
+        pytest.skip('already the forced configuration')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_first_layer_bf16 and not raster',
+                        '-p', 'no:cacheprovider'], env=dict(os.environ, SSD_FIRST_ROWS_BF16='0'),
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def layer_local_forward_check(net, m, preset, b, x, only=None):
     """Every op's forward recomputed by the oracle from the GPU's own (bf16) input activation and the
     bf16-rounded filter; head outputs are fp32.  only: optional list of op names ('conv4_2', 'pool3', 'heads/map0',
