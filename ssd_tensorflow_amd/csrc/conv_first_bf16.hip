@@ -179,7 +179,11 @@ struct FirstRowsArgs {
     unsigned magic_segs, magic_ho;      // ceil(2^32 / segs), ceil(2^32 / Ho)
     int nrowtiles;              // B * Ho * segs
 };
+#ifndef FIRST_AHEAD
+#define FIRST_AHEAD 1
+#endif
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv_first_fwd_rows_kernel(FirstRowsArgs pp) {
@@ -287,22 +291,41 @@ __global__ __launch_bounds__(256) void conv_first_fwd_rows_kernel(FirstRowsArgs 
         }
     };
 
-    // One tile AHEAD: the next tile's gathers are issued before this tile's results are stored.  Stores count in vmcnt like loads and
-    // retire in order with them: with the gathers issued BEHIND the previous tile's stores, every tile waited for four store
-    // acknowledgements (a round trip to L2 under 368 MB of write traffic) before its own loads could be waited for -- the kernel ran
-    // at 2.6 TB/s of stores whatever its instruction count or occupancy.
+    // One tile of look-ahead: the next tile's gathers are issued before this tile's results are stored (stores count in vmcnt like
+    // loads and retire in order with them: issued BEHIND the previous tile's stores, every gather waited for four store
+    // acknowledgements first).  What a tile then still costs a wave -- 2.8 us at two waves per SIMD, 0.122 ms for the layer against the
+    // 0.065-0.075 ms a pure store stream needs -- is the gathers' own return time under 368 MB of write traffic.  Looking further ahead
+    // (FIRST_AHEAD 2: 0.121 ms, 3: 0.122, 4: 0.123, profiles/r06_af_*) and handing the stores to waves of their own (four gather + four
+    // store waves behind one raw barrier per tile: 0.131 ms, profiles/r06_ae_*) changed nothing, and the deeper rings failed the
+    // 300 x 300 case of tests/test_gpu_bf16.py: only the depth-1 form is built.
+    constexpr int AHEAD = FIRST_AHEAD;
     const int nwaves = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
-    float raw[2][8];
-    TileGeom g{};
-    if (tile < pp.nrowtiles) { g = geom(tile); gather(g, raw); }
-    for (; tile < pp.nrowtiles; tile += nwaves) {
+    const int tile0 = blockIdx.x * 4 + wave;
+    // (every wave runs whole rounds of AHEAD tiles and every tile -- also the null tiles past the end, whose gathers and stores all
+    // carry the out-of-range offset -- issues exactly 16 loads and 4 stores: the waits below are COUNTED ones the compiler can prove)
+    const int nround = tile0 < pp.nrowtiles ? cdiv_i(cdiv_i(pp.nrowtiles - tile0, nwaves), AHEAD) : 0;
+    auto geom_or_null = [&](int tile) {
+        if (tile < pp.nrowtiles) return geom(tile);
+        TileGeom g{};
+        g.npx = 0; g.interior = false;
+        return g;
+    };
+    float raw[AHEAD][2][8];
+    TileGeom gq[AHEAD];
+    if (nround > 0) {
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) { gq[a] = geom_or_null(tile0 + a * nwaves); gather(gq[a], raw[a]); }
+    }
+    for (int r = 0; r < nround; ++r) {
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a) {
+        const int tile = tile0 + (r * AHEAD + a) * nwaves;
         bf16x8 xb[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) xb[ks] = __builtin_bit_cast(bf16x8, pack8(raw[ks]));
-        const TileGeom gc = g;
-        const int next = tile + nwaves;
-        if (next < pp.nrowtiles) { g = geom(next); gather(g, raw); }
+        for (int ks = 0; ks < 2; ++ks) xb[ks] = __builtin_bit_cast(bf16x8, pack8(raw[a][ks]));
+        const TileGeom gc = gq[a];
+        gq[a] = geom_or_null(tile + AHEAD * nwaves);
+        gather(gq[a], raw[a]);
         const int row = gc.row, ow0 = gc.ow0, npx = gc.npx;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -331,6 +354,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_rows_kernel(FirstRowsArgs 
             const u32x4 v = *reinterpret_cast<const u32x4*>(T + px * ROWB + ch * 16);
             __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, px < npx ? (unsigned)((px * p.Co + ch * 8) * 2) : OOBF, ybase, 0);
         }
+      }
     }
 }
 

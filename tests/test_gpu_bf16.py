@@ -240,6 +240,19 @@ def test_first_layer_bf16_raster_form():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_first_layer_bf16_many_tiles_per_wave():
+    """SSD_FIRST_GRID=16: the row-aligned conv1_1 forward with 64 waves for everything -- dozens of tiles per wave, so the
+    one-tile-ahead ring, its null tiles past the end and the counted waits all run (the default grid gives the small cases one tile
+    per wave)."""
+    import os, subprocess, sys
+    if os.environ.get('SSD_FIRST_GRID') == '16':
+        pytest.skip('already the forced configuration')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_first_layer_bf16 and not raster and not many',
+                        '-p', 'no:cacheprovider'], env=dict(os.environ, SSD_FIRST_GRID='16'),
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def layer_local_forward_check(net, m, preset, b, x, only=None):
     """Every op's forward recomputed by the oracle from the GPU's own (bf16) input activation and the
     bf16-rounded filter; head outputs are fp32.  only: optional list of op names ('conv4_2', 'pool3', 'heads/map0',
