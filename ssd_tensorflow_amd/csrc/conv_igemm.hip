@@ -1249,6 +1249,9 @@ static int pick_tile(long long M, int N, int mode) {
     // (LDS-DMA kernels: forward is best on 128x128 (conv2_2 126, conv3_2 131, conv4_2 125 TF/s), the data gradient on 64x128
     // (123-128), on 64x64 when N = 64 (conv1_2 110))
     static const double dma_fwd[4] = {1.03, 1.0, 1.0, 0.96}, dma_dg[4] = {0.96, 0.97, 1.0, 0.94};
+    // N = 64 (conv1_2, the un-pooling conv2_1).  Round 6 re-measured the data gradient on the LDS-DMA kernels: alone, 128 x 64 runs 1.821 /
+    // 0.956 ms against 64 x 64's 1.894 / 0.968 (256 x 64, two workgroups of 80 KB per CU: 1.938 / 1.007; profiles/r06_ai_*) -- in the
+    // overlapped step the order is the other way round, 50.197 against 50.133 ms (profiles/r06_aj_*): the 64 x 64 tile stays.
     if (mode == MODE_DGRAD && N <= 64) return 3;
     const double* eff = mode == MODE_FWD ? dma_fwd : dma_dg;
     int best = 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06ag
+TAG=r06aj
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_tail.py tests/test_gpu_model.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -4
-bash tools/ab_variants.sh "$O/ab_cast_split_bf16.txt" 5 bf16 "cast_split_0:SSD_CAST_SPLIT=0" "cast_split_1:SSD_CAST_SPLIT=1"
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_pool_fusion.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -3
+bash tools/ab_variants.sh "$O/ab_dgrad_n64_tile_f32.txt" 4 f32 "n64_tile_64x64:SSD_DGRAD_N64_TILE=3" "n64_tile_128x64:SSD_DGRAD_N64_TILE=1"
