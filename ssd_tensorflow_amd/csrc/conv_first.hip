@@ -126,7 +126,10 @@ void conv_first_fwd_f32(const ConvDesc& d, const float* x, const float* w, const
         }
     a.ntiles = cdiv(a.M, 32);
     int blocks = cdiv(a.ntiles, 4);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    // the workgroups that are resident at once (three per CU at 168 registers): the prologue -- 32 filter and 32 bias loads per lane -- is
+    // paid once per slot: 2048 workgroups 0.221 ms, 1024 0.266, 768 0.202, 512 0.223 (profiles/r06_ak_*; conv_first_bf16.hip has the story)
+    static const int cap = env_int("SSD_FIRST_GRID_F32", 256 * 3);
+    if (blocks > cap) blocks = cap;
     ProfScope prof("conv_first_fwd", conv_flops(d), 4.0 * ((double)d.B * d.Hi * d.Wi * d.Ci + (double)a.M * d.Co), s);
     hipLaunchKernelGGL(conv_first_fwd_f32_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
     HIP_OK(hipGetLastError());

@@ -1,7 +1,8 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06aj
+TAG=r06ak
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_pool_fusion.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -3
-bash tools/ab_variants.sh "$O/ab_dgrad_n64_tile_f32.txt" 4 f32 "n64_tile_64x64:SSD_DGRAD_N64_TILE=3" "n64_tile_128x64:SSD_DGRAD_N64_TILE=1"
+for g in 2048 1024 768 512; do
+  SSD_FIRST_GRID_F32=$g timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-overlap --per-layer 2>&1 > /dev/null | grep -E 'conv_first_fwd' | sed "s/^/grid=$g /"
+done | tee "$O/per_layer_conv1_1_grid_f32.txt"
