@@ -271,8 +271,14 @@ def self_check(out, serialized):
         problems.append(f'kernel sum {ksum:.3f} ms/step > {"1.3 x " if serialized else ""}ms_per_step {ms:.3f}')
     if r is not None and not (0.0 < r['frac'] <= 1.0):
         problems.append(f'roofline.frac {r["frac"]} outside (0, 1]')
-    if out.get('model_mfma_frac') is not None and not (0.0 < out['model_mfma_frac'] <= 1.0):
-        problems.append(f'model_mfma_frac {out["model_mfma_frac"]} outside (0, 1]')
+    # model_mfma_frac prices the step by the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md 8d; the fp32 step runs its 3x3 trunk
+    # layers in the Winograd F(4x4, 3x3) form (csrc/winograd.hip: 4x fewer multiplies), so that figure may exceed 1 there and only
+    # there -- what cannot exceed 1 is the fraction of the peak the matrix pipe was actually asked for (executed_mfma_frac)
+    wino = bool(out.get('algorithm'))
+    if out.get('model_mfma_frac') is not None and not (0.0 < out['model_mfma_frac'] <= (4.0 if wino else 1.0)):
+        problems.append(f'model_mfma_frac {out["model_mfma_frac"]} outside (0, {4 if wino else 1}]')
+    if out.get('executed_mfma_frac') is not None and not (0.0 < out['executed_mfma_frac'] <= 1.0):
+        problems.append(f'executed_mfma_frac {out["executed_mfma_frac"]} outside (0, 1]')
     if problems:
         raise SystemExit('[bench] self-check failed: ' + '; '.join(problems))
     return 'dominant kernel <= step, kernel sum <= %sstep, fractions in (0, 1]' % ('1.3 x ' if serialized else '')
@@ -543,6 +549,18 @@ def run_config(a, rank, world, local):
             tot = sum(k['ms'] for k in kernels.values())
             out['kernel_ms_per_step'] = {k: round(v['ms'] / a.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernel_ms_sum_per_step'] = round(tot / a.steps, 4)
+            if a.mode != 'decode':
+                # the FLOPs the launches actually executed (each launcher's own count: the Winograd GEMMs count their 36 small
+                # products, not the direct convolution they replace) over the timed step
+                ex = sum(k['flops'] for k in kernels.values()) / a.steps
+                wl = sorted(k for k in kernels if k.startswith('wino_gemm'))
+                out['executed_tflops'] = round(ex / (dt / a.steps) / 1e12 / world, 2)
+                out['executed_mfma_frac'] = round(ex / (dt / a.steps) / 1e12 / peak_mfma, 4)
+                if wl:
+                    nl = sum(kernels[k]['launches'] for k in wl) // a.steps
+                    out['algorithm'] = ('3x3 / stride 1 trunk layers in the Winograd F(4x4, 3x3) form (%d GEMM launches per step, csrc/winograd.hip); '
+                                        'model_tflops / model_mfma_frac price the step by the direct-convolution FLOPs of SURVEY.md 8d '
+                                        '(%.2f GFLOP per image), executed_* by the FLOPs the kernels ran' % (nl, flops_img / 1e9))
         if world == 1 and not a.no_cpu_baseline and a.mode == 'train':
             out['cpu_baseline'] = cpu_baseline(a.preset)
         else:
@@ -834,7 +852,7 @@ def main():
             try:
                 r = run_config(sub, rank, world, local)
                 out[name] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'host_issue_ms_per_step', 'steps', 'warmup', 'dtype', 'config',
-                                               'model_tflops', 'model_mfma_frac', 'roofline', 'kernel_ms_sum_per_step', 'losses_check', 'self_check', 'ms_per_image')
+                                               'model_tflops', 'model_mfma_frac', 'executed_tflops', 'executed_mfma_frac', 'algorithm', 'roofline', 'kernel_ms_sum_per_step', 'losses_check', 'self_check', 'ms_per_image')
                              if k in r}
             except (Exception, SystemExit) as e:      # noqa: BLE001 -- a secondary block never costs the headline line
                 out[name] = {'error': f'{type(e).__name__}: {e}'}

@@ -859,6 +859,62 @@ int ssd_op_conv2d_first_wgrad_bf16(const float* x, const void* dy, float* dw, fl
                           weight_decay, ws, (hipStream_t)stream);
     API_END
 }
+namespace {
+struct WinoWs {      // the op-level scratch: [U][Uflip][V][Mx][Yt][Ya][slabs]
+    float *U, *Uf, *V, *Mx, *Yt, *Ya, *slabs;
+    size_t total;
+    WinoWs(const ConvDesc& d, float* ws) {
+        const size_t u = (size_t)36 * d.Ci * d.Co, t = (size_t)36 * wino_tiles(d);
+        U = ws; Uf = U + u; V = Uf + u; Mx = V + t * d.Ci; Yt = Mx + t * std::max(d.Ci, d.Co); Ya = Yt + t * d.Co; slabs = Ya + t * d.Co;
+        total = (size_t)(slabs - ws) + wino_wgrad_ws_floats(d);
+    }
+};
+}  // namespace
+size_t ssd_op_conv2d_wino_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil,
+                                    int pad_h, int pad_w) {
+    const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    return wino_applicable(d) ? WinoWs(d, nullptr).total : 0;
+}
+int ssd_op_conv2d_wino_fwd(const float* x, const float* w, const float* bias, float* y, float* y_pool, void* rec, float* ws, int flags,
+                           int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h,
+                           int pad_w, int relu, void* stream) {
+    API_BEGIN
+    const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    const WinoWs k(d, ws);
+    if (!(flags & 1)) wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    wino_fwd(d, x, k.U, bias, y, relu != 0, k.V, (size_t)wino_tiles(d) * d.Ci, k.Mx, y_pool, rec, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* mask, int accumulate, const void* rec, int uh, int uw,
+                             float* ws, int flags, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                             int dil, int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    const WinoWs k(d, ws);
+    if (!(flags & 1)) wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    wino_bwd_transform(d, dy, k.Yt, nullptr, (hipStream_t)stream);
+    wino_dgrad(d, k.Yt, k.Uf, dx, mask, accumulate != 0, k.Mx, rec, uh, uw, (hipStream_t)stream);
+    API_END
+}
+int ssd_op_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, float* dbias, const float* w, float weight_decay, float* ws,
+                             int flags, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil,
+                             int pad_h, int pad_w, void* stream) {
+    API_BEGIN
+    const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    const WinoWs k(d, ws);
+    const size_t vps = (size_t)wino_tiles(d) * d.Ci;
+    if (!(flags & 2)) {      // the input's transform: through wino_fwd's first kernel would need a filter; use the dy transform's B^T form on x
+        ConvDesc dx = d;
+        dx.Co = d.Ci; dx.Ho = d.Hi; dx.Wo = d.Wi;
+        wino_bwd_transform(dx, x, k.V, nullptr, (hipStream_t)stream);
+    }
+    wino_bwd_transform(d, dy, nullptr, k.Ya, (hipStream_t)stream);
+    wino_wgrad(d, k.V, vps, k.Ya, dw, dbias, w, weight_decay, k.slabs, (hipStream_t)stream);
+    API_END
+}
 size_t ssd_op_conv2d_wgrad_ws_floats(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
                                      int dil, int pad_h, int pad_w) {
     return conv_wgrad_ws_floats(mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w));

@@ -52,6 +52,41 @@ size_t conv_first_wgrad_f32_ws_floats(const ConvDesc& d);
 void conv_first_wgrad_f32(const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias, const float* w,
                           float weight_decay, float* ws, hipStream_t s);
 
+// ---- Round 6: Winograd F(4x4, 3x3) for the fp32 3x3 / stride 1 / SAME layers (winograd.hip) ------------------------------------------
+// Transformed tensors are position-major [36][tiles][C]; *_ps = elements between two positions (so a forward lane can own a row range
+// of a full-batch tensor).  U = the filter's transform [36][Ci][Co] (forward), Uflip = [36][Co][Ci] of the rotated filter (data gradient).
+bool wino_applicable(const ConvDesc& d);
+int wino_tiles(const ConvDesc& d);                         // B * ceil(H / 4) * ceil(W / 4)
+void wino_filter(const ConvDesc& d, const float* w, float* U, float* Uflip, hipStream_t s);      // either may be nullptr
+// every Winograd layer's filter transforms in one launch per kind (the step runs them at the start of forward, beside conv1_x)
+struct WinoFilterPlan {
+    static constexpr int MAX = 16;
+    struct Item {
+        const float* w;
+        float *U, *Uf;
+        int Ci, Co, blk0;
+    } it[MAX];
+    int n = 0, blocks = 0;
+    double elems = 0;
+    void add(const float* w, float* U, float* Uf, int Ci, int Co);
+};
+void wino_filter_plan(const WinoFilterPlan& plan, bool forward, bool flipped, hipStream_t s);
+size_t wino_fwd_ws_floats(const ConvDesc& d);              // Mws: 36 * tiles * Co
+// y = relu?(conv(x) + bias); V [36][.][Ci] receives the input's transform (kept by a training step for wino_wgrad).  y_pool != nullptr:
+// the fused 2x2 pool of conv_fwd_pool instead of y (same values, same record).
+void wino_fwd(const ConvDesc& d, const float* x, const float* U, const float* bias, float* y, bool relu, float* V, size_t v_ps,
+              float* Mws, float* y_pool, void* pool_rec, hipStream_t s);
+// dy -> Yt (B^T dy B, the data gradient's operand) and / or Ya (A dy A^T, the weight gradient's), each [36][tiles][Co]; nullptr skips one
+void wino_bwd_transform(const ConvDesc& d, const float* dy, float* Yt, float* Ya, hipStream_t s);
+size_t wino_dgrad_ws_floats(const ConvDesc& d);            // Xws: 36 * tiles * Ci
+// conv_dgrad's semantics (mask, accumulate) from the transformed dy; unpool_rec != nullptr: conv_dgrad_unpool's
+void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* dx, const float* mask, bool accumulate, float* Xws,
+                const void* unpool_rec, int UH, int UW, hipStream_t s);
+size_t wino_wgrad_ws_floats(const ConvDesc& d);
+// conv_wgrad's semantics from the forward's V and the transformed dy
+void wino_wgrad(const ConvDesc& d, const float* V, size_t v_ps, const float* Ya, float* dw, float* dbias, const float* w,
+                float weight_decay, float* ws, hipStream_t s);
+
 // ---- bf16 configuration (conv_bf16.hip): bf16 activations / gradients / filter mirrors, fp32 accumulate ----
 struct bf16_t;
 

@@ -54,6 +54,11 @@ struct Op {
     int pool_after = -1, unpool = -1;
     // head op: index of the feature map, else -1
     int head = -1;
+    // Round 6 (fp32): the Winograd F(4x4, 3x3) form of this layer's passes (net.hip plan_winograd; conv.h wino_*): forward, data
+    // gradient, weight gradient; the layer's filter transforms [36][Ci][Co] / [36][Co][Ci] and its input's transform [36][tiles][Ci]
+    // (written by forward, read by the weight gradient)
+    bool wino_f = false, wino_d = false, wino_w = false;
+    float *wino_U = nullptr, *wino_Uf = nullptr, *wino_V = nullptr;
 };
 
 struct Variable {
@@ -199,6 +204,14 @@ private:
     std::vector<char> in_wgroup_;        // ops whose weight gradient came out of this backward pass' grouped launch
     bool bw_chain_done_ = false;         // this backward pass has issued the chain's data gradients and grouped weight gradients
     void plan_tail_chain();
+    // Round 6 (fp32): Winograd layers.  Scratch shared by every such layer: the GEMM results of a forward lane (wino_m_), the
+    // transformed dy / dx of the data gradient (main stream: wino_yt_, wino_xw_), the transformed dy and the slabs of the weight
+    // gradient (weight-gradient stream: wino_ya_, wino_slab_).  One stream runs each kind in order, so one buffer per kind suffices.
+    void plan_winograd();
+    WinoFilterPlan wino_plan_;
+    bool wino_any_f_ = false, wino_any_d_ = false;
+    float *wino_m_[2] = {nullptr, nullptr}, *wino_yt_ = nullptr, *wino_xw_ = nullptr, *wino_ya_ = nullptr, *wino_slab_ = nullptr;
+    hipEvent_t ev_wino_ = nullptr;
     void launch_tail_forward(int b0, int nb, hipStream_t s);
     void launch_tail_backward(int b, bool* side_used);
     void build_orders();

@@ -530,6 +530,55 @@ void Net::launch_tail_backward(int b, bool* side_used) {
     if (wside) *side_used = true;
 }
 
+// Round 6 (fp32): which layers take the Winograd form (conv.h wino_*).  SSD_WINOGRAD = bits 0 forward / 1 data gradient / 2 weight
+// gradient (default 7; the weight gradient reads the forward's transform of the layer's input, so bit 2 needs bit 0);
+// SSD_WINO_MIN_CC = the smallest Ci * Co that takes it (default 8192: conv2_1 and up).  The transforms move 2.25x the activations per
+// pass and the 36 GEMMs have k = the channel count: conv1_2 (64 -> 64) measured 1.90 / 2.18 / 2.2 ms forward / data / weight gradient
+// against the direct kernels' 1.85 / 1.91 / 1.93 (profiles/r06_ao_per_layer_f32_wino_all.txt).  The trunk's 3x3 / stride 1 / SAME layers
+// with channel counts in multiples of 32.
+void Net::plan_winograd() {
+    if (bf16_) return;
+    const int mode = env_i("SSD_WINOGRAD", 7), min_cc = env_i("SSD_WINO_MIN_CC", 8192);
+    if (!(mode & 7)) return;
+    size_t m_max = 0, yt_max = 0, xw_max = 0, slab_max = 0;
+    for (Op& op : ops_) {
+        if (op.kind != OP_CONV || op.head >= 0) continue;
+        const ConvDesc d = conv_desc(op, Bmax_);
+        if (!wino_applicable(d) || d.Ci * d.Co < min_cc) continue;
+        op.wino_f = (mode & 1) != 0;
+        op.wino_d = (mode & 2) != 0 && training_ && op.in != input_t_;
+        op.wino_w = (mode & 4) != 0 && training_ && op.wino_f;
+        if (!(op.wino_f || op.wino_d)) continue;
+        const size_t u = (size_t)36 * d.Ci * d.Co, t = (size_t)36 * wino_tiles(d);
+        if (op.wino_f) {
+            op.wino_U = (float*)dalloc(u * sizeof(float));
+            op.wino_V = (float*)dalloc(t * d.Ci * sizeof(float));
+            m_max = std::max(m_max, t * d.Co);
+        }
+        if (op.wino_d) {
+            op.wino_Uf = (float*)dalloc(u * sizeof(float));
+            yt_max = std::max(yt_max, t * d.Co);
+            xw_max = std::max(xw_max, t * d.Ci);
+        }
+        if (op.wino_w) {
+            yt_max = std::max(yt_max, t * d.Co);
+            for (int b = 1; b <= Bmax_; ++b) slab_max = std::max(slab_max, wino_wgrad_ws_floats(conv_desc(op, b)));
+        }
+        wino_plan_.add(params_ + op.w_off, op.wino_U, op.wino_Uf, d.Ci, d.Co);
+        wino_any_f_ |= op.wino_f;
+        wino_any_d_ |= op.wino_d;
+    }
+    if (wino_plan_.n == 0) return;
+    HIP_OK(hipEventCreateWithFlags(&ev_wino_, hipEventDisableTiming));
+    if (m_max) for (int l = 0; l < 2; ++l) wino_m_[l] = (float*)dalloc(m_max * sizeof(float));
+    if (training_) {
+        wino_yt_ = (float*)dalloc(yt_max * sizeof(float));
+        wino_xw_ = (float*)dalloc(xw_max * sizeof(float));
+        wino_ya_ = (float*)dalloc(yt_max * sizeof(float));
+        wino_slab_ = (float*)dalloc(slab_max * sizeof(float));
+    }
+}
+
 void Net::pool_fusion(int* out, int cap, int* count) const {
     int k = 0;
     for (const Op& op : ops_)
@@ -734,6 +783,7 @@ Net::Net(const char* preset, int num_classes, int max_batch, int device, bool tr
     }
     plan_pool_fusion();
     plan_tail_chain();
+    plan_winograd();
     // Round 5: an event per gradient tensor (round 4: the small heads' feature maps only).  The data-gradient kernel that writes it
     // CARRIES the event (g_stop_event), and the weight-gradient stream / the other class wait for exactly that kernel: no event
     // packet between two data gradients on the main stream, none inside the side chain.  SSD_STOP_EVENTS=0: round 4's records.
@@ -759,6 +809,7 @@ Net::~Net() {
         (void)hipStreamDestroy(hstream_);
         (void)hipEventDestroy(ev_h_);
         (void)hipEventDestroy(ev_cast_);
+        if (ev_wino_) (void)hipEventDestroy(ev_wino_);
         if (!s2_is_w_) (void)hipStreamDestroy(s2_);
         (void)hipEventDestroy(ev2_h_);
         (void)hipEventDestroy(ev_l2_);
@@ -805,10 +856,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         hipEvent_t* ev_fmap;
         hipEvent_t ev_h;
         int b0, nb;
-        bool heads_on_side, cast_pending;
+        bool heads_on_side, cast_pending, wino_pending;
         bool fmap_carried[MAX_MAPS];      // the feature map's producer carried ev_fmap[head] itself (g_stop_event)
-    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false, {}},
-                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false, {}}};
+    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false, false, {}},
+                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false, false, {}}};
     // feature map tensor -> the head that reads it (-1: none), for the carried events
     auto head_of = [&](int tensor) {
         for (const Op& o : ops_)
@@ -823,6 +874,16 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         HIP_OK(hipStreamWaitEvent(hstream_, ev_fmap_[MAX_MAPS - 1], 0));
         if (nl == 2) HIP_OK(hipStreamWaitEvent(s2_, ev_fmap_[MAX_MAPS - 1], 0));
         lane[0].heads_on_side = true;
+    }
+    if (wino_plan_.n > 0) {
+        // Winograd layers (plan_winograd): the filters' transforms, fresh from the fp32 masters like the bf16 mirrors below -- two
+        // launches for all layers on the side stream, beside conv1_x; a lane's first Winograd layer waits for them
+        prof_.layer = "filters";
+        wino_filter_plan(wino_plan_, wino_any_f_, wino_any_d_ && train_mode, side ? hstream_ : stream_);
+        if (side) {
+            HIP_OK(hipEventRecord(ev_wino_, hstream_));
+            lane[0].wino_pending = lane[1].wino_pending = true;
+        }
     }
     if (bf16_) {
         // the fp32 masters may have been updated by the optimizer, a variable load or the caller (external
@@ -926,6 +987,20 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 }
                 const float* xin = reinterpret_cast<const float*>(at(in, run_b0));
                 void* yout = at(out, run_b0);
+                // Round 6: the Winograd form (plan_winograd).  A lane owns the tile rows of its images in the layer's full-batch
+                // transform V (which the weight gradient reads) and its own GEMM-result scratch.
+                const bool wino = op.wino_f && cs == ln.s;
+                float* wino_V = nullptr;
+                size_t wino_vps = 0;
+                if (wino) {
+                    if (ln.wino_pending) {
+                        HIP_OK(hipStreamWaitEvent(ln.s, ev_wino_, 0));
+                        ln.wino_pending = false;
+                    }
+                    const size_t tpi = (size_t)cdiv(d.Ho, 4) * cdiv(d.Wo, 4);
+                    wino_V = op.wino_V + (size_t)run_b0 * tpi * d.Ci;
+                    wino_vps = (size_t)b * tpi * d.Ci;
+                }
                 if (op.pool_after >= 0) {
                     // Pool fusion (round 5): this conv's epilogue takes the 2x2 maxima itself and writes the POOLED tensor (+ the
                     // pool's 12-bit record in training); its own output has no other reader -- forward or backward -- and is
@@ -934,7 +1009,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     const Tensor& pt = tensors_[pl.out];
                     void* rec = (pl.pool_rec && train_mode)
                                     ? static_cast<char*>(pl.pool_rec) + (size_t)run_b0 * pt.H * pt.W * (pt.C / 4) * sizeof(unsigned short) : nullptr;
-                    if (!bf16_)
+                    if (wino)
+                        wino_fwd(d, xin, op.wino_U, params_ + op.b_off, nullptr, true, wino_V, wino_vps, wino_m_[li],
+                                 reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
+                    else if (!bf16_)
                         conv_fwd_pool(d, xin, params_ + op.w_off, params_ + op.b_off, reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
                     else
                         conv_fwd_pool_bf16(d, reinterpret_cast<const bf16_t*>(xin), wq_oi_ + op.w_off, params_ + op.b_off,
@@ -948,7 +1026,10 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     bool* flag;
                     ~CarryScope() { if (flag) *flag = g_stop_event == nullptr; g_stop_event = nullptr; }
                 } carry_scope{fh >= 0 ? &ln.fmap_carried[fh] : nullptr};
-                if (!bf16_)
+                if (wino)
+                    wino_fwd(d, xin, op.wino_U, params_ + op.b_off, static_cast<float*>(yout), op.relu, wino_V, wino_vps, wino_m_[li],
+                             nullptr, nullptr, cs);
+                else if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
                 else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
                     conv_first_fwd_bf16(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<bf16_t*>(yout), op.relu, cs);
@@ -1044,7 +1125,12 @@ void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
     const ConvDesc d = conv_desc(op, b);
     float* slab = wgrad_ws_ + op.ws_off;
     prof_.layer = op.name.c_str();
-    if (!bf16_) {
+    if (op.wino_w) {      // Round 6: from the forward's transform of the input and the transformed dy (conv.h wino_wgrad)
+        const size_t tpi = (size_t)cdiv(d.Ho, 4) * cdiv(d.Wo, 4);
+        wino_bwd_transform(d, out.gf(), nullptr, wino_ya_, ws);
+        wino_wgrad(d, op.wino_V, (size_t)b * tpi * d.Ci, wino_ya_, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
+                   wino_slab_, ws);
+    } else if (!bf16_) {
         conv_wgrad(d, in.f(), out.gf(), grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_, slab, ws);
     } else if (in.data_f32) {   // conv1_1
         if (first_layer_kernel(d))
@@ -1175,7 +1261,11 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 }
                 g_stop_event = stop_events_ ? dst.gev : nullptr;      // the launch carries dst's event (taken by the gather launchers)
                 struct Disarm { ~Disarm() { g_stop_event = nullptr; } } disarm;      // (also when the launch throws)
-                if (!bf16_) {
+                if (op.wino_d && cls == 0) {      // Round 6: the Winograd form (its scratch belongs to the main stream)
+                    wino_bwd_transform(d, out.gf(), wino_yt_, nullptr, ds);
+                    wino_dgrad(d, wino_yt_, op.wino_Uf, up ? dst.gf() : in.gf(), mask ? in.f() : nullptr, !up && in.done > 0, wino_xw_,
+                               up ? up->pool_rec : nullptr, dst.H, dst.W, ds);
+                } else if (!bf16_) {
                     if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);
                 } else {

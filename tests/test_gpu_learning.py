@@ -8,8 +8,13 @@ channels and shifts hue / saturation.  Everything runs through the product's own
 (feeder with worker processes, StepLoop, decode + NMS of every batch from epoch 2 on, GPU APCalculator), from Xavier
 weights (there is no vgg.zip), SGD + momentum at the reference's magnitude of learning rate.
 
-Schedule: 96 steps at 3e-4, the reference's 7.5e-4 (train.py:66) until step 768, then 1e-4 -- 1280 steps at batch 32 over
-1024 training images.  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
+Schedule: 96 steps at 3e-4, then 6e-4 until step 768, then 1e-4 -- 1280 steps at batch 32 over 1024 training images.  (Rounds 4-5 ran
+the middle phase at the reference's 7.5e-4, train.py:66.  Round 6 moved the fp32 trunk to the Winograd form: another rounding, another
+step time and with it another batch order out of the feeder's workers, i.e. another trajectory of the same chaotic run -- and that one
+spiked at step ~740 (loss 3.4 -> 8.5, mAP 0.91 -> 0.0, re-learning to 0.48 by the end) while the direct kernels' run of the same
+schedule reached 1.000: profiles/r06_ar_learn_probe.txt, which also shows both forms converging at 6e-4 and 5e-4, and
+profiles/r06_aq_wino_probe.txt: at the trained state every filter gradient of the Winograd step agrees with the direct step's to
+5e-5.  The spike is the collapse the next paragraph describes, so the asserted schedule keeps 20 % of margin to it.)  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
 fp32 passes mAP 0.5 on the training sample at step ~480, 0.9 at ~670 and sits at 1.000 / 1.000 (training / held-out)
 from step ~900 on, total loss 16.5 -> 2.6 (of which 2.18 is the l2 term); bf16 follows the same curve to 0.95 at step
 ~930.  Left at 7.5e-4 or 1e-3 for thousands of steps, a run in EITHER dtype occasionally collapses (a loss spike, mAP back to
@@ -34,7 +39,7 @@ from ssd_tensorflow_amd.training_data import TrainingData
 pytestmark = pytest.mark.gpu
 
 EPOCHS, NTRAIN, NVALID, BATCH = 40, 1024, 128, 32
-LR_VALUES, LR_BOUNDARIES = '0.0003;0.00075;0.0001', '96;768'
+LR_VALUES, LR_BOUNDARIES = '0.0003;0.0006;0.0001', '96;768'
 
 
 def run_driver(tmp_path, tag, dtype, epochs=EPOCHS, augment='false', workers=4):
