@@ -864,8 +864,8 @@ struct WinoWs {      // the op-level scratch: [U][Uflip][V][Mx][Yt][Ya][slabs]
     float *U, *Uf, *V, *Mx, *Yt, *Ya, *slabs;
     size_t total;
     WinoWs(const ConvDesc& d, float* ws) {
-        const size_t u = (size_t)36 * d.Ci * d.Co, t = (size_t)36 * wino_tiles(d);
-        U = ws; Uf = U + u; V = Uf + u; Mx = V + t * d.Ci; Yt = Mx + t * std::max(d.Ci, d.Co); Ya = Yt + t * d.Co; slabs = Ya + t * d.Co;
+        const size_t cop = wino_kpad(d.Co), u = (size_t)36 * d.Ci * cop, t = (size_t)36 * wino_tiles(d);
+        U = ws; Uf = U + u; V = Uf + u; Mx = V + t * d.Ci; Yt = Mx + t * std::max((size_t)d.Ci, cop); Ya = Yt + t * cop; slabs = Ya + t * cop;
         total = (size_t)(slabs - ws) + wino_wgrad_ws_floats(d);
     }
 };
@@ -880,9 +880,12 @@ int ssd_op_conv2d_wino_fwd(const float* x, const float* w, const float* bias, fl
                            int pad_w, int relu, void* stream) {
     API_BEGIN
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
-    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4");
     const WinoWs k(d, ws);
-    if (!(flags & 1)) wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    if (!(flags & 1)) {
+        HIP_OK(hipMemsetAsync(k.Uf, 0, (size_t)36 * d.Ci * wino_kpad(d.Co) * sizeof(float), (hipStream_t)stream));      // the pad rows
+        wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    }
     wino_fwd(d, x, k.U, bias, y, relu != 0, k.V, (size_t)wino_tiles(d) * d.Ci, k.Mx, y_pool, rec, (hipStream_t)stream);
     API_END
 }
@@ -891,9 +894,12 @@ int ssd_op_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const f
                              int dil, int pad_h, int pad_w, void* stream) {
     API_BEGIN
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
-    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4");
     const WinoWs k(d, ws);
-    if (!(flags & 1)) wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    if (!(flags & 1)) {
+        HIP_OK(hipMemsetAsync(k.Uf, 0, (size_t)36 * d.Ci * wino_kpad(d.Co) * sizeof(float), (hipStream_t)stream));      // the pad rows
+        wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
+    }
     wino_bwd_transform(d, dy, k.Yt, nullptr, (hipStream_t)stream);
     wino_dgrad(d, k.Yt, k.Uf, dx, mask, accumulate != 0, k.Mx, rec, uh, uw, (hipStream_t)stream);
     API_END
@@ -903,7 +909,7 @@ int ssd_op_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, float* 
                              int pad_h, int pad_w, void* stream) {
     API_BEGIN
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
-    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32");
+    SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4");
     const WinoWs k(d, ws);
     const size_t vps = (size_t)wino_tiles(d) * d.Ci;
     if (!(flags & 2)) {      // the input's transform: through wino_fwd's first kernel would need a filter; use the dy transform's B^T form on x

@@ -56,7 +56,9 @@ void conv_first_wgrad_f32(const ConvDesc& d, const float* x, const float* dy, fl
 // Transformed tensors are position-major [36][tiles][C]; *_ps = elements between two positions (so a forward lane can own a row range
 // of a full-batch tensor).  U = the filter's transform [36][Ci][Co] (forward), Uflip = [36][Co][Ci] of the rotated filter (data gradient).
 bool wino_applicable(const ConvDesc& d);
-int wino_tiles(const ConvDesc& d);                         // B * ceil(H / 4) * ceil(W / 4)
+int wino_tiles(const ConvDesc& d);                         // B * ceil(H / 4) * ceil(W / 4) (dilation d: per residue class, see winograd.hip)
+int wino_kpad(int c);                                      // c rounded up to the GEMMs' k granularity (32): row length of the transformed dy,
+                                                           // rows per position of Uflip (pad rows / columns are zero; Uflip's are the caller's to clear once)
 void wino_filter(const ConvDesc& d, const float* w, float* U, float* Uflip, hipStream_t s);      // either may be nullptr
 // every Winograd layer's filter transforms in one launch per kind (the step runs them at the start of forward, beside conv1_x)
 struct WinoFilterPlan {
@@ -64,7 +66,7 @@ struct WinoFilterPlan {
     struct Item {
         const float* w;
         float *U, *Uf;
-        int Ci, Co, blk0;
+        int Ci, Co, Cop, blk0;
     } it[MAX];
     int n = 0, blocks = 0;
     double elems = 0;
@@ -76,7 +78,7 @@ size_t wino_fwd_ws_floats(const ConvDesc& d);              // Mws: 36 * tiles * 
 // the fused 2x2 pool of conv_fwd_pool instead of y (same values, same record).
 void wino_fwd(const ConvDesc& d, const float* x, const float* U, const float* bias, float* y, bool relu, float* V, size_t v_ps,
               float* Mws, float* y_pool, void* pool_rec, hipStream_t s);
-// dy -> Yt (B^T dy B, the data gradient's operand) and / or Ya (A dy A^T, the weight gradient's), each [36][tiles][Co]; nullptr skips one
+// dy -> Yt (B^T dy B, the data gradient's operand) and / or Ya (A dy A^T, the weight gradient's), each [36][tiles][wino_kpad(Co)]; nullptr skips one
 void wino_bwd_transform(const ConvDesc& d, const float* dy, float* Yt, float* Ya, hipStream_t s);
 size_t wino_dgrad_ws_floats(const ConvDesc& d);            // Xws: 36 * tiles * Ci
 // conv_dgrad's semantics (mask, accumulate) from the transformed dy; unpool_rec != nullptr: conv_dgrad_unpool's

@@ -210,7 +210,7 @@ private:
     void plan_winograd();
     WinoFilterPlan wino_plan_;
     bool wino_any_f_ = false, wino_any_d_ = false;
-    float *wino_m_[2] = {nullptr, nullptr}, *wino_yt_ = nullptr, *wino_xw_ = nullptr, *wino_ya_ = nullptr, *wino_slab_ = nullptr;
+    float *wino_m_[3] = {nullptr, nullptr, nullptr}, *wino_yt_ = nullptr, *wino_xw_ = nullptr, *wino_ya_ = nullptr, *wino_slab_ = nullptr;
     hipEvent_t ev_wino_ = nullptr;
     void launch_tail_forward(int b0, int nb, hipStream_t s);
     void launch_tail_backward(int b, bool* side_used);

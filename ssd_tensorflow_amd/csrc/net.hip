@@ -531,37 +531,41 @@ void Net::launch_tail_backward(int b, bool* side_used) {
 }
 
 // Round 6 (fp32): which layers take the Winograd form (conv.h wino_*).  SSD_WINOGRAD = bits 0 forward / 1 data gradient / 2 weight
-// gradient (default 7; the weight gradient reads the forward's transform of the layer's input, so bit 2 needs bit 0);
+// gradient / 3 the big maps' multibox heads too (default 15; the weight gradient reads the forward's transform of the layer's input, so bit 2 needs bit 0);
 // SSD_WINO_MIN_CC = the smallest Ci * Co that takes it (default 8192: conv2_1 and up).  The transforms move 2.25x the activations per
 // pass and the 36 GEMMs have k = the channel count: conv1_2 (64 -> 64) measured 1.90 / 2.18 / 2.2 ms forward / data / weight gradient
 // against the direct kernels' 1.85 / 1.91 / 1.93 (profiles/r06_ao_per_layer_f32_wino_all.txt).  The trunk's 3x3 / stride 1 / SAME layers
 // with channel counts in multiples of 32.
 void Net::plan_winograd() {
     if (bf16_) return;
-    const int mode = env_i("SSD_WINOGRAD", 7), min_cc = env_i("SSD_WINO_MIN_CC", 8192);
+    const int mode = env_i("SSD_WINOGRAD", 15), min_cc = env_i("SSD_WINO_MIN_CC", 8192), head_min_hw = env_i("SSD_WINO_HEAD_MIN_HW", 16);
     if (!(mode & 7)) return;
     size_t m_max = 0, yt_max = 0, xw_max = 0, slab_max = 0;
     for (Op& op : ops_) {
-        if (op.kind != OP_CONV || op.head >= 0) continue;
+        if (op.kind != OP_CONV) continue;
         const ConvDesc d = conv_desc(op, Bmax_);
         if (!wino_applicable(d) || d.Ci * d.Co < min_cc) continue;
+        // the multibox heads of the big maps (38x38 / 19x19; vgg512: 64x64 ... 16x16): below that a layer is a handful of tiles
+        // whose three launches cost more than the one they replace
+        if (op.head >= 0 && (d.Ho < head_min_hw || !(mode & 8))) continue;
         op.wino_f = (mode & 1) != 0;
         op.wino_d = (mode & 2) != 0 && training_ && op.in != input_t_;
         op.wino_w = (mode & 4) != 0 && training_ && op.wino_f;
         if (!(op.wino_f || op.wino_d)) continue;
-        const size_t u = (size_t)36 * d.Ci * d.Co, t = (size_t)36 * wino_tiles(d);
+        const size_t u = (size_t)36 * d.Ci * d.Co, uf = (size_t)36 * d.Ci * wino_kpad(d.Co), t = (size_t)36 * wino_tiles(d);
         if (op.wino_f) {
             op.wino_U = (float*)dalloc(u * sizeof(float));
             op.wino_V = (float*)dalloc(t * d.Ci * sizeof(float));
             m_max = std::max(m_max, t * d.Co);
         }
         if (op.wino_d) {
-            op.wino_Uf = (float*)dalloc(u * sizeof(float));
-            yt_max = std::max(yt_max, t * d.Co);
+            op.wino_Uf = (float*)dalloc(uf * sizeof(float));
+            HIP_OK(hipMemset(op.wino_Uf, 0, uf * sizeof(float)));      // (rows Co ... kpad(Co) - 1 of every position stay zero)
+            yt_max = std::max(yt_max, t * wino_kpad(d.Co));
             xw_max = std::max(xw_max, t * d.Ci);
         }
         if (op.wino_w) {
-            yt_max = std::max(yt_max, t * d.Co);
+            yt_max = std::max(yt_max, t * wino_kpad(d.Co));
             for (int b = 1; b <= Bmax_; ++b) slab_max = std::max(slab_max, wino_wgrad_ws_floats(conv_desc(op, b)));
         }
         wino_plan_.add(params_ + op.w_off, op.wino_U, op.wino_Uf, d.Ci, d.Co);
@@ -570,7 +574,7 @@ void Net::plan_winograd() {
     }
     if (wino_plan_.n == 0) return;
     HIP_OK(hipEventCreateWithFlags(&ev_wino_, hipEventDisableTiming));
-    if (m_max) for (int l = 0; l < 2; ++l) wino_m_[l] = (float*)dalloc(m_max * sizeof(float));
+    if (m_max) for (int l = 0; l < 3; ++l) wino_m_[l] = (float*)dalloc(m_max * sizeof(float));
     if (training_) {
         wino_yt_ = (float*)dalloc(yt_max * sizeof(float));
         wino_xw_ = (float*)dalloc(xw_max * sizeof(float));
@@ -989,15 +993,17 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 void* yout = at(out, run_b0);
                 // Round 6: the Winograd form (plan_winograd).  A lane owns the tile rows of its images in the layer's full-batch
                 // transform V (which the weight gradient reads) and its own GEMM-result scratch.
-                const bool wino = op.wino_f && cs == ln.s;
+                // (GEMM-result scratch: one per stream that runs such layers -- the lanes' main streams and the side stream of the heads)
+                float* const wino_M = cs == ln.s ? wino_m_[li] : cs == hstream_ ? wino_m_[2] : nullptr;
+                const bool wino = op.wino_f && wino_M;
                 float* wino_V = nullptr;
                 size_t wino_vps = 0;
                 if (wino) {
-                    if (ln.wino_pending) {
+                    if (cs == ln.s && ln.wino_pending) {      // (the side stream ran the filter transforms itself)
                         HIP_OK(hipStreamWaitEvent(ln.s, ev_wino_, 0));
                         ln.wino_pending = false;
                     }
-                    const size_t tpi = (size_t)cdiv(d.Ho, 4) * cdiv(d.Wo, 4);
+                    const size_t tpi = (size_t)wino_tiles(d) / d.B;
                     wino_V = op.wino_V + (size_t)run_b0 * tpi * d.Ci;
                     wino_vps = (size_t)b * tpi * d.Ci;
                 }
@@ -1010,7 +1016,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     void* rec = (pl.pool_rec && train_mode)
                                     ? static_cast<char*>(pl.pool_rec) + (size_t)run_b0 * pt.H * pt.W * (pt.C / 4) * sizeof(unsigned short) : nullptr;
                     if (wino)
-                        wino_fwd(d, xin, op.wino_U, params_ + op.b_off, nullptr, true, wino_V, wino_vps, wino_m_[li],
+                        wino_fwd(d, xin, op.wino_U, params_ + op.b_off, nullptr, true, wino_V, wino_vps, wino_M,
                                  reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
                     else if (!bf16_)
                         conv_fwd_pool(d, xin, params_ + op.w_off, params_ + op.b_off, reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
@@ -1027,7 +1033,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     ~CarryScope() { if (flag) *flag = g_stop_event == nullptr; g_stop_event = nullptr; }
                 } carry_scope{fh >= 0 ? &ln.fmap_carried[fh] : nullptr};
                 if (wino)
-                    wino_fwd(d, xin, op.wino_U, params_ + op.b_off, static_cast<float*>(yout), op.relu, wino_V, wino_vps, wino_m_[li],
+                    wino_fwd(d, xin, op.wino_U, params_ + op.b_off, static_cast<float*>(yout), op.relu, wino_V, wino_vps, wino_M,
                              nullptr, nullptr, cs);
                 else if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
@@ -1126,7 +1132,7 @@ void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
     float* slab = wgrad_ws_ + op.ws_off;
     prof_.layer = op.name.c_str();
     if (op.wino_w) {      // Round 6: from the forward's transform of the input and the transformed dy (conv.h wino_wgrad)
-        const size_t tpi = (size_t)cdiv(d.Ho, 4) * cdiv(d.Wo, 4);
+        const size_t tpi = (size_t)wino_tiles(d) / d.B;
         wino_bwd_transform(d, out.gf(), nullptr, wino_ya_, ws);
         wino_wgrad(d, op.wino_V, (size_t)b * tpi * d.Ci, wino_ya_, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
                    wino_slab_, ws);

@@ -65,30 +65,34 @@ __device__ __forceinline__ void at4(const f32x4 m0, const f32x4 m1, const f32x4 
 // AT: Va = A e A^T of the patch's inner 4x4 (rows 4i ... 4i + 3), zero outside         (weight gradient's dy)
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Va,
-                                                      int H, int W, int C, int th, int tw, int T, unsigned x_bytes, size_t v_ps,
-                                                      size_t va_ps) {
-    const int c4n = C >> 2;
+                                                      int H, int W, int C, int Cp, int th, int tw, int T, unsigned x_bytes,
+                                                      size_t v_ps, size_t va_ps, int D) {
+    // Cp >= C: row length of V / Va (a GEMM's k must be a multiple of 32: the multibox heads' 104 / 152 channels are padded with zeros)
+    const int c4n = Cp >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int q = idx % c4n, t = idx / c4n;
     if (t >= T) return;
     const int j = t % tw, t2 = t / tw;
     const int i = t2 % th, b = t2 / th;
+    // dilation D: the pixels of one residue class (h mod D, w mod D) form an image of their own that the filter walks with unit steps;
+    // tile row i = (tile of the class) * D + class.  D = 1: hb = 4 i, one class.
+    const int hb = (i % D) + D * 4 * (i / D), wb = (j % D) + D * 4 * (j / D);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
     constexpr int LO = BT ? 0 : 1, HI = BT ? 6 : 5;
     f32x4 d[6][6];
 #pragma unroll
     for (int r = LO; r < HI; ++r) {
-        const int h = 4 * i - 1 + r;
+        const int h = hb + D * (r - 1);
         const bool hv = (unsigned)h < (unsigned)H;
 #pragma unroll
         for (int s = LO; s < HI; ++s) {
-            const int w = 4 * j - 1 + s;
-            const bool ok = hv && (unsigned)w < (unsigned)W;
+            const int w = wb + D * (s - 1);
+            const bool ok = hv && (unsigned)w < (unsigned)W && q * 4 < C;
             const unsigned off = ok ? (unsigned)(((b * H + h) * W + w) * C + q * 4) * 4u : WOOB;
             d[r][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
     }
-    const size_t row = (size_t)t * C + q * 4;
+    const size_t row = (size_t)t * Cp + q * 4;
     if constexpr (AT) {
         f32x4 c[6][4];      // A e: columns first
 #pragma unroll
@@ -131,6 +135,7 @@ struct WinoOutArgs {
     const float* mask;
     int relu, accum;
     int H, W, N, th, tw, T;
+    int D;                             // dilation (MODE 0 / 1; the pool forms are D = 1)
     unsigned short* pool_rec;          // MODE 2: may be nullptr
     int PH, PW;                        // MODE 2: pooled size
     const unsigned short* unpool_rec;  // MODE 3
@@ -145,6 +150,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoOutArgs p) {
     if (t >= p.T) return;
     const int j = t % p.tw, t2 = t / p.tw;
     const int i = t2 % p.th, b = t2 / p.th;
+    const int D = (MODE == 0 || MODE == 1) ? p.D : 1;
+    const int hb = (i % D) + D * 4 * (i / D), wb = (j % D) + D * 4 * (j / D);      // (wino_in_kernel)
     const float* src = p.M + (size_t)t * p.N + q * 4;
     f32x4 c[4][6];
 #pragma unroll
@@ -178,22 +185,22 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoOutArgs p) {
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int h = 4 * i + r;
+            const int h = hb + D * r;
             if (h >= p.H) continue;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int w = 4 * j + s;
+                const int w = wb + D * s;
                 if (w < p.W) *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + h) * p.W + w) * p.N + q * 4) = o[r][s];
             }
         }
     } else if constexpr (MODE == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int h = 4 * i + r;
+            const int h = hb + D * r;
             if (h >= p.H) continue;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int w = 4 * j + s;
+                const int w = wb + D * s;
                 if (w >= p.W) continue;
                 const size_t e0 = ((size_t)(b * p.H + h) * p.W + w) * p.N + q * 4;
                 f32x4 v = o[r][s];
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(WinoFilterPlan plan) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) c[k][b] = u[k];
     }
-    const size_t ps = (size_t)Ci * Co;
+    const size_t ps = FLIP ? (size_t)plan.it[li].Cop * Ci : (size_t)Ci * Co;      // (the flipped form has Cop >= Co rows; the pad rows stay zero)
     const size_t e = FLIP ? (size_t)co * Ci + ci : (size_t)ci * Co + co;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -441,6 +448,7 @@ struct WinoTnArgs {
     const float* Y;      // Ya  [36][.][Co]
     float* ws;           // [nsplit][36 * Ci * Co + Co]
     int T, Ci, Co;
+    int x_ld, y_ld;      // row lengths of X / Y (>= Ci / Co)
     size_t x_ps, y_ps;
     int CT, NT, tchunk, nsplit;
 };
@@ -471,19 +479,19 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(WinoTnArgs p) {
     const bool do_bias = pos == 7 && ct == 0;
 
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (size_t)pos * p.x_ps), 0,
-                                                                           (unsigned)((size_t)tend * p.Ci * 4u), 0x00020000);
+                                                                           (unsigned)((size_t)tend * p.x_ld * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (size_t)pos * p.y_ps), 0,
-                                                                           (unsigned)((size_t)tend * p.Co * 4u), 0x00020000);
+                                                                           (unsigned)((size_t)tend * p.y_ld * 4u), 0x00020000);
     const int xr = tid / XC, xc = tid % XC, yr = tid / YC, yc = tid % YC;
     const bool xcv = c0 + xc * 4 < p.Ci, ycv = n0 + yc * 4 < p.Co;
     unsigned xoff[X_N], yoff[Y_N];
     // rows at or past tend fall outside the descriptor (its size ends at row tend): zeros, no per-iteration test.  The offsets
     // advance in the VECTOR offset, which is what the descriptor's range check sees.
 #pragma unroll
-    for (int j = 0; j < X_N; ++j) xoff[j] = xcv ? (unsigned)(((tbeg + xr + j * XRPP) * p.Ci + c0 + xc * 4) * 4) : WOOB;
+    for (int j = 0; j < X_N; ++j) xoff[j] = xcv ? (unsigned)(((tbeg + xr + j * XRPP) * p.x_ld + c0 + xc * 4) * 4) : WOOB;
 #pragma unroll
-    for (int j = 0; j < Y_N; ++j) yoff[j] = ycv ? (unsigned)(((tbeg + yr + j * YRPP) * p.Co + n0 + yc * 4) * 4) : WOOB;
-    const unsigned xadv = xcv ? (unsigned)(BP * p.Ci * 4) : 0u, yadv = ycv ? (unsigned)(BP * p.Co * 4) : 0u;
+    for (int j = 0; j < Y_N; ++j) yoff[j] = ycv ? (unsigned)(((tbeg + yr + j * YRPP) * p.y_ld + n0 + yc * 4) * 4) : WOOB;
+    const unsigned xadv = xcv ? (unsigned)(BP * p.x_ld * 4) : 0u, yadv = ycv ? (unsigned)(BP * p.y_ld * 4) : 0u;
     auto issue = [&](int it, int stage) {
         unsigned char* Xs = lds + stage * STAGE + wave * 1024;
         unsigned char* Ys = lds + stage * STAGE + X_BYTES + wave * 1024;
@@ -615,19 +623,22 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 // =====================================================================================================================================
 // host side
 // =====================================================================================================================================
+// tiles along an axis of n pixels: each of the `dil` residue classes has ceil(n / dil) pixels = ceil(that / 4) tiles
+static int tiles_1d(int n, int dil) { return dil * cdiv(cdiv(n, dil), 4); }
 bool wino_applicable(const ConvDesc& d) {
-    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil == 1 && d.pad_h == 1 && d.pad_w == 1 && d.Ho == d.Hi && d.Wo == d.Wi &&
-           d.Ci % 32 == 0 && d.Co % 32 == 0 && wino_tiles(d) >= 1 &&
-           (long long)wino_tiles(d) * std::max(d.Ci, d.Co) < (1LL << 30) - 4 &&        // 32-bit byte offsets inside one position
+    return d.KH == 3 && d.KW == 3 && d.stride == 1 && d.dil >= 1 && d.pad_h == d.dil && d.pad_w == d.dil && d.Ho == d.Hi && d.Wo == d.Wi &&
+           d.Ci % 32 == 0 && d.Co % 4 == 0 && wino_tiles(d) >= 1 &&
+           (long long)wino_tiles(d) * std::max(d.Ci, wino_kpad(d.Co)) < (1LL << 30) - 4 &&        // 32-bit byte offsets inside one position
            (long long)d.B * d.Hi * d.Wi * std::max(d.Ci, d.Co) < (1LL << 30) - 4;
 }
-int wino_tiles(const ConvDesc& d) { return d.B * cdiv(d.Ho, 4) * cdiv(d.Wo, 4); }
+int wino_kpad(int c) { return (c + 31) / 32 * 32; }
+int wino_tiles(const ConvDesc& d) { return d.B * tiles_1d(d.Ho, d.dil) * tiles_1d(d.Wo, d.dil); }
 
-static void require(const ConvDesc& d) { SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers with channel counts in multiples of 32"); }
+static void require(const ConvDesc& d) { SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4"); }
 
 void WinoFilterPlan::add(const float* w, float* U, float* Uf, int Ci, int Co) {
     SSD_REQUIRE(n < MAX, "winograd: more than %d layers in one filter plan", MAX);
-    it[n] = Item{w, U, Uf, Ci, Co, blocks};
+    it[n] = Item{w, U, Uf, Ci, Co, wino_kpad(Co), blocks};
     blocks += cdiv((long long)Ci * Co, 256);
     elems += (double)Ci * Co;
     ++n;
@@ -653,20 +664,20 @@ void wino_filter(const ConvDesc& d, const float* w, float* U, float* Uflip, hipS
 }
 
 // x [B][H][W][C] -> V (B^T d B) and / or Va (A e A^T), both [36][.][C] with v_ps / va_ps elements between positions
-static void launch_in(const float* x, float* V, float* Va, int B, int H, int W, int C, size_t v_ps, size_t va_ps, hipStream_t s) {
-    const int th = cdiv(H, 4), tw = cdiv(W, 4), T = B * th * tw;
+static void launch_in(const float* x, float* V, float* Va, int B, int H, int W, int C, int Cp, int D, size_t v_ps, size_t va_ps, hipStream_t s) {
+    const int th = tiles_1d(H, D), tw = tiles_1d(W, D), T = B * th * tw;
     const unsigned xb = (unsigned)((size_t)B * H * W * C * 4u);
-    const int grid = cdiv((long long)T * (C / 4), 256);
-    const double by = 4.0 * ((double)B * H * W * C + 36.0 * T * C * ((V ? 1 : 0) + (Va ? 1 : 0)));
+    const int grid = cdiv((long long)T * (Cp / 4), 256);
+    const double by = 4.0 * ((double)B * H * W * C + 36.0 * T * Cp * ((V ? 1 : 0) + (Va ? 1 : 0)));
     if (V && Va) {
         ProfScope prof("wino_in_dual", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<true, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, th, tw, T, xb, v_ps, va_ps);
+        hipLaunchKernelGGL((wino_in_kernel<true, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
     } else if (V) {
         ProfScope prof("wino_in", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<true, false>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, th, tw, T, xb, v_ps, va_ps);
+        hipLaunchKernelGGL((wino_in_kernel<true, false>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
     } else {
         ProfScope prof("wino_in_wgrad", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<false, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, th, tw, T, xb, v_ps, va_ps);
+        hipLaunchKernelGGL((wino_in_kernel<false, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
     }
     HIP_OK(hipGetLastError());
 }
@@ -715,13 +726,14 @@ void wino_fwd(const ConvDesc& d, const float* x, const float* U, const float* bi
               float* Mws, float* y_pool, void* pool_rec, hipStream_t s) {
     require(d);
     const int T = wino_tiles(d);
-    launch_in(x, V, nullptr, d.B, d.Hi, d.Wi, d.Ci, v_ps, 0, s);
+    launch_in(x, V, nullptr, d.B, d.Hi, d.Wi, d.Ci, d.Ci, d.dil, v_ps, 0, s);
     gemm_nn(V, v_ps, U, Mws, (size_t)T * d.Co, T, d.Co, d.Ci, s);
     WinoOutArgs a{};
     a.M = Mws; a.m_ps = (size_t)T * d.Co; a.bias = bias; a.relu = relu; a.H = d.Ho; a.W = d.Wo; a.N = d.Co;
-    a.th = cdiv(d.Ho, 4); a.tw = cdiv(d.Wo, 4); a.T = T;
+    a.th = tiles_1d(d.Ho, d.dil); a.tw = tiles_1d(d.Wo, d.dil); a.T = T; a.D = d.dil;
     const double mb = 4.0 * 36 * T * d.Co;
     if (y_pool) {
+        SSD_REQUIRE(d.dil == 1, "winograd: the fused pool is for undilated layers");
         a.y = y_pool; a.pool_rec = static_cast<unsigned short*>(pool_rec); a.PH = (d.Ho + 1) / 2; a.PW = (d.Wo + 1) / 2;
         launch_out<2>(a, "wino_out_pool", mb + 4.0 * d.B * a.PH * a.PW * d.Co, s);
     } else {
@@ -734,20 +746,21 @@ size_t wino_dgrad_ws_floats(const ConvDesc& d) { return (size_t)36 * wino_tiles(
 
 void wino_bwd_transform(const ConvDesc& d, const float* dy, float* Yt, float* Ya, hipStream_t s) {
     require(d);
-    const size_t ps = (size_t)wino_tiles(d) * d.Co;
-    launch_in(dy, Yt, Ya, d.B, d.Ho, d.Wo, d.Co, ps, ps, s);
+    const size_t ps = (size_t)wino_tiles(d) * wino_kpad(d.Co);
+    launch_in(dy, Yt, Ya, d.B, d.Ho, d.Wo, d.Co, wino_kpad(d.Co), d.dil, ps, ps, s);
 }
 
 void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* dx, const float* mask, bool accumulate, float* Xws,
                 const void* unpool_rec, int UH, int UW, hipStream_t s) {
     require(d);
     const int T = wino_tiles(d);
-    gemm_nn(Yt, (size_t)T * d.Co, Uflip, Xws, (size_t)T * d.Ci, T, d.Ci, d.Co, s);
+    gemm_nn(Yt, (size_t)T * wino_kpad(d.Co), Uflip, Xws, (size_t)T * d.Ci, T, d.Ci, wino_kpad(d.Co), s);
     WinoOutArgs a{};
     a.M = Xws; a.m_ps = (size_t)T * d.Ci; a.y = dx; a.mask = mask; a.accum = accumulate; a.H = d.Hi; a.W = d.Wi; a.N = d.Ci;
-    a.th = cdiv(d.Hi, 4); a.tw = cdiv(d.Wi, 4); a.T = T;
+    a.th = tiles_1d(d.Hi, d.dil); a.tw = tiles_1d(d.Wi, d.dil); a.T = T; a.D = d.dil;
     const double mb = 4.0 * 36 * T * d.Ci;
     if (unpool_rec) {
+        SSD_REQUIRE(d.dil == 1, "winograd: the un-pooling form is for undilated layers");
         a.unpool_rec = static_cast<const unsigned short*>(unpool_rec); a.UH = UH; a.UW = UW;
         launch_out<3>(a, "wino_out_unpool", mb + 4.0 * d.B * UH * UW * d.Ci, s);
     } else {
@@ -781,7 +794,8 @@ void wino_wgrad(const ConvDesc& d, const float* V, size_t v_ps, const float* Ya,
     require(d);
     const int T = wino_tiles(d);
     WinoTnArgs a{};
-    a.X = V; a.Y = Ya; a.ws = ws; a.T = T; a.Ci = d.Ci; a.Co = d.Co; a.x_ps = v_ps; a.y_ps = (size_t)T * d.Co;
+    a.X = V; a.Y = Ya; a.ws = ws; a.T = T; a.Ci = d.Ci; a.Co = d.Co; a.x_ps = v_ps; a.y_ps = (size_t)T * wino_kpad(d.Co);
+    a.x_ld = d.Ci; a.y_ld = wino_kpad(d.Co);
     a.CT = cdiv(d.Ci, 128); a.NT = cdiv(d.Co, 128);
     a.nsplit = tn_splits(d);
     a.tchunk = cdiv(cdiv(T, a.nsplit), 32) * 32;

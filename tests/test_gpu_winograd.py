@@ -22,6 +22,14 @@ CASES = [
     ('conv2_1-like 150x150 64->128', 1, 150, 150, 64, 128),
     ('tiny 3x2 32->32 b5 (one tile per image)', 5, 3, 2, 32, 32),
     ('exact tiles 8x12 128->96', 2, 8, 12, 128, 96),
+    # dilated (a-trous, ssdvgg.py:260-262): every residue class (h mod 6, w mod 6) is an image of its own, one tile each at 19x19
+    ('mod_conv6 dil 6 19x19 256->512', 2, 19, 19, 256, 512, 6),
+    ('mod_conv6 of vgg512: dil 6 32x32 128->256 (two tiles per class)', 1, 32, 32, 128, 256, 6),
+    ('dil 2 odd 13x9 64->64', 3, 13, 9, 64, 64, 2),
+    # the multibox heads' channel counts (4 / 6 boxes x 25, padded to 104 / 152): the data gradient's k is padded to 128 / 160 with zeros
+    ('head map0-like 38x38 256->104', 1, 38, 38, 256, 104),
+    ('head map1-like 19x19 512->152 b2', 2, 19, 19, 512, 152),
+    ('12 output channels 9x9 32->12', 2, 9, 9, 32, 12),
 ]
 
 
@@ -30,13 +38,13 @@ def raw(t):
     return t.cpu().numpy().view(np.uint8 if t.dtype != torch.float32 else np.uint32)
 
 
-def _run(name, b, h, w, ci, co, relu=True):
+def _run(name, b, h, w, ci, co, dil=1, relu=True):
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     x = np.maximum(rng.normal(0, 1, (b, h, w, ci)), 0).astype(np.float32)
     wt = (rng.normal(0, 1, (3, 3, ci, co)) / np.sqrt(9 * ci)).astype(np.float32)
     bias = rng.normal(0, 0.1, (co,)).astype(np.float32)
     dy = rng.normal(0, 1, (b, h, w, co)).astype(np.float32)
-    xt, wtt, bt, pre, y_ref = oracle_conv(x, wt, bias, 1, 1, 'SAME', relu)
+    xt, wtt, bt, pre, y_ref = oracle_conv(x, wt, bias, 1, dil, 'SAME', relu)
     g = torch.tensor(dy).permute(0, 3, 1, 2)
     gpre = g * (pre > 0).float() if relu else g
     pre.backward(gpre)
@@ -44,7 +52,7 @@ def _run(name, b, h, w, ci, co, relu=True):
     dw_ref, db_ref = wtt.grad.numpy(), bt.grad.numpy()
     dy_pre = gpre.permute(0, 2, 3, 1).contiguous().numpy()
 
-    geom = (b, h, w, ci, h, w, co, 3, 3, 1, 1, 1, 1)
+    geom = (b, h, w, ci, h, w, co, 3, 3, 1, dil, dil, dil)
     nws = lib.ssd_op_conv2d_wino_ws_floats(*geom)
     assert nws > 0
     ws_ = torch.empty((nws,), dtype=torch.float32, device='cuda')
@@ -91,6 +99,15 @@ def test_winograd_fwd_dgrad_wgrad(case):
 
 def test_winograd_no_relu():
     _run('no relu 10x10 64->64', 2, 10, 10, 64, 64, relu=False)
+
+
+def test_winograd_fused_pool_refuses_dilation():
+    geom = (1, 8, 8, 32, 8, 8, 32, 3, 3, 1, 2, 2, 2)
+    ws_ = torch.empty((lib.ssd_op_conv2d_wino_ws_floats(*geom),), dtype=torch.float32, device='cuda')
+    t = torch.zeros((1, 8, 8, 32), dtype=torch.float32, device='cuda')
+    w_ = torch.zeros((3, 3, 32, 32), dtype=torch.float32, device='cuda')
+    rc = lib.ssd_op_conv2d_wino_fwd(ptr(t), ptr(w_), None, None, ptr(t), None, ptr(ws_), 0, *geom, 1, None)
+    assert rc != 0 and b'undilated' in lib.ssd_last_error()
 
 
 POOL_CASES = [
@@ -152,10 +169,12 @@ def test_winograd_fused_pool_bit_identical_to_the_pooling_passes(case):
 
 
 def test_winograd_refuses_other_shapes():
-    # stride 2, dilation, 1x1, channels not in multiples of 32: not this algorithm's
+    # stride 2, VALID padding, 1x1, input channels not in multiples of 32 / output channels not of 4: not this algorithm's
     assert lib.ssd_op_conv2d_wino_ws_floats(2, 19, 19, 256, 10, 10, 512, 3, 3, 2, 1, 0, 0) == 0
-    assert lib.ssd_op_conv2d_wino_ws_floats(2, 19, 19, 512, 19, 19, 1024, 3, 3, 1, 6, 6, 6) == 0
+    assert lib.ssd_op_conv2d_wino_ws_floats(2, 5, 5, 128, 3, 3, 256, 3, 3, 1, 1, 0, 0) == 0
+    assert lib.ssd_op_conv2d_wino_ws_floats(2, 19, 19, 512, 19, 19, 1024, 3, 3, 1, 6, 6, 6) > 0
     assert lib.ssd_op_conv2d_wino_ws_floats(2, 19, 19, 1024, 19, 19, 1024, 1, 1, 1, 1, 0, 0) == 0
-    assert lib.ssd_op_conv2d_wino_ws_floats(2, 38, 38, 512, 38, 38, 100, 3, 3, 1, 1, 1, 1) == 0
-    rc = lib.ssd_op_conv2d_wino_fwd(None, None, None, None, None, None, None, 0, 2, 38, 38, 512, 38, 38, 100, 3, 3, 1, 1, 1, 1, 1, None)
+    assert lib.ssd_op_conv2d_wino_ws_floats(2, 38, 38, 100, 38, 38, 512, 3, 3, 1, 1, 1, 1) == 0
+    assert lib.ssd_op_conv2d_wino_ws_floats(2, 38, 38, 512, 38, 38, 102, 3, 3, 1, 1, 1, 1) == 0
+    rc = lib.ssd_op_conv2d_wino_fwd(None, None, None, None, None, None, None, 0, 2, 38, 38, 100, 38, 38, 512, 3, 3, 1, 1, 1, 1, 1, None)
     assert rc != 0 and b'winograd' in lib.ssd_last_error()

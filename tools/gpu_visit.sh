@@ -1,10 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06ar
+TAG=r06at
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-for lr in 0.00075 0.0006 0.0005; do
-  timeout 300 python tools/learn_probe.py f32 "0.0003;$lr;0.0001" "96;768" 2>&1 | grep -v "amdgpu.ids" | tail -4 | tee -a $O/learn_probe.txt
-done
-SSD_WINOGRAD=0 timeout 300 python tools/learn_probe.py f32 "0.0003;0.00075;0.0001" "96;768" 2>&1 | grep -v "amdgpu.ids" | tail -4 | tee -a $O/learn_probe.txt
-SSD_WINOGRAD=0 timeout 300 python tools/learn_probe.py f32 "0.0003;0.0006;0.0001" "96;768" 2>&1 | grep -v "amdgpu.ids" | tail -4 | tee -a $O/learn_probe.txt
+timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider --durations=8 2>&1 | grep -v amdgpu.ids | tail -25 | tee $O/gpu_tests.log
+python bench.py --no-secondary --no-cpu-baseline --per-layer > $O/bench_f32.json 2> $O/per_layer_f32.txt; tail -c 1200 $O/bench_f32.json
