@@ -532,13 +532,14 @@ void Net::launch_tail_backward(int b, bool* side_used) {
 
 // Round 6 (fp32): which layers take the Winograd form (conv.h wino_*).  SSD_WINOGRAD = bits 0 forward / 1 data gradient / 2 weight
 // gradient / 3 the big maps' multibox heads too (default 15; the weight gradient reads the forward's transform of the layer's input, so bit 2 needs bit 0);
-// SSD_WINO_MIN_CC = the smallest Ci * Co that takes it (default 8192: conv2_1 and up).  The transforms move 2.25x the activations per
-// pass and the 36 GEMMs have k = the channel count: conv1_2 (64 -> 64) measured 1.90 / 2.18 / 2.2 ms forward / data / weight gradient
-// against the direct kernels' 1.85 / 1.91 / 1.93 (profiles/r06_ao_per_layer_f32_wino_all.txt).  The trunk's 3x3 / stride 1 / SAME layers
-// with channel counts in multiples of 32.
+// SSD_WINO_MIN_CC = the smallest Ci * Co that takes it (default 4096: conv1_2 and up).  The transforms move 2.25x the activations per
+// pass and the 36 GEMMs have k = the channel count: at 64 -> 64 channels they are HBM-bound (16 FLOP per byte), and only with 64-wide
+// tiles does conv1_2 beat its direct kernels -- 1.55 / 1.65 / 1.14 ms forward / data / weight gradient against 1.95 / 1.91 / 2.04
+// (profiles/r06_aw_bench_conv_narrow_tiles.txt; with 128-wide tiles, half of them zeros: 1.90 / 2.18 / 2.2,
+// profiles/r06_ao_per_layer_f32_wino_all.txt).  The trunk's 3x3 / stride 1 / SAME layers with Ci in multiples of 32.
 void Net::plan_winograd() {
     if (bf16_) return;
-    const int mode = env_i("SSD_WINOGRAD", 15), min_cc = env_i("SSD_WINO_MIN_CC", 8192), head_min_hw = env_i("SSD_WINO_HEAD_MIN_HW", 16);
+    const int mode = env_i("SSD_WINOGRAD", 15), min_cc = env_i("SSD_WINO_MIN_CC", 4096), head_min_hw = env_i("SSD_WINO_HEAD_MIN_HW", 16);
     if (!(mode & 7)) return;
     size_t m_max = 0, yt_max = 0, xw_max = 0, slab_max = 0;
     for (Op& op : ops_) {

@@ -594,12 +594,23 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     f32x4 c[3][6];
 #pragma unroll
     for (int l = 0; l < 6; ++l) {
+        // a column's six positions x four slabs = 24 loads in flight, added in slab order
         f32x4 s[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < nsplit; ++sp) a += *reinterpret_cast<const f32x4*>(ws + (size_t)sp * stride + (size_t)(k * 6 + l) * cc + e);
-            s[k] = a;
+        for (int k = 0; k < 6; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp0 = 0; sp0 < nsplit; sp0 += 4) {
+            f32x4 v[6][4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[k][u] = *reinterpret_cast<const f32x4*>(ws + (size_t)min(sp0 + u, nsplit - 1) * stride + (size_t)(k * 6 + l) * cc + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sp0 + u < nsplit) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s[k] += v[k][u];
+                }
         }
         f32x4 g[3];
         gt3(s[0], s[1], s[2], s[3], s[4], s[5], g);
@@ -704,6 +715,7 @@ static void gemm_nn(const float* A, size_t a_ps, const float* Bm, float* C, size
     // 128 x 128 unless its last row of tiles would be mostly empty (19 x 19 maps: 800 tiles at batch 32)
     int cfg = 0;
     if (forced >= 0) cfg = forced;
+    else if (N <= 64) cfg = 1;      // (a 128-wide n tile would multiply 64 columns of zeros)
     else if ((double)cdiv(M, 128) * 128 > 1.06 * M && (double)cdiv(M, 64) * 64 < (double)cdiv(M, 128) * 128) cfg = 2;
     switch (cfg) {
     case 0: launch_nn<2, 2, 2, 2>(a, "wino_gemm_128x128", s); break;
@@ -771,23 +783,45 @@ void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* d
 // ---- weight gradient ------------------------------------------------------------------------------------------------------------------
 // Splits of T: the launch should be a whole number of rounds of the chip's 512 workgroup slots (two 64 KB workgroups per CU) and every
 // slab costs a write + a read of 36 Ci Co floats; modelled in microseconds, the cheapest of 1 ... 16 splits wins.
+// tile of the weight-gradient GEMMs: 128 x 128 unless a channel count is 64 or less
+static void tn_tile(const ConvDesc& d, int* bk, int* bn) {
+    *bk = d.Ci <= 64 ? 64 : 128;
+    *bn = d.Co <= 64 ? 64 : 128;
+}
 static int tn_splits(const ConvDesc& d) {
     static const int forced = env_int("SSD_WINO_SPLITS", 0);
     const int T = wino_tiles(d);
     if (forced > 0) return std::min(forced, std::max(1, T / 32));
-    const int base = 36 * cdiv(d.Ci, 128) * cdiv(d.Co, 128);
+    int bk, bn;
+    tn_tile(d, &bk, &bn);
+    const int base = 36 * cdiv(d.Ci, bk) * cdiv(d.Co, bn);
+    const double slots = 256.0 * std::min(8, (int)(160 * 1024 / (2 * 32 * (bk + bn) * 4)));      // co-resident workgroups of the chip
+    const double it_us = 3.4 * (bk * bn) / (128.0 * 128.0) * slots / 512.0;                     // one 32-row step of every resident workgroup
     int best = 1;
     double bc = 1e300;
     for (int ns = 1; ns <= 16; ++ns) {
         const int chunk = cdiv(cdiv(T, ns), 32) * 32;
         if (ns > 1 && chunk < 128) break;
-        const double rounds = std::ceil((double)base * ns / 512.0);
-        const double cost = rounds * (chunk / 32) * 3.4 + (ns > 1 ? 2.0 * ns * 36.0 * d.Ci * d.Co * 4.0 / 4.0e6 : 0.0);
+        const double rounds = std::ceil((double)base * ns / slots);
+        const double cost = rounds * (chunk / 32) * it_us + (ns > 1 ? 2.0 * ns * 36.0 * d.Ci * d.Co * 4.0 / 4.0e6 : 0.0);
         if (cost < bc) { bc = cost; best = ns; }
     }
     return best;
 }
 size_t wino_wgrad_ws_floats(const ConvDesc& d) { return (size_t)tn_splits(d) * ((size_t)36 * d.Ci * d.Co + d.Co); }
+
+template <int WM, int WN, int TM, int TN>
+static void launch_tn(WinoTnArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
+    constexpr int BKT = 32 * TM * WM, BNT = 32 * TN * WN;
+    constexpr size_t lds = 2 * (size_t)32 * (BKT + BNT) * 4;
+    auto kern = wino_gemm_tn_kernel<WM, WN, TM, TN>;
+    static bool once = (set_lds(kern, lds), true);
+    (void)once;
+    a.CT = cdiv(a.Ci, BKT); a.NT = cdiv(a.Co, BNT);
+    ProfScope prof(label, flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(36 * a.CT * a.NT * a.nsplit), dim3(256), lds, s, a);
+    HIP_OK(hipGetLastError());
+}
 
 void wino_wgrad(const ConvDesc& d, const float* V, size_t v_ps, const float* Ya, float* dw, float* dbias, const float* w,
                 float weight_decay, float* ws, hipStream_t s) {
@@ -796,21 +830,17 @@ void wino_wgrad(const ConvDesc& d, const float* V, size_t v_ps, const float* Ya,
     WinoTnArgs a{};
     a.X = V; a.Y = Ya; a.ws = ws; a.T = T; a.Ci = d.Ci; a.Co = d.Co; a.x_ps = v_ps; a.y_ps = (size_t)T * wino_kpad(d.Co);
     a.x_ld = d.Ci; a.y_ld = wino_kpad(d.Co);
-    a.CT = cdiv(d.Ci, 128); a.NT = cdiv(d.Co, 128);
     a.nsplit = tn_splits(d);
     a.tchunk = cdiv(cdiv(T, a.nsplit), 32) * 32;
     a.nsplit = cdiv(T, a.tchunk);      // (rounding the chunk up to whole iterations may empty the last split)
     SSD_REQUIRE((size_t)a.nsplit <= (size_t)tn_splits(d), "winograd: split plan");
-    {
-        constexpr size_t lds = 2 * (size_t)32 * (128 + 128) * 4;
-        auto kern = wino_gemm_tn_kernel<2, 2, 2, 2>;
-        static bool once = (set_lds(kern, lds), true);
-        (void)once;
-        ProfScope prof("wino_gemm_tn_128x128", 2.0 * 36 * T * (double)d.Ci * d.Co,
-                       4.0 * 36 * ((double)T * (d.Ci + d.Co) + (double)a.nsplit * d.Ci * d.Co), s);
-        hipLaunchKernelGGL(kern, dim3(36 * a.CT * a.NT * a.nsplit), dim3(256), lds, s, a);
-        HIP_OK(hipGetLastError());
-    }
+    const double fl = 2.0 * 36 * T * (double)d.Ci * d.Co, by = 4.0 * 36 * ((double)T * (d.Ci + d.Co) + (double)a.nsplit * d.Ci * d.Co);
+    int bk, bn;
+    tn_tile(d, &bk, &bn);
+    if (bk == 128 && bn == 128) launch_tn<2, 2, 2, 2>(a, "wino_gemm_tn_128x128", fl, by, s);
+    else if (bk == 64 && bn == 128) launch_tn<2, 2, 1, 2>(a, "wino_gemm_tn_64x128", fl, by, s);
+    else if (bk == 128 && bn == 64) launch_tn<4, 1, 1, 2>(a, "wino_gemm_tn_128x64", fl, by, s);
+    else launch_tn<2, 2, 1, 1>(a, "wino_gemm_tn_64x64", fl, by, s);
     {
         const int n = d.Ci * (d.Co / 4) + d.Co / 4;
         ProfScope prof("wino_wgrad_reduce", 0, 4.0 * ((double)a.nsplit * 36 + 18) * d.Ci * d.Co, s);
