@@ -70,6 +70,14 @@ KERNEL_SYMBOLS = {
     'conv_fwd_pool_bf16_c64': ['conv_fwd_pool_bf16_c64_kernel'], 'conv_fwd_pool_bf16_rows_256x128': ['conv_fwd_pool_bf16_rows_kernel'],
     'conv_dgrad_unpool_bf16_rows_256x128': ['conv_gather_bf16_rows_kernel<1, 4'], 'conv_dgrad_unpool_bf16_rows_128x128': ['conv_gather_bf16_rows_kernel<1, 2, 2'],
     'conv_dgrad_unpool_bf16_256x64_8w': _gbf(1, 8, 1, 1, 2), 'conv_dgrad_unpool_bf16_128x64': _gbf(1, 4, 1, 1, 2),
+    # round 6: the Winograd F(4x4, 3x3) kernels of the fp32 trunk (csrc/winograd.hip)
+    'wino_gemm_128x128': ['wino_gemm_nn_kernel<2, 2, 2, 2>'], 'wino_gemm_128x64': ['wino_gemm_nn_kernel<4, 1, 1, 2>'],
+    'wino_gemm_64x128': ['wino_gemm_nn_kernel<2, 2, 1, 2>'], 'wino_gemm_64x64': ['wino_gemm_nn_kernel<2, 2, 1, 1>'],
+    'wino_gemm_tn_128x128': ['wino_gemm_tn_kernel<2, 2, 2, 2>'], 'wino_gemm_tn_64x128': ['wino_gemm_tn_kernel<2, 2, 1, 2>'],
+    'wino_gemm_tn_128x64': ['wino_gemm_tn_kernel<4, 1, 1, 2>'], 'wino_gemm_tn_64x64': ['wino_gemm_tn_kernel<2, 2, 1, 1>'],
+    'wino_in': ['wino_in_kernel<true, false>'], 'wino_in_wgrad': ['wino_in_kernel<false, true>'], 'wino_in_dual': ['wino_in_kernel<true, true>'],
+    'wino_out': ['wino_out_kernel<0>'], 'wino_out_dgrad': ['wino_out_kernel<1>'], 'wino_out_pool': ['wino_out_kernel<2>'], 'wino_out_unpool': ['wino_out_kernel<3>'],
+    'wino_wgrad_reduce': ['wino_wgrad_reduce_kernel'], 'wino_filter': ['wino_filter_kernel<false>'], 'wino_filter_flip': ['wino_filter_kernel<true>'],
     'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'],
     'multibox_loss': ['heads_kernel<true>'], 'multibox_loss_grad': ['loss_grad_kernel<'], 'heads_result': ['heads_kernel<false>'],
     'conv_fwd_bf16_128x128': _gbf(0, 2, 2, 2, 2), 'conv_fwd_bf16_128x64': _gbf(0, 4, 1, 1, 2),
