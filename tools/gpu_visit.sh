@@ -1,7 +1,6 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06ax
+TAG=r06az
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 2>&1 | grep -v amdgpu.ids | tail -14 | tee $O/gpu_tests.log
-python bench.py --no-secondary --no-cpu-baseline --per-layer > $O/bench_f32.json 2> $O/per_layer_f32.txt; tail -c 600 $O/bench_f32.json
+bash tools/ab_variants.sh "$O/ab_wino_phase_f32.txt" 3 f32 "base:SSD_X=0" "fw_phase:SSD_WINO_FW_PHASE=1" "bw_phase:SSD_WINO_BW_PHASE=1" "both:SSD_WINO_FW_PHASE=1 SSD_WINO_BW_PHASE=1"
