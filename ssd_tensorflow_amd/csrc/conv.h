@@ -62,7 +62,7 @@ int wino_kpad(int c);                                      // c rounded up to th
 void wino_filter(const ConvDesc& d, const float* w, float* U, float* Uflip, hipStream_t s);      // either may be nullptr
 // every Winograd layer's filter transforms in one launch per kind (the step runs them at the start of forward, beside conv1_x)
 struct WinoFilterPlan {
-    static constexpr int MAX = 16;
+    static constexpr int MAX = 24;
     struct Item {
         const float* w;
         float *U, *Uf;

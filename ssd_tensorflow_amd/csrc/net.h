@@ -208,10 +208,11 @@ private:
     // transformed dy / dx of the data gradient (main stream: wino_yt_, wino_xw_), the transformed dy and the slabs of the weight
     // gradient (weight-gradient stream: wino_ya_, wino_slab_).  One stream runs each kind in order, so one buffer per kind suffices.
     void plan_winograd();
-    WinoFilterPlan wino_plan_;
+    WinoFilterPlan wino_plan_, wino_plan_first_, wino_plan_flip_;      // forward transforms of all layers but the first / of the first / flipped ones
+    bool wino_flip_pending_ = false;
     bool wino_any_f_ = false, wino_any_d_ = false;
-    float *wino_m_[3] = {nullptr, nullptr, nullptr}, *wino_yt_ = nullptr, *wino_xw_ = nullptr, *wino_ya_ = nullptr, *wino_slab_ = nullptr;
-    hipEvent_t ev_wino_ = nullptr;
+    float *wino_m_[3] = {nullptr, nullptr, nullptr}, *wino_vs_[3] = {nullptr, nullptr, nullptr}, *wino_yt_ = nullptr, *wino_xw_ = nullptr, *wino_ya_ = nullptr, *wino_slab_ = nullptr;
+    hipEvent_t ev_wino_ = nullptr, ev_wino_first_ = nullptr, ev_wino_flip_ = nullptr;
     void launch_tail_forward(int b0, int nb, hipStream_t s);
     void launch_tail_backward(int b, bool* side_used);
     void build_orders();

@@ -541,7 +541,7 @@ void Net::plan_winograd() {
     if (bf16_) return;
     const int mode = env_i("SSD_WINOGRAD", 15), min_cc = env_i("SSD_WINO_MIN_CC", 4096), head_min_hw = env_i("SSD_WINO_HEAD_MIN_HW", 16);
     if (!(mode & 7)) return;
-    size_t m_max = 0, yt_max = 0, xw_max = 0, slab_max = 0;
+    size_t m_max = 0, v_max = 0, yt_max = 0, xw_max = 0, slab_max = 0;
     for (Op& op : ops_) {
         if (op.kind != OP_CONV) continue;
         const ConvDesc d = conv_desc(op, Bmax_);
@@ -556,7 +556,9 @@ void Net::plan_winograd() {
         const size_t u = (size_t)36 * d.Ci * d.Co, uf = (size_t)36 * d.Ci * wino_kpad(d.Co), t = (size_t)36 * wino_tiles(d);
         if (op.wino_f) {
             op.wino_U = (float*)dalloc(u * sizeof(float));
-            op.wino_V = (float*)dalloc(t * d.Ci * sizeof(float));
+            // the input's transform: kept per layer by a training handle (the weight gradient reads it), per-stream scratch otherwise
+            if (training_) op.wino_V = (float*)dalloc(t * d.Ci * sizeof(float));
+            else v_max = std::max(v_max, t * d.Ci);
             m_max = std::max(m_max, t * d.Co);
         }
         if (op.wino_d) {
@@ -569,13 +571,18 @@ void Net::plan_winograd() {
             yt_max = std::max(yt_max, t * wino_kpad(d.Co));
             for (int b = 1; b <= Bmax_; ++b) slab_max = std::max(slab_max, wino_wgrad_ws_floats(conv_desc(op, b)));
         }
-        wino_plan_.add(params_ + op.w_off, op.wino_U, op.wino_Uf, d.Ci, d.Co);
+        // (the first Winograd layer's forward transform is a launch of its own: the lanes wait for a 16 KB filter, not for all of them)
+        (wino_plan_first_.n == 0 && op.wino_f ? wino_plan_first_ : wino_plan_).add(params_ + op.w_off, op.wino_U, nullptr, d.Ci, d.Co);
+        if (op.wino_Uf) wino_plan_flip_.add(params_ + op.w_off, nullptr, op.wino_Uf, d.Ci, d.Co);
         wino_any_f_ |= op.wino_f;
         wino_any_d_ |= op.wino_d;
     }
-    if (wino_plan_.n == 0) return;
+    if (wino_plan_.n + wino_plan_first_.n + wino_plan_flip_.n == 0) return;
     HIP_OK(hipEventCreateWithFlags(&ev_wino_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_wino_first_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_wino_flip_, hipEventDisableTiming));
     if (m_max) for (int l = 0; l < 3; ++l) wino_m_[l] = (float*)dalloc(m_max * sizeof(float));
+    if (v_max) for (int l = 0; l < 3; ++l) wino_vs_[l] = (float*)dalloc(v_max * sizeof(float));
     if (training_) {
         wino_yt_ = (float*)dalloc(yt_max * sizeof(float));
         wino_xw_ = (float*)dalloc(xw_max * sizeof(float));
@@ -815,6 +822,8 @@ Net::~Net() {
         (void)hipEventDestroy(ev_h_);
         (void)hipEventDestroy(ev_cast_);
         if (ev_wino_) (void)hipEventDestroy(ev_wino_);
+        if (ev_wino_first_) (void)hipEventDestroy(ev_wino_first_);
+        if (ev_wino_flip_) (void)hipEventDestroy(ev_wino_flip_);
         if (!s2_is_w_) (void)hipStreamDestroy(s2_);
         (void)hipEventDestroy(ev2_h_);
         (void)hipEventDestroy(ev_l2_);
@@ -861,10 +870,11 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         hipEvent_t* ev_fmap;
         hipEvent_t ev_h;
         int b0, nb;
-        bool heads_on_side, cast_pending, wino_pending;
+        bool heads_on_side, cast_pending;
+        int wino_pending;                 // filter-transform events this lane has still to wait for: 2 = the first layer's, then 1 = the rest
         bool fmap_carried[MAX_MAPS];      // the feature map's producer carried ev_fmap[head] itself (g_stop_event)
-    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false, false, {}},
-                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false, false, {}}};
+    } lane[2] = {{stream_, hstream_, ev_fmap_, ev_h_, 0, nl == 2 ? (b + 1) / 2 : b, false, false, 0, {}},
+                 {s2_, s2_, ev2_fmap_, ev2_h_, (b + 1) / 2, b - (b + 1) / 2, false, false, 0, {}}};
     // feature map tensor -> the head that reads it (-1: none), for the carried events
     auto head_of = [&](int tensor) {
         for (const Op& o : ops_)
@@ -880,15 +890,22 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
         if (nl == 2) HIP_OK(hipStreamWaitEvent(s2_, ev_fmap_[MAX_MAPS - 1], 0));
         lane[0].heads_on_side = true;
     }
-    if (wino_plan_.n > 0) {
-        // Winograd layers (plan_winograd): the filters' transforms, fresh from the fp32 masters like the bf16 mirrors below -- two
-        // launches for all layers on the side stream, beside conv1_x; a lane's first Winograd layer waits for them
+    if (wino_plan_.n + wino_plan_first_.n > 0) {
+        // Winograd layers (plan_winograd): the filters' transforms, fresh from the fp32 masters like the bf16 mirrors below, on the side
+        // stream beside conv1_1: the first such layer's own (a launch of microseconds: what the lanes wait for), the other layers', and --
+        // training -- the flipped forms of the data gradients, which only backward waits for (backward_begin)
         prof_.layer = "filters";
-        wino_filter_plan(wino_plan_, wino_any_f_, wino_any_d_ && train_mode, side ? hstream_ : stream_);
-        if (side) {
-            HIP_OK(hipEventRecord(ev_wino_, hstream_));
-            lane[0].wino_pending = lane[1].wino_pending = true;
+        hipStream_t fs = side ? hstream_ : stream_;
+        wino_filter_plan(wino_plan_first_, true, false, fs);
+        if (side) HIP_OK(hipEventRecord(ev_wino_first_, fs));
+        wino_filter_plan(wino_plan_, true, false, fs);
+        if (side) HIP_OK(hipEventRecord(ev_wino_, fs));
+        if (train_mode && wino_plan_flip_.n > 0) {
+            wino_filter_plan(wino_plan_flip_, false, true, fs);
+            if (side) HIP_OK(hipEventRecord(ev_wino_flip_, fs));
+            wino_flip_pending_ = side;
         }
+        if (side) lane[0].wino_pending = lane[1].wino_pending = 2;
     }
     if (bf16_) {
         // the fp32 masters may have been updated by the optimizer, a variable load or the caller (external
@@ -1001,12 +1018,19 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 size_t wino_vps = 0;
                 if (wino) {
                     if (cs == ln.s && ln.wino_pending) {      // (the side stream ran the filter transforms itself)
-                        HIP_OK(hipStreamWaitEvent(ln.s, ev_wino_, 0));
-                        ln.wino_pending = false;
+                        // (waiting for ALL transforms incl. the flipped ones before the first layer: 24.00 against 23.69 ms median,
+                        // profiles/r06_bc_ab_filter_split_f32.txt)
+                        HIP_OK(hipStreamWaitEvent(ln.s, ln.wino_pending == 2 ? ev_wino_first_ : ev_wino_, 0));
+                        --ln.wino_pending;
                     }
                     const size_t tpi = (size_t)wino_tiles(d) / d.B;
-                    wino_V = op.wino_V + (size_t)run_b0 * tpi * d.Ci;
-                    wino_vps = (size_t)b * tpi * d.Ci;
+                    if (op.wino_V) {      // a training handle: this launch's rows of the layer's full-batch transform
+                        wino_V = op.wino_V + (size_t)run_b0 * tpi * d.Ci;
+                        wino_vps = (size_t)b * tpi * d.Ci;
+                    } else {              // an inference handle: the stream's own scratch
+                        wino_V = wino_vs_[cs == ln.s ? li : 2];
+                        wino_vps = (size_t)run_nb * tpi * d.Ci;
+                    }
                 }
                 if (op.pool_after >= 0) {
                     // Pool fusion (round 5): this conv's epilogue takes the 2x2 maxima itself and writes the POOLED tensor (+ the
@@ -1157,6 +1181,10 @@ void Net::backward_begin(int b, const float* y) {
     for (Tensor& t : tensors_) { t.done = 0; t.gstream = 0; t.gseq = 0; t.gev_set = false; }
     bw_issued_[0] = bw_issued_[1] = 0;
     bw_seen_[0][0] = bw_seen_[0][1] = bw_seen_[1][0] = bw_seen_[1][1] = 0;
+    if (wino_flip_pending_) {      // the data gradients' filter transforms (side stream, issued by forward)
+        HIP_OK(hipStreamWaitEvent(stream_, ev_wino_flip_, 0));
+        wino_flip_pending_ = false;
+    }
     multibox_loss_grad(heads_, b, 0, result_, y, lw_, stream_);
     for (int t : head_t_) bw_wrote(0, tensors_[t]);      // the loss gradient, on the main stream
     if (side) bw_sync(1, 0);      // the side stream starts behind it (the small maps' head data gradients: backward_step)
