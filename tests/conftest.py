@@ -34,3 +34,10 @@ def unfused_pools(monkeypatch):
     activation and gradient is materialised for the layer-local oracle checks; tests/test_gpu_pool_fusion.py shows the fused
     step bit-identical to this one."""
     monkeypatch.setenv('SSD_POOL_FUSE', '0')
+
+
+@pytest.fixture
+def direct_convs(monkeypatch):
+    """Handles created inside the test run the 3x3 / stride 1 layers on the direct fp32 kernels (SSD_WINOGRAD=0, read per
+    handle): the form every layer had before round 6 stays under the same oracle tests as the Winograd form that replaced it."""
+    monkeypatch.setenv('SSD_WINOGRAD', '0')

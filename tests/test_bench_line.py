@@ -60,3 +60,20 @@ def test_trace_tools_parse_a_kernel_trace(tmp_path):
     gp = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_gaps.py'), str(path)], capture_output=True, text=True, timeout=60)
     assert gp.returncode == 0, gp.stderr
     assert 'idle 2.0 us/step' in gp.stdout
+
+
+def test_self_check_prices_the_winograd_step_by_executed_flops():
+    """model_mfma_frac (algorithmic direct-convolution FLOPs) may exceed 1 only in a block that says which algorithm ran
+    (DESIGN.md 4.9); the fraction of the peak the matrix pipe was ASKED for may never."""
+    import pytest
+    b = _bench()
+    base = dict(ms_per_step=24.0, kernel_ms_per_step={'wino_gemm_128x128': 7.0}, kernel_ms_sum_per_step=26.0,
+                roofline=dict(frac=0.72), model_mfma_frac=1.6, executed_mfma_frac=0.47)
+    with pytest.raises(SystemExit):
+        b.self_check(dict(base), True)                                   # > 1 without the algorithm note
+    assert 'fractions' in b.self_check(dict(base, algorithm='winograd'), True)
+    with pytest.raises(SystemExit):
+        b.self_check(dict(base, algorithm='winograd', executed_mfma_frac=1.02), True)
+    with pytest.raises(SystemExit):
+        b.self_check(dict(base, algorithm='winograd', model_mfma_frac=4.5), True)
+    assert 'wino_gemm_128x128' in b.KERNEL_SYMBOLS and 'wino_out_unpool' in b.KERNEL_SYMBOLS

@@ -189,6 +189,43 @@ def test_step_vgg300():
     sess.close()
 
 
+@pytest.mark.usefixtures('unfused_pools', 'direct_convs')
+def test_step_vgg300_on_the_direct_kernels():
+    """The same checks with SSD_WINOGRAD=0: the direct kernels of csrc/conv_igemm.hip as the step's 3x3 layers (what a same-box
+    A/B of DESIGN.md 4.9 runs, and what the bf16 configuration's conv1_1 and every strided / 1x1 layer still use)."""
+    test_step_vgg300()
+
+
+def test_winograd_step_agrees_with_the_direct_step(monkeypatch):
+    """One forward + backward of the same batch and weights on two handles -- SSD_WINOGRAD=0 and the default: the losses to 1e-6,
+    every filter gradient above mod_pool5 to 1e-4 of its norm (below it the two steps may mine different negatives: module header)."""
+    b = 4
+    preset = ob.get_preset('vgg300')
+    w = ref.init_params(preset, 20, seed=7, bias_scale=0.01)
+    x, y, _ = ref.synth_batch(np.random.default_rng(99), b, preset)
+    xt = torch.from_numpy(x).cuda(); yt = torch.from_numpy(y).cuda()
+    sess = Session(0)
+    out = {}
+    for mode in ('0', '15'):
+        monkeypatch.setenv('SSD_WINOGRAD', mode)
+        net = SSDVGG(sess, 'vgg300')
+        net.build_from_vgg(None, 20, max_batch=b, weights=w)
+        net.build_optimizer(0.001)
+        net.forward_backward_dev(xt, yt)
+        torch.cuda.synchronize()
+        out[mode] = (net.get_losses(), net.save_gradients(), net.activation('conv4_3', b), net.activation('mod_conv7', b))
+        net.close()
+    sess.close()
+    (La, ga, a43, a7), (Lb, gb, b43, b7) = out['0'], out['15']
+    for k in La:
+        assert abs(La[k] - Lb[k]) <= 1e-5 * abs(La[k]), (k, La[k], Lb[k])
+    assert report('conv4_3 Winograd vs direct', max_rel(b43, a43)) < 1e-4
+    assert report('mod_conv7 Winograd vs direct', max_rel(b7, a7)) < 1e-4
+    top = [k for k in ga if k.startswith(('classifiers', 'conv8', 'conv9', 'conv10', 'conv11', 'mod_conv'))]
+    assert report('worst filter gradient above mod_pool5', max(rel_err(gb[k], ga[k]) for k in top)) < 1e-3
+    assert report('worst filter gradient', max(rel_err(gb[k], ga[k]) for k in ga)) < 3e-2
+
+
 def test_train_steps_track_oracle():
     """sess.run([result, losses, optimizer]) twice; weights stay on the oracle's trajectory."""
     b = 1
