@@ -259,9 +259,11 @@ void Net::build_orders() {
     // (gpurun_out r05p timeline).  Behind the chain they run at full rate and nothing waits for them: step 6.864 -> 6.810 ms
     // (profiles/r05_r_ab_bw_defer_bf16.txt; on the side stream beside mod_conv6 instead: 6.885).  fp32 keeps graph order: its big
     // heads are 0.74 ms of kernels against a 0.3 ms chain that fits beside them (256-thread tiles), deferring measured +0.5 %.
-    // SSD_BW_BIG_HEADS_LAST=0 / 1 overrides.
+    // Round 6: with the tail as ONE launch per direction (plan_tail_chain) there is no chain of small launches left to starve, and graph
+    // order measures 0.7 - 0.9 % faster in bf16 as well (6.719 against 6.769 ms, 6.746 against 6.808: profiles/r06_bd_ab_bw_order_bf16.txt,
+    // r06_am_ab_bw_defer_sync_bf16.txt): graph order is the default in both dtypes, SSD_BW_BIG_HEADS_LAST=1 restores round 5's.
     bw_defer_first_ = -1;
-    if (env_i("SSD_BW_BIG_HEADS_LAST", bf16_ ? 1 : 0) && tail_first_ + 1 < n && heads_.nmaps >= 3) {
+    if (env_i("SSD_BW_BIG_HEADS_LAST", 0) && tail_first_ + 1 < n && heads_.nmaps >= 3) {
         std::vector<int> moved, rest;
         for (int i : bwd_order_) {
             const Op& op = ops_[i];
