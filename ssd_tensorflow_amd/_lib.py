@@ -112,8 +112,9 @@ SIGNATURES = {
     'ssd_op_conv2d_wgrad_ws_floats': (sz, [i32] * 13),
     'ssd_op_conv2d_wgrad': (i32, [vp, vp, vp, vp, vp, f32, vp] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_wino_ws_floats': (sz, [i32] * 13),
-    'ssd_op_conv2d_wino_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),
-    'ssd_op_conv2d_wino_dgrad': (i32, [vp, vp, vp, vp, i32, vp, i32, i32, vp, i32] + [i32] * 13 + [vp]),
+    'ssd_op_conv2d_wino_bits_words': (sz, [i32] * 13),
+    'ssd_op_conv2d_wino_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),
+    'ssd_op_conv2d_wino_dgrad': (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, i32] + [i32] * 13 + [vp]),
     'ssd_op_conv2d_wino_wgrad': (i32, [vp, vp, vp, vp, vp, f32, vp, i32] + [i32] * 13 + [vp]),
     'ssd_op_cast_filter': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'ssd_op_conv2d_fwd_bf16': (i32, [vp, vp, vp, vp, i32] + [i32] * 14 + [vp]),

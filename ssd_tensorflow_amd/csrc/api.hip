@@ -875,9 +875,14 @@ size_t ssd_op_conv2d_wino_ws_floats(int b, int hi, int wi, int ci, int ho, int w
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
     return wino_applicable(d) ? WinoWs(d, nullptr).total : 0;
 }
-int ssd_op_conv2d_wino_fwd(const float* x, const float* w, const float* bias, float* y, float* y_pool, void* rec, float* ws, int flags,
-                           int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil, int pad_h,
-                           int pad_w, int relu, void* stream) {
+size_t ssd_op_conv2d_wino_bits_words(int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil,
+                                     int pad_h, int pad_w) {
+    const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
+    return wino_applicable(d) ? (size_t)wino_tiles(d) * (d.Ci / 4) : 0;
+}
+int ssd_op_conv2d_wino_fwd(const float* x, const float* w, const float* bias, float* y, float* y_pool, void* rec, void* relu_bits, float* ws,
+                           int flags, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int dil,
+                           int pad_h, int pad_w, int relu, void* stream) {
     API_BEGIN
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
     SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4");
@@ -886,12 +891,12 @@ int ssd_op_conv2d_wino_fwd(const float* x, const float* w, const float* bias, fl
         HIP_OK(hipMemsetAsync(k.Uf, 0, (size_t)36 * d.Ci * wino_kpad(d.Co) * sizeof(float), (hipStream_t)stream));      // the pad rows
         wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
     }
-    wino_fwd(d, x, k.U, bias, y, relu != 0, k.V, (size_t)wino_tiles(d) * d.Ci, k.Mx, y_pool, rec, (hipStream_t)stream);
+    wino_fwd(d, x, k.U, bias, y, relu != 0, k.V, (size_t)wino_tiles(d) * d.Ci, k.Mx, y_pool, rec, (hipStream_t)stream, relu_bits);
     API_END
 }
-int ssd_op_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* mask, int accumulate, const void* rec, int uh, int uw,
-                             float* ws, int flags, int b, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
-                             int dil, int pad_h, int pad_w, void* stream) {
+int ssd_op_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* mask, const void* mask_bits, int accumulate,
+                             const void* rec, int uh, int uw, float* ws, int flags, int b, int hi, int wi, int ci, int ho, int wo, int co,
+                             int kh, int kw, int stride, int dil, int pad_h, int pad_w, void* stream) {
     API_BEGIN
     const ConvDesc d = mk(b, hi, wi, ci, ho, wo, co, kh, kw, stride, dil, pad_h, pad_w);
     SSD_REQUIRE(wino_applicable(d), "winograd: 3x3 / stride 1 / SAME layers (any dilation), Ci in multiples of 32, Co of 4");
@@ -901,7 +906,7 @@ int ssd_op_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const f
         wino_filter(d, w, k.U, k.Uf, (hipStream_t)stream);
     }
     wino_bwd_transform(d, dy, k.Yt, nullptr, (hipStream_t)stream);
-    wino_dgrad(d, k.Yt, k.Uf, dx, mask, accumulate != 0, k.Mx, rec, uh, uw, (hipStream_t)stream);
+    wino_dgrad(d, k.Yt, k.Uf, dx, mask, accumulate != 0, k.Mx, rec, uh, uw, (hipStream_t)stream, mask_bits);
     API_END
 }
 int ssd_op_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, float* dbias, const float* w, float weight_decay, float* ws,

@@ -76,14 +76,16 @@ void wino_filter_plan(const WinoFilterPlan& plan, bool forward, bool flipped, hi
 size_t wino_fwd_ws_floats(const ConvDesc& d);              // Mws: 36 * tiles * Co
 // y = relu?(conv(x) + bias); V [36][.][Ci] receives the input's transform (kept by a training step for wino_wgrad).  y_pool != nullptr:
 // the fused 2x2 pool of conv_fwd_pool instead of y (same values, same record).
+// relu_bits (optional, tiles * Ci / 4 64-bit words): which of x's values are positive, per tile and 4 channels -- what wino_dgrad of the
+// SAME layer takes as mask_bits in place of a second read of x
 void wino_fwd(const ConvDesc& d, const float* x, const float* U, const float* bias, float* y, bool relu, float* V, size_t v_ps,
-              float* Mws, float* y_pool, void* pool_rec, hipStream_t s);
+              float* Mws, float* y_pool, void* pool_rec, hipStream_t s, void* relu_bits = nullptr);
 // dy -> Yt (B^T dy B, the data gradient's operand) and / or Ya (A dy A^T, the weight gradient's), each [36][tiles][wino_kpad(Co)]; nullptr skips one
 void wino_bwd_transform(const ConvDesc& d, const float* dy, float* Yt, float* Ya, hipStream_t s);
 size_t wino_dgrad_ws_floats(const ConvDesc& d);            // Xws: 36 * tiles * Ci
 // conv_dgrad's semantics (mask, accumulate) from the transformed dy; unpool_rec != nullptr: conv_dgrad_unpool's
 void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* dx, const float* mask, bool accumulate, float* Xws,
-                const void* unpool_rec, int UH, int UW, hipStream_t s);
+                const void* unpool_rec, int UH, int UW, hipStream_t s, const void* mask_bits = nullptr);
 size_t wino_wgrad_ws_floats(const ConvDesc& d);
 // conv_wgrad's semantics from the forward's V and the transformed dy
 void wino_wgrad(const ConvDesc& d, const float* V, size_t v_ps, const float* Ya, float* dw, float* dbias, const float* w,

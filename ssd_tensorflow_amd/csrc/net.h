@@ -59,6 +59,8 @@ struct Op {
     // (written by forward, read by the weight gradient)
     bool wino_f = false, wino_d = false, wino_w = false;
     float *wino_U = nullptr, *wino_Uf = nullptr, *wino_V = nullptr;
+    void* wino_bits = nullptr;       // the relu mask of the layer's input as bits (forward's input transform -> the data gradient's output transform)
+    long long wino_bits_step = -1;   // the forward pass that wrote them (Net::fwd_serial_)
 };
 
 struct Variable {
@@ -208,6 +210,7 @@ private:
     // transformed dy / dx of the data gradient (main stream: wino_yt_, wino_xw_), the transformed dy and the slabs of the weight
     // gradient (weight-gradient stream: wino_ya_, wino_slab_).  One stream runs each kind in order, so one buffer per kind suffices.
     void plan_winograd();
+    long long fwd_serial_ = 0;           // forward passes so far
     WinoFilterPlan wino_plan_, wino_plan_first_, wino_plan_flip_;      // forward transforms of all layers but the first / of the first / flipped ones
     bool wino_flip_pending_ = false;
     bool wino_any_f_ = false, wino_any_d_ = false;

@@ -563,6 +563,7 @@ void Net::plan_winograd() {
             else v_max = std::max(v_max, t * d.Ci);
             m_max = std::max(m_max, t * d.Co);
         }
+        if (op.wino_f && op.wino_d && env_i("SSD_WINO_MASK_BITS", 1)) op.wino_bits = dalloc((size_t)wino_tiles(d) * (d.Ci / 4) * 8);
         if (op.wino_d) {
             op.wino_Uf = (float*)dalloc(uf * sizeof(float));
             HIP_OK(hipMemset(op.wino_Uf, 0, uf * sizeof(float)));      // (rows Co ... kpad(Co) - 1 of every position stay zero)
@@ -862,6 +863,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
     g_prof = &prof_;
     tensors_[input_t_].data = const_cast<float*>(x);
     pool_arg_op_ = -1;
+    ++fwd_serial_;
     const bool side = hstream_ && overlap_;
     static const int lanes_env = [] { const char* v = getenv("SSD_FWD_LANES"); return v ? atoi(v) : 0; }();
     const int want_lanes = lanes_env > 0 ? lanes_env : 2;
@@ -1017,6 +1019,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 float* const wino_M = cs == ln.s ? wino_m_[li] : cs == hstream_ ? wino_m_[2] : nullptr;
                 const bool wino = op.wino_f && wino_M;
                 float* wino_V = nullptr;
+                void* wino_bits = nullptr;
                 size_t wino_vps = 0;
                 if (wino) {
                     if (cs == ln.s && ln.wino_pending) {      // (the side stream ran the filter transforms itself)
@@ -1033,6 +1036,11 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                         wino_V = wino_vs_[cs == ln.s ? li : 2];
                         wino_vps = (size_t)run_nb * tpi * d.Ci;
                     }
+                    // training: the input transform notes the relu mask of this layer's input for its own data gradient (conv.h)
+                    if (train_mode && op.wino_bits) {
+                        wino_bits = static_cast<char*>(op.wino_bits) + (size_t)run_b0 * tpi * (d.Ci / 4) * 8;
+                        ops_[op_index].wino_bits_step = fwd_serial_;
+                    }
                 }
                 if (op.pool_after >= 0) {
                     // Pool fusion (round 5): this conv's epilogue takes the 2x2 maxima itself and writes the POOLED tensor (+ the
@@ -1044,7 +1052,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                                     ? static_cast<char*>(pl.pool_rec) + (size_t)run_b0 * pt.H * pt.W * (pt.C / 4) * sizeof(unsigned short) : nullptr;
                     if (wino)
                         wino_fwd(d, xin, op.wino_U, params_ + op.b_off, nullptr, true, wino_V, wino_vps, wino_M,
-                                 reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
+                                 reinterpret_cast<float*>(at(pt, run_b0)), rec, cs, wino_bits);
                     else if (!bf16_)
                         conv_fwd_pool(d, xin, params_ + op.w_off, params_ + op.b_off, reinterpret_cast<float*>(at(pt, run_b0)), rec, cs);
                     else
@@ -1061,7 +1069,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                 } carry_scope{fh >= 0 ? &ln.fmap_carried[fh] : nullptr};
                 if (wino)
                     wino_fwd(d, xin, op.wino_U, params_ + op.b_off, static_cast<float*>(yout), op.relu, wino_V, wino_vps, wino_M,
-                             nullptr, nullptr, cs);
+                             nullptr, nullptr, cs, wino_bits);
                 else if (!bf16_)
                     conv_fwd(d, xin, params_ + op.w_off, params_ + op.b_off, static_cast<float*>(yout), op.relu, cs);
                 else if (in.data_f32 && first_layer_kernel(d))      // conv1_1: fp32 image and master filter in, bf16 out
@@ -1301,7 +1309,8 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
                 if (op.wino_d && cls == 0) {      // Round 6: the Winograd form (its scratch belongs to the main stream)
                     wino_bwd_transform(d, out.gf(), wino_yt_, nullptr, ds);
                     wino_dgrad(d, wino_yt_, op.wino_Uf, up ? dst.gf() : in.gf(), mask ? in.f() : nullptr, !up && in.done > 0, wino_xw_,
-                               up ? up->pool_rec : nullptr, dst.H, dst.W, ds);
+                               up ? up->pool_rec : nullptr, dst.H, dst.W, ds,
+                               op.wino_bits && op.wino_bits_step == fwd_serial_ ? op.wino_bits : nullptr);      // (the forward of THIS step wrote them)
                 } else if (!bf16_) {
                     if (up) conv_dgrad_unpool(d, out.gf(), params_ + op.w_off, dst.gf(), up->pool_rec, dst.H, dst.W, ds);
                     else conv_dgrad(d, out.gf(), params_ + op.w_off, in.gf(), mask ? in.f() : nullptr, in.done > 0, ds);

@@ -66,7 +66,7 @@ __device__ __forceinline__ void at4(const f32x4 m0, const f32x4 m1, const f32x4 
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, float* __restrict__ Va,
                                                       int H, int W, int C, int Cp, int th, int tw, int T, unsigned x_bytes,
-                                                      size_t v_ps, size_t va_ps, int D) {
+                                                      size_t v_ps, size_t va_ps, int D, unsigned long long* __restrict__ bits) {
     // Cp >= C: row length of V / Va (a GEMM's k must be a multiple of 32: the multibox heads' 104 / 152 channels are padded with zeros)
     const int c4n = Cp >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -93,6 +93,20 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         }
     }
     const size_t row = (size_t)t * Cp + q * 4;
+    if constexpr (BT) {
+        // forward only: which of the tile's 16 pixels x 4 channels are positive -- the relu mask the data gradient's output transform
+        // of THIS layer applies to dx (conv.h wino_dgrad mask_bits): 8 bytes instead of a second read of the fp32 tensor
+        if (bits) {
+            unsigned long long m = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m |= (unsigned long long)(d[r + 1][s + 1][e] > 0.f) << ((r * 4 + s) * 4 + e);
+            bits[(size_t)t * c4n + q] = m;
+        }
+    }
     if constexpr (AT) {
         f32x4 c[6][4];      // A e: columns first
 #pragma unroll
@@ -133,6 +147,7 @@ struct WinoOutArgs {
     float* y;
     const float* bias;
     const float* mask;
+    const unsigned long long* mask_bits;      // MODE 1: the mask as the forward's bits (one word per tile and 4 channels) instead of `mask`
     int relu, accum;
     int H, W, N, th, tw, T;
     int D;                             // dilation (MODE 0 / 1; the pool forms are D = 1)
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoOutArgs p) {
             }
         }
     } else if constexpr (MODE == 1) {
+        const unsigned long long mbits = p.mask_bits ? p.mask_bits[(size_t)t * c4n + q] : 0ull;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int h = hb + D * r;
@@ -205,7 +221,11 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoOutArgs p) {
                 const size_t e0 = ((size_t)(b * p.H + h) * p.W + w) * p.N + q * 4;
                 f32x4 v = o[r][s];
                 if (p.accum) v += *reinterpret_cast<const f32x4*>(p.y + e0);
-                if (p.mask) {
+                if (p.mask_bits) {
+                    const unsigned mb = (unsigned)(mbits >> ((r * 4 + s) * 4)) & 15u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (mb >> e) & 1u ? v[e] : 0.f;
+                } else if (p.mask) {
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + e0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
@@ -675,20 +695,21 @@ void wino_filter(const ConvDesc& d, const float* w, float* U, float* Uflip, hipS
 }
 
 // x [B][H][W][C] -> V (B^T d B) and / or Va (A e A^T), both [36][.][C] with v_ps / va_ps elements between positions
-static void launch_in(const float* x, float* V, float* Va, int B, int H, int W, int C, int Cp, int D, size_t v_ps, size_t va_ps, hipStream_t s) {
+static void launch_in(const float* x, float* V, float* Va, int B, int H, int W, int C, int Cp, int D, size_t v_ps, size_t va_ps, hipStream_t s,
+                      unsigned long long* bits = nullptr) {
     const int th = tiles_1d(H, D), tw = tiles_1d(W, D), T = B * th * tw;
     const unsigned xb = (unsigned)((size_t)B * H * W * C * 4u);
     const int grid = cdiv((long long)T * (Cp / 4), 256);
     const double by = 4.0 * ((double)B * H * W * C + 36.0 * T * Cp * ((V ? 1 : 0) + (Va ? 1 : 0)));
     if (V && Va) {
         ProfScope prof("wino_in_dual", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<true, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
+        hipLaunchKernelGGL((wino_in_kernel<true, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D, bits);
     } else if (V) {
         ProfScope prof("wino_in", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<true, false>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
+        hipLaunchKernelGGL((wino_in_kernel<true, false>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D, bits);
     } else {
         ProfScope prof("wino_in_wgrad", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<false, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D);
+        hipLaunchKernelGGL((wino_in_kernel<false, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D, bits);
     }
     HIP_OK(hipGetLastError());
 }
@@ -735,10 +756,10 @@ static void launch_out(WinoOutArgs& a, const char* label, double bytes, hipStrea
 size_t wino_fwd_ws_floats(const ConvDesc& d) { return (size_t)36 * wino_tiles(d) * d.Co; }
 
 void wino_fwd(const ConvDesc& d, const float* x, const float* U, const float* bias, float* y, bool relu, float* V, size_t v_ps,
-              float* Mws, float* y_pool, void* pool_rec, hipStream_t s) {
+              float* Mws, float* y_pool, void* pool_rec, hipStream_t s, void* relu_bits) {
     require(d);
     const int T = wino_tiles(d);
-    launch_in(x, V, nullptr, d.B, d.Hi, d.Wi, d.Ci, d.Ci, d.dil, v_ps, 0, s);
+    launch_in(x, V, nullptr, d.B, d.Hi, d.Wi, d.Ci, d.Ci, d.dil, v_ps, 0, s, static_cast<unsigned long long*>(relu_bits));
     gemm_nn(V, v_ps, U, Mws, (size_t)T * d.Co, T, d.Co, d.Ci, s);
     WinoOutArgs a{};
     a.M = Mws; a.m_ps = (size_t)T * d.Co; a.bias = bias; a.relu = relu; a.H = d.Ho; a.W = d.Wo; a.N = d.Co;
@@ -763,12 +784,13 @@ void wino_bwd_transform(const ConvDesc& d, const float* dy, float* Yt, float* Ya
 }
 
 void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* dx, const float* mask, bool accumulate, float* Xws,
-                const void* unpool_rec, int UH, int UW, hipStream_t s) {
+                const void* unpool_rec, int UH, int UW, hipStream_t s, const void* mask_bits) {
     require(d);
     const int T = wino_tiles(d);
     gemm_nn(Yt, (size_t)T * wino_kpad(d.Co), Uflip, Xws, (size_t)T * d.Ci, T, d.Ci, wino_kpad(d.Co), s);
     WinoOutArgs a{};
     a.M = Xws; a.m_ps = (size_t)T * d.Ci; a.y = dx; a.mask = mask; a.accum = accumulate; a.H = d.Hi; a.W = d.Wi; a.N = d.Ci;
+    a.mask_bits = mask ? static_cast<const unsigned long long*>(mask_bits) : nullptr;
     a.th = tiles_1d(d.Hi, d.dil); a.tw = tiles_1d(d.Wi, d.dil); a.T = T; a.D = d.dil;
     const double mb = 4.0 * 36 * T * d.Ci;
     if (unpool_rec) {
@@ -776,7 +798,7 @@ void wino_dgrad(const ConvDesc& d, const float* Yt, const float* Uflip, float* d
         a.unpool_rec = static_cast<const unsigned short*>(unpool_rec); a.UH = UH; a.UW = UW;
         launch_out<3>(a, "wino_out_unpool", mb + 4.0 * d.B * UH * UW * d.Ci, s);
     } else {
-        launch_out<1>(a, "wino_out_dgrad", mb + 4.0 * d.B * d.Hi * d.Wi * d.Ci * (mask ? 2 : 1), s);
+        launch_out<1>(a, "wino_out_dgrad", mb + 4.0 * d.B * d.Hi * d.Wi * d.Ci * (mask && !a.mask_bits ? 2 : 1), s);
     }
 }
 

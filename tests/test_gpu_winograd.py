@@ -58,7 +58,7 @@ def _run(name, b, h, w, ci, co, dil=1, relu=True):
     ws_ = torch.empty((nws,), dtype=torch.float32, device='cuda')
     x_, w_, b_ = dev(x), dev(wt), dev(bias)
     y_ = torch.full((b, h, w, co), 7.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), ptr(y_), None, None, ptr(ws_), 0, *geom, int(relu), None))
+    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), ptr(y_), None, None, None, ptr(ws_), 0, *geom, int(relu), None))
     e_f = max_rel(host(y_), y_ref.detach().permute(0, 2, 3, 1).numpy())
     assert e_f < TOL, f'{name}: forward max-rel {e_f:.3e}'
 
@@ -80,14 +80,20 @@ def _run(name, b, h, w, ci, co, dil=1, relu=True):
     assert np.array_equal(raw(gw_), raw(gw2_)) and np.array_equal(raw(gb_), raw(gb2_))
 
     gx_ = torch.full((b, h, w, ci), 3.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_dgrad(ptr(gdy_), ptr(w_), ptr(gx_), None, 0, None, 0, 0, ptr(ws_), 0, *geom, None))
+    check(lib.ssd_op_conv2d_wino_dgrad(ptr(gdy_), ptr(w_), ptr(gx_), None, None, 0, None, 0, 0, ptr(ws_), 0, *geom, None))
     e_d = max_rel(host(gx_), dx_ref)
     assert e_d < TOL, f'{name}: dgrad max-rel {e_d:.3e}'
     prev = rng.normal(0, 1, x.shape).astype(np.float32)
     gx_ = dev(prev)
-    check(lib.ssd_op_conv2d_wino_dgrad(ptr(gdy_), ptr(w_), ptr(gx_), ptr(x_), 1, None, 0, 0, ptr(ws_), 1, *geom, None))
+    check(lib.ssd_op_conv2d_wino_dgrad(ptr(gdy_), ptr(w_), ptr(gx_), ptr(x_), None, 1, None, 0, 0, ptr(ws_), 1, *geom, None))
     e_m = max_rel(host(gx_), (dx_ref + prev) * (x > 0))
     assert e_m < TOL, f'{name}: dgrad accumulate+mask max-rel {e_m:.3e}'
+    # the relu mask as the forward's bits (one 64-bit word per tile and 4 channels) instead of the fp32 tensor: the same bits out
+    bits_ = torch.full((lib.ssd_op_conv2d_wino_bits_words(*geom),), -1, dtype=torch.int64, device='cuda')
+    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), ptr(y_), None, None, ptr(bits_), ptr(ws_), 1, *geom, int(relu), None))
+    gx2_ = dev(prev)
+    check(lib.ssd_op_conv2d_wino_dgrad(ptr(gdy_), ptr(w_), ptr(gx2_), ptr(x_), ptr(bits_), 1, None, 0, 0, ptr(ws_), 1, *geom, None))
+    assert np.array_equal(raw(gx2_), raw(gx_)), f'{name}: mask bits differ from the fp32 mask'
     print(f'{name}: fwd {e_f:.2e} wgrad {e_w:.2e} bias {e_b:.2e} dgrad {e_d:.2e}')
     return x_, w_, b_, y_, ws_, geom
 
@@ -106,7 +112,7 @@ def test_winograd_fused_pool_refuses_dilation():
     ws_ = torch.empty((lib.ssd_op_conv2d_wino_ws_floats(*geom),), dtype=torch.float32, device='cuda')
     t = torch.zeros((1, 8, 8, 32), dtype=torch.float32, device='cuda')
     w_ = torch.zeros((3, 3, 32, 32), dtype=torch.float32, device='cuda')
-    rc = lib.ssd_op_conv2d_wino_fwd(ptr(t), ptr(w_), None, None, ptr(t), None, ptr(ws_), 0, *geom, 1, None)
+    rc = lib.ssd_op_conv2d_wino_fwd(ptr(t), ptr(w_), None, None, ptr(t), None, None, ptr(ws_), 0, *geom, 1, None)
     assert rc != 0 and b'undilated' in lib.ssd_last_error()
 
 
@@ -130,18 +136,18 @@ def test_winograd_fused_pool_bit_identical_to_the_pooling_passes(case):
     x_, w_, b_ = dev(x), dev(wt), dev(bias)
     ws_ = torch.empty((lib.ssd_op_conv2d_wino_ws_floats(*geom),), dtype=torch.float32, device='cuda')
     y_ = torch.empty((b, h, w, co), dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), ptr(y_), None, None, ptr(ws_), 0, *geom, 1, None))
+    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), ptr(y_), None, None, None, ptr(ws_), 0, *geom, 1, None))
     p_ref = torch.full((b, ph, pw, co), 7.0, dtype=torch.float32, device='cuda')
     r_ref = torch.full((b, ph, pw, co // 4), -1, dtype=torch.int16, device='cuda')
     check(lib.ssd_op_maxpool_rec_fwd(ptr(y_), ptr(p_ref), ptr(r_ref), 0, b, h, w, co, None))
     p_got = torch.full((b, ph, pw, co), 9.0, dtype=torch.float32, device='cuda')
     r_got = torch.full((b, ph, pw, co // 4), -2, dtype=torch.int16, device='cuda')
-    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), None, ptr(p_got), ptr(r_got), ptr(ws_), 1, *geom, 1, None))
+    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), None, ptr(p_got), ptr(r_got), None, ptr(ws_), 1, *geom, 1, None))
     assert np.array_equal(raw(p_got), raw(p_ref)), f'{name}: pooled tensor differs'
     assert np.array_equal(raw(r_got), raw(r_ref)), f'{name}: record differs'
     assert np.count_nonzero(host(p_ref)) > 0.3 * p_ref.numel()
     p2 = torch.full((b, ph, pw, co), 9.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), None, ptr(p2), None, ptr(ws_), 1, *geom, 1, None))
+    check(lib.ssd_op_conv2d_wino_fwd(ptr(x_), ptr(w_), ptr(b_), None, ptr(p2), None, None, ptr(ws_), 1, *geom, 1, None))
     assert np.array_equal(raw(p2), raw(p_ref))
     # ... and against the direct kernel's fused pool: same values to rounding
     p_dir = torch.empty_like(p_ref)
@@ -156,11 +162,11 @@ def test_winograd_fused_pool_bit_identical_to_the_pooling_passes(case):
     geom2 = (b, ph, pw, co, ph, pw, c2, 3, 3, 1, 1, 1, 1)
     ws2_ = torch.empty((lib.ssd_op_conv2d_wino_ws_floats(*geom2),), dtype=torch.float32, device='cuda')
     dxp = torch.full((b, ph, pw, co), 3.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy_), ptr(w2_), ptr(dxp), None, 0, None, 0, 0, ptr(ws2_), 0, *geom2, None))
+    check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy_), ptr(w2_), ptr(dxp), None, None, 0, None, 0, 0, ptr(ws2_), 0, *geom2, None))
     dx_ref = torch.full((b, h, w, co), 5.0, dtype=torch.float32, device='cuda')
     check(lib.ssd_op_maxpool_rec_bwd(ptr(r_ref), ptr(dxp), ptr(dx_ref), 1, 0, b, h, w, co, None))
     dx_got = torch.full((b, h, w, co), 6.0, dtype=torch.float32, device='cuda')
-    check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy_), ptr(w2_), ptr(dx_got), None, 0, ptr(r_ref), h, w, ptr(ws2_), 1, *geom2, None))
+    check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy_), ptr(w2_), ptr(dx_got), None, None, 0, ptr(r_ref), h, w, ptr(ws2_), 1, *geom2, None))
     assert np.array_equal(raw(dx_got), raw(dx_ref)), f'{name}: un-pooled data gradient differs'
     assert np.count_nonzero(host(dx_ref)) > 0.02 * dx_ref.numel()
     dx_dir = torch.empty_like(dx_ref)
@@ -176,5 +182,5 @@ def test_winograd_refuses_other_shapes():
     assert lib.ssd_op_conv2d_wino_ws_floats(2, 19, 19, 1024, 19, 19, 1024, 1, 1, 1, 1, 0, 0) == 0
     assert lib.ssd_op_conv2d_wino_ws_floats(2, 38, 38, 100, 38, 38, 512, 3, 3, 1, 1, 1, 1) == 0
     assert lib.ssd_op_conv2d_wino_ws_floats(2, 38, 38, 512, 38, 38, 102, 3, 3, 1, 1, 1, 1) == 0
-    rc = lib.ssd_op_conv2d_wino_fwd(None, None, None, None, None, None, None, 0, 2, 38, 38, 100, 38, 38, 512, 3, 3, 1, 1, 1, 1, 1, None)
+    rc = lib.ssd_op_conv2d_wino_fwd(None, None, None, None, None, None, None, None, 0, 2, 38, 38, 100, 38, 38, 512, 3, 3, 1, 1, 1, 1, 1, None)
     assert rc != 0 and b'winograd' in lib.ssd_last_error()

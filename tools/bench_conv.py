@@ -87,8 +87,8 @@ for name, hw, ci, co, k, s, d in LAYERS:
     nws = lib.ssd_op_conv2d_wino_ws_floats(*geom)
     if nws and os.environ.get('SSD_BENCH_WINO', '1') != '0':      # the Winograd forms, steady state (filter transforms / V current)
         wws = torch.empty((nws,), device='cuda')
-        check(lib.ssd_op_conv2d_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), None, None, ptr(wws), 0, *geom, 1, None))
-        fns.update(wino_fwd=lambda: check(lib.ssd_op_conv2d_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), None, None, ptr(wws), 1, *geom, 1, None)),
-                   wino_dgrad=lambda: check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy), ptr(w), ptr(dx), ptr(x), 0, None, 0, 0, ptr(wws), 1, *geom, None)),
+        check(lib.ssd_op_conv2d_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), None, None, None, ptr(wws), 0, *geom, 1, None))
+        fns.update(wino_fwd=lambda: check(lib.ssd_op_conv2d_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), None, None, None, ptr(wws), 1, *geom, 1, None)),
+                   wino_dgrad=lambda: check(lib.ssd_op_conv2d_wino_dgrad(ptr(dy), ptr(w), ptr(dx), ptr(x), None, 0, None, 0, 0, ptr(wws), 1, *geom, None)),
                    wino_wgrad=lambda: check(lib.ssd_op_conv2d_wino_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(w), 0.0005, ptr(wws), 3, *geom, None)))
     timeit(fns, fl, name)

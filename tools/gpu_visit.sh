@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06bd
+TAG=r06be
 O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-bash tools/ab_variants.sh "$O/ab_bw_order_bf16.txt" 5 bf16 "heads_last:SSD_BW_BIG_HEADS_LAST=1" "graph_order:SSD_BW_BIG_HEADS_LAST=0"
-bash tools/ab_variants.sh "$O/ab_bw_order_f32.txt" 3 f32 "graph_order:SSD_BW_BIG_HEADS_LAST=0" "heads_last:SSD_BW_BIG_HEADS_LAST=1"
+timeout 900 python -m pytest tests/test_gpu_winograd.py tests/test_gpu_model.py tests/test_gpu_pool_fusion.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | grep -E "passed|failed|rror" | tee $O/tests.txt
+bash tools/ab_variants.sh "$O/ab_mask_bits_f32.txt" 3 f32 "bits:SSD_WINO_MASK_BITS=1" "fp32_mask:SSD_WINO_MASK_BITS=0"
