@@ -61,6 +61,7 @@ struct Op {
     float *wino_U = nullptr, *wino_Uf = nullptr, *wino_V = nullptr;
     void* wino_bits = nullptr;       // the relu mask of the layer's input as bits (forward's input transform -> the data gradient's output transform)
     long long wino_bits_step = -1;   // the forward pass that wrote them (Net::fwd_serial_)
+    long long wino_v_step = -1;      // the forward pass that wrote wino_V
 };
 
 struct Variable {

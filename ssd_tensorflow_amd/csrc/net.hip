@@ -563,7 +563,7 @@ void Net::plan_winograd() {
             else v_max = std::max(v_max, t * d.Ci);
             m_max = std::max(m_max, t * d.Co);
         }
-        if (op.wino_f && op.wino_d && env_i("SSD_WINO_MASK_BITS", 1)) op.wino_bits = dalloc((size_t)wino_tiles(d) * (d.Ci / 4) * 8);
+        if (op.wino_f && op.wino_d) op.wino_bits = dalloc((size_t)wino_tiles(d) * (d.Ci / 4) * 8);      // (against the fp32 mask: 23.47 -> 23.02 ms, profiles/r06_be_*)
         if (op.wino_d) {
             op.wino_Uf = (float*)dalloc(uf * sizeof(float));
             HIP_OK(hipMemset(op.wino_Uf, 0, uf * sizeof(float)));      // (rows Co ... kpad(Co) - 1 of every position stay zero)
@@ -1032,6 +1032,7 @@ void Net::forward(const float* x, int b, bool train_mode, const float* y) {
                     if (op.wino_V) {      // a training handle: this launch's rows of the layer's full-batch transform
                         wino_V = op.wino_V + (size_t)run_b0 * tpi * d.Ci;
                         wino_vps = (size_t)b * tpi * d.Ci;
+                        if (train_mode) ops_[op_index].wino_v_step = fwd_serial_;
                     } else {              // an inference handle: the stream's own scratch
                         wino_V = wino_vs_[cs == ln.s ? li : 2];
                         wino_vps = (size_t)run_nb * tpi * d.Ci;
@@ -1166,7 +1167,9 @@ void Net::launch_wgrad(int op_index, int b, hipStream_t ws) {
     const ConvDesc d = conv_desc(op, b);
     float* slab = wgrad_ws_ + op.ws_off;
     prof_.layer = op.name.c_str();
-    if (op.wino_w) {      // Round 6: from the forward's transform of the input and the transformed dy (conv.h wino_wgrad)
+    // Round 6: from the forward's transform of the input and the transformed dy (conv.h wino_wgrad) -- if the forward pass of THIS step
+    // left that transform (a launch that ran on a stream without Winograd scratch took the direct kernel: the direct weight gradient then)
+    if (op.wino_w && op.wino_v_step == fwd_serial_) {
         const size_t tpi = (size_t)wino_tiles(d) / d.B;
         wino_bwd_transform(d, out.gf(), nullptr, wino_ya_, ws);
         wino_wgrad(d, op.wino_V, (size_t)b * tpi * d.Ci, wino_ya_, grads_ + op.w_off, grads_ + op.b_off, params_ + op.w_off, wd_,
