@@ -75,7 +75,7 @@ KERNEL_SYMBOLS = {
     'wino_gemm_64x128': ['wino_gemm_nn_kernel<2, 2, 1, 2>'], 'wino_gemm_64x64': ['wino_gemm_nn_kernel<2, 2, 1, 1>'],
     'wino_gemm_tn_128x128': ['wino_gemm_tn_kernel<2, 2, 2, 2>'], 'wino_gemm_tn_64x128': ['wino_gemm_tn_kernel<2, 2, 1, 2>'],
     'wino_gemm_tn_128x64': ['wino_gemm_tn_kernel<4, 1, 1, 2>'], 'wino_gemm_tn_64x64': ['wino_gemm_tn_kernel<2, 2, 1, 1>'],
-    'wino_in': ['wino_in_kernel<true, false>'], 'wino_in_wgrad': ['wino_in_kernel<false, true>'], 'wino_in_dual': ['wino_in_kernel<true, true>'],
+    'wino_in': ['wino_in_kernel<true, false>'], 'wino_in_wgrad': ['wino_in_kernel<false, true>'],
     'wino_out': ['wino_out_kernel<0>'], 'wino_out_dgrad': ['wino_out_kernel<1>'], 'wino_out_pool': ['wino_out_kernel<2>'], 'wino_out_unpool': ['wino_out_kernel<3>'],
     'wino_wgrad_reduce': ['wino_wgrad_reduce_kernel'], 'wino_filter': ['wino_filter_kernel<false>'], 'wino_filter_flip': ['wino_filter_kernel<true>'],
     'detect_scan': ['detect_scan_kernel'], 'detect_image': ['detect_image_kernel'],

@@ -14,6 +14,10 @@
 //                  dg = G^T (sum of slabs, fixed order) G + weight_decay g;  dbias = column sums of dy = sum_t (A dy A^T)_(1,1)
 //                  (wino_wgrad_reduce_kernel)
 //
+// The same form serves the dilated layer (mod_conv6: every residue class of the dilation is an image of its own, wino_in_kernel) and the
+// multibox heads of the big maps (output channels in multiples of 4: the data gradient's k is padded to 32 with zeros).  The relu mask a
+// data gradient applies to dx is the layer's own input > 0: the forward's input transform has it in registers and leaves it as bits.
+//
 // Tiles t = (image, tile row, tile column) in raster order; T = B * ceil(H/4) * ceil(W/4).  Every transformed tensor is position-major
 // [36][T][C] so that each of the 36 GEMMs reads plain row-major matrices and the transforms write whole 128-byte lines per (tile, position).
 // The transforms are exact-arithmetic identities; in fp32 their rounding error is ~1e-6 of the output scale (tests: 1e-3 relative
@@ -701,9 +705,10 @@ static void launch_in(const float* x, float* V, float* Va, int B, int H, int W, 
     const unsigned xb = (unsigned)((size_t)B * H * W * C * 4u);
     const int grid = cdiv((long long)T * (Cp / 4), 256);
     const double by = 4.0 * ((double)B * H * W * C + 36.0 * T * Cp * ((V ? 1 : 0) + (Va ? 1 : 0)));
-    if (V && Va) {
-        ProfScope prof("wino_in_dual", 0, by, s);
-        hipLaunchKernelGGL((wino_in_kernel<true, true>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D, bits);
+    if (V && Va) {      // (one kernel for both was never measured faster than the data gradient's stream running its own: two launches)
+        launch_in(x, V, nullptr, B, H, W, C, Cp, D, v_ps, 0, s, bits);
+        launch_in(x, nullptr, Va, B, H, W, C, Cp, D, 0, va_ps, s);
+        return;
     } else if (V) {
         ProfScope prof("wino_in", 0, by, s);
         hipLaunchKernelGGL((wino_in_kernel<true, false>), dim3(grid), dim3(256), 0, s, x, V, Va, H, W, C, Cp, th, tw, T, xb, v_ps, va_ps, D, bits);
