@@ -1,11 +1,17 @@
 #!/bin/bash
+# Round-6 evidence visit: the whole -m gpu suite, smoke, the default bench line, both profile sets, duty tables, timelines.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=r06bh
-O=$R/gpurun_out/$TAG; mkdir -p "$O"; cd "$R"
-for v in "" frag2 "" frag2; do
-  lib=""; [ -n "$v" ] && lib="$R/ssd_tensorflow_amd/libssdvgg_hip_$v.so"
-  echo "== variant ${v:-product}" | tee -a $O/gemm_frag2.txt
-  SSD_LIB=$lib timeout 300 python tools/bench_conv.py conv2_2,conv3_2,conv4_2,conv5_2 2>&1 | grep -v amdgpu.ids | sed 's/ fwd.*| wino_fwd/ wino_fwd/' | tee -a $O/gemm_frag2.txt
+export GRAFT_REPO_ROOT=$R
+TAG=${1:-r06_zz}
+cd "$R"
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.txt 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/${TAG}_smoke.txt
+GPU_EXTRA="prof profbf16" bash tools/gpu_round.sh $TAG
+bash tools/pmc_duty.sh ${TAG}_duty > /dev/null 2>&1
+bash tools/pmc_duty.sh ${TAG}_duty_bf16 --dtype bf16 > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+for dt in f32 bf16; do
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/pt_$dt -o t -- python "$R/bench.py" --dtype $dt --steps 8 --warmup 8 --no-cpu-baseline --no-secondary --no-kernel-events > /dev/null 2>&1
+  python "$R/tools/timeline.py" /tmp/pt_$dt/t_kernel_trace.csv > "$R/gpurun_out/$TAG/timeline_$dt.txt" 2>&1
 done
-SSD_LIB=$R/ssd_tensorflow_amd/libssdvgg_hip_frag2.so timeout 300 python -m pytest tests/test_gpu_winograd.py -x -q -p no:cacheprovider 2>&1 | grep -E "passed|failed" | tee -a $O/gemm_frag2.txt
+ls "$R/gpurun_out/$TAG" "$R/gpurun_out/${TAG}_prof" "$R/gpurun_out/${TAG}_prof_bf16" | head -60
