@@ -30,7 +30,7 @@ CASES = [
     ('head map0-like 38x38 256->104', 1, 38, 38, 256, 104),
     ('head map1-like 19x19 512->152 b2', 2, 19, 19, 512, 152),
     ('12 output channels 9x9 32->12', 2, 9, 9, 32, 12),
-    ('128 -> 64 channels 21x10 (the weight gradient's 128 x 64 tile)', 2, 21, 10, 128, 64),
+    ('128 -> 64 channels 21x10 (128 x 64 tile of the weight-gradient GEMM)', 2, 21, 10, 128, 64),
 ]
 
 
