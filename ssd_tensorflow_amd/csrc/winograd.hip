@@ -741,7 +741,7 @@ static void gemm_nn(const float* A, size_t a_ps, const float* Bm, float* C, size
     // 128 x 128 unless its last row of tiles would be mostly empty (19 x 19 maps: 800 tiles at batch 32)
     int cfg = 0;
     if (forced >= 0) cfg = forced;
-    else if (N <= 64) cfg = 1;      // (a 128-wide n tile would multiply 64 columns of zeros)
+    else if (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) cfg = 1;      // (a 128-wide n tile would multiply 64 columns of zeros: N = 64, the 152-channel heads)
     else if ((double)cdiv(M, 128) * 128 > 1.06 * M && (double)cdiv(M, 64) * 64 < (double)cdiv(M, 128) * 128) cfg = 2;
     switch (cfg) {
     case 0: launch_nn<2, 2, 2, 2>(a, "wino_gemm_128x128", s); break;
