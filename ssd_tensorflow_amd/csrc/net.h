@@ -180,7 +180,6 @@ private:
     hipStream_t s2_ = nullptr;                  // second forward lane: its main stream, which also runs its heads (= wstream_ in a training handle)
     hipEvent_t ev2_h_ = nullptr, ev_l2_ = nullptr, ev_join_ = nullptr, ev2_fmap_[MAX_MAPS] = {};
     int tail_first_ = 0;                 // op index of conv8_1: the extra layers behind it form backward's side chain
-    int bw_defer_first_ = -1;            // first of the big heads issued behind the chain (build_orders), -1: graph order
     bool stop_events_ = true;            // data gradients carry their gradient tensor's event (common.h g_stop_event)
     // Issue orders (net.hip build_orders): forward walks fwd_order_ (every multibox head right behind its feature map), backward
     // walks bwd_order_ (reverse graph order)

@@ -252,32 +252,11 @@ void Net::build_orders() {
     }
     bwd_order_.clear();
     for (int i = n - 1; i >= 0; --i) bwd_order_.push_back(i);
-    // Round 5, bf16: the two BIG heads (38x38, 19x19) and the l2-norm go BEHIND the chain conv11_2 ... conv8_2, and the main stream
-    // waits for the chain's end before it starts them.  In graph order their data gradients (1456 / 1444 workgroups) fill every CU
-    // while the chain's first links are due, and those are launches of 4 - 52 workgroups that need an EMPTY CU (16 waves, 128 KB of
-    // LDS: pick_tile_h): the chain's second link started when the big kernels had no workgroup left to place, 140 us late
-    // (gpurun_out r05p timeline).  Behind the chain they run at full rate and nothing waits for them: step 6.864 -> 6.810 ms
-    // (profiles/r05_r_ab_bw_defer_bf16.txt; on the side stream beside mod_conv6 instead: 6.885).  fp32 keeps graph order: its big
-    // heads are 0.74 ms of kernels against a 0.3 ms chain that fits beside them (256-thread tiles), deferring measured +0.5 %.
-    // Round 6: with the tail as ONE launch per direction (plan_tail_chain) there is no chain of small launches left to starve, and graph
-    // order measures 0.7 - 0.9 % faster in bf16 as well (6.719 against 6.769 ms, 6.746 against 6.808: profiles/r06_bd_ab_bw_order_bf16.txt,
-    // r06_am_ab_bw_defer_sync_bf16.txt): graph order is the default in both dtypes, SSD_BW_BIG_HEADS_LAST=1 restores round 5's.
-    bw_defer_first_ = -1;
-    if (env_i("SSD_BW_BIG_HEADS_LAST", 0) && tail_first_ + 1 < n && heads_.nmaps >= 3) {
-        std::vector<int> moved, rest;
-        for (int i : bwd_order_) {
-            const Op& op = ops_[i];
-            if ((op.kind == OP_CONV && (op.head == 0 || op.head == 1)) || op.kind == OP_L2NORM) moved.push_back(i);
-            else rest.push_back(i);
-        }
-        bwd_order_.clear();
-        for (int i : rest) {
-            bwd_order_.push_back(i);
-            if (i == tail_first_ + 1) bwd_order_.insert(bwd_order_.end(), moved.begin(), moved.end());
-        }
-        bw_defer_first_ = moved.front();
-    }
-    // every op exactly once: an op the rewrite above failed to re-insert would silently never run backward
+    // (Round 5 ran the bf16 step with the two BIG heads and the l2-norm BEHIND the chain conv11_2 ... conv8_2 -- in graph order their data
+    // gradients filled every CU while the chain's first small links were due: 6.864 -> 6.810 ms, profiles/r05_r_ab_bw_defer_bf16.txt.  With
+    // round 6's one-launch tail there is no chain of small launches left to starve and graph order measures 0.7 - 0.9 % faster in bf16,
+    // equal in fp32 (profiles/r06_bd_ab_bw_order_*.txt, r06_am_ab_bw_defer_sync_bf16.txt): the reordering and its switch are gone.)
+    // every op exactly once
     SSD_REQUIRE((int)bwd_order_.size() == n && (int)fwd_order_.size() == n, "issue orders lost an op (%zu forward, %zu backward of %d)",
                 fwd_order_.size(), bwd_order_.size(), n);
 }
@@ -1230,7 +1209,6 @@ bool Net::backward_step(size_t min_floats, size_t* off, size_t* count, bool sync
         // or accumulates into a gradient that the other class wrote last (bw_need): conv8_1 joins the chain.
         const int cls = bw_class(op, op_index);
         hipStream_t ds = cls == 1 ? hstream_ : stream_;
-        if (op_index == bw_defer_first_ && hstream_ && overlap_) bw_sync(0, 1);      // the main stream's big kernels start behind the chain
         if (chain_bwd_ && in_chain_[op_index] && !op_ablated(op.name, op.kind, op.head, op.k)) {
             // Round 6 (plan_tail_chain): the first chain op met issues the chain's data gradients (one launch) and every chain layer's
             // weight gradient (one grouped launch); the other members are skipped when their turn comes -- all but the chain's first

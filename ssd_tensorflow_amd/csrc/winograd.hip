@@ -816,9 +816,7 @@ static void tn_tile(const ConvDesc& d, int* bk, int* bn) {
     *bn = d.Co <= 64 ? 64 : 128;
 }
 static int tn_splits(const ConvDesc& d) {
-    static const int forced = env_int("SSD_WINO_SPLITS", 0);
     const int T = wino_tiles(d);
-    if (forced > 0) return std::min(forced, std::max(1, T / 32));
     int bk, bn;
     tn_tile(d, &bk, &bn);
     const int base = 36 * cdiv(d.Ci, bk) * cdiv(d.Co, bn);
