@@ -9,8 +9,8 @@ channels and shifts hue / saturation.  Everything runs through the product's own
 weights (there is no vgg.zip), SGD + momentum at the reference's magnitude of learning rate.
 
 Schedule: 96 steps at 3e-4, then 6e-4 until step 768, then 1e-4 -- 1280 steps at batch 32 over 1024 training images.  (Rounds 4-5 ran
-the middle phase at the reference's 7.5e-4, train.py:66.  Round 6 moved the fp32 trunk to the Winograd form: another rounding, another
-step time and with it another batch order out of the feeder's workers, i.e. another trajectory of the same chaotic run -- and that one
+the middle phase at the reference's 7.5e-4, train.py:66.  Round 6 moved the fp32 trunk to the Winograd form: another rounding, i.e. another
+trajectory of the same chaotic run -- and the first such tree's
 spiked at step ~740 (loss 3.4 -> 8.5, mAP 0.91 -> 0.0, re-learning to 0.48 by the end) while the direct kernels' run of the same
 schedule reached 1.000: profiles/r06_ar_learn_probe.txt, which also shows both forms converging at 6e-4 and 5e-4, and
 profiles/r06_aq_wino_probe.txt: at the trained state every filter gradient of the Winograd step agrees with the direct step's to
