@@ -81,8 +81,10 @@ def test_shapes_training_converges_in_both_dtypes(tmp_path):
     # bf16 against fp32, same seed, same batches, at the end of training.  Measured (profiles/r04_m_gpu_learning_tests.log): mAP
     # 0.976 / 0.977 (bf16, training / held-out) against 0.999 / 0.976 (fp32); total loss 3.019 against 2.903 (+4.0 %), held-out
     # 3.395 against 3.293 (+3.1 %).  The two are different trajectories of the same chaotic training run, so the bounds leave room.
+    # Round 6 (6e-4 schedule, fp32 on the Winograd form): 0.9999 / 1.0000 against 0.9543 / 0.9993, total loss 2.812 against 2.926 (-3.9 %),
+    # held-out 3.231 against 3.296 -- the training-sample mAP is made of ~40 detections per class, one of them is 0.02: the bound on it is 0.08.
     a, b = res['bf16'], res['f32']
-    assert abs(a['maps'][-1][0] - b['maps'][-1][0]) <= 0.05 and abs(a['maps'][-1][1] - b['maps'][-1][1]) <= 0.05
+    assert abs(a['maps'][-1][0] - b['maps'][-1][0]) <= 0.08 and abs(a['maps'][-1][1] - b['maps'][-1][1]) <= 0.05
     assert abs(a['train'][-1][0] - b['train'][-1][0]) <= 0.08 * b['train'][-1][0]
     assert abs(a['valid'][-1][0] - b['valid'][-1][0]) <= 0.08 * b['valid'][-1][0]
 
