@@ -1,0 +1,115 @@
+import numpy as np, itertools, fractions
+from fractions import Fraction as F
+
+def toom_cook(points, m=4, r=3):
+    """Cook-Toom matrices for F(m, r) with n = m + r - 1 points, the last being infinity.  Returns AT (m x n), G (n x r), BT (n x n) as
+    Fractions such that y = AT [(G g) * (BT d)] for 1-D correlation y_i = sum_k d_{i+k} g_k."""
+    n = m + r - 1
+    pts = points[:n - 1]
+    # polynomial evaluation matrices: A (n x m), G (n x r): rows = evaluation at point p: [1, p, p^2, ...]; infinity row: leading coeff
+    AT = [[F(0)] * n for _ in range(m)]
+    for j, p in enumerate(pts):
+        for i in range(m):
+            AT[i][j] = F(p) ** i
+    AT[m - 1][n - 1] = F(1)
+    Gm = [[F(0)] * r for _ in range(n)]
+    for j, p in enumerate(pts):
+        # scale factor 1 / prod_{k != j} (p_j - p_k)
+        den = F(1)
+        for k, q in enumerate(pts):
+            if k != j: den *= (F(p) - F(q))
+        for i in range(r):
+            Gm[j][i] = F(p) ** i / den
+    Gm[n - 1][r - 1] = F(1)
+    # BT: from the Lagrange basis: BT = (interpolation matrix)^T ... solve by requiring the identity on unit vectors
+    # Build via: for linear convolution s = g * d' (transposition principle).  Simpler: solve BT numerically as the inverse-transpose of the
+    # Vandermonde-like matrix V (n x n) with rows [1, p, ..., p^{n-1}] and infinity row [0,...,0,1], including the scaling above.
+    V = [[F(0)] * n for _ in range(n)]
+    for j, p in enumerate(pts):
+        den = F(1)
+        for k, q in enumerate(pts):
+            if k != j: den *= (F(p) - F(q))
+        for i in range(n):
+            V[j][i] = F(p) ** i
+        # the 1/den scaling went into G; BT must carry the remaining product so that AT diag BT ... -> use transposition principle:
+    V[n - 1][n - 1] = F(1)
+    return AT, Gm, V
+
+def mat(a): return np.array([[float(x) for x in r] for r in a], dtype=np.float64)
+
+def derive(points, m=4, r=3):
+    """Numerically: AT, G from the construction, BT solved from the bilinear identity by least squares over unit vectors."""
+    n = m + r - 1
+    AT, Gm, _ = toom_cook(points, m, r)
+    AT, Gm = mat(AT), mat(Gm)
+    # unknown BT (n x n): y_i = sum_j AT[i,j] * (G g)_j * (BT d)_j must equal sum_k d_{i+k} g_k for all g, d
+    # for each j: (G g)_j is a known linear form; linear system in BT entries
+    rows = []; rhs = []
+    for gi in range(r):
+        g = np.zeros(r); g[gi] = 1
+        Gg = Gm @ g
+        for di in range(n):
+            d = np.zeros(n); d[di] = 1
+            for i in range(m):
+                # sum_j AT[i,j] Gg[j] BT[j,di] = [di == i + gi]
+                row = np.zeros((n, n)); row[:, di] = AT[i, :] * Gg
+                rows.append(row.ravel()); rhs.append(1.0 if di == i + gi else 0.0)
+    Amat = np.array(rows); b = np.array(rhs)
+    sol, res, rk, sv = np.linalg.lstsq(Amat, b, rcond=None)
+    BT = sol.reshape(n, n)
+    assert np.abs(Amat @ sol - b).max() < 1e-9, np.abs(Amat @ sol - b).max()
+    return AT, Gm, BT
+
+def err2d(AT, G, BT, trials=40, seed=0, relu=True):
+    rng = np.random.default_rng(seed)
+    A32, G32, B32 = AT.astype(np.float32), G.astype(np.float32), BT.astype(np.float32)
+    es = []
+    for _ in range(trials):
+        C = 64
+        d = rng.normal(0, 1, (C, 6, 6))
+        if relu: d = np.maximum(d, 0)
+        g = rng.normal(0, 1, (C, 3, 3)) / np.sqrt(9 * C)
+        # exact
+        y = np.zeros((4, 4))
+        for i in range(4):
+            for j in range(4):
+                y[i, j] = (d[:, i:i+3, j:j+3] * g).sum()
+        d32, g32 = d.astype(np.float32), g.astype(np.float32)
+        U = np.einsum('ij,cjk,lk->cil', G32, g32, G32).astype(np.float32)
+        V = np.einsum('ij,cjk,lk->cil', B32, d32, B32).astype(np.float32)
+        M = (U * V).astype(np.float32).sum(0, dtype=np.float32)
+        yw = (A32 @ M @ A32.T).astype(np.float32)
+        # direct in fp32
+        yd = np.zeros((4, 4), np.float32)
+        for i in range(4):
+            for j in range(4):
+                yd[i, j] = (d32[:, i:i+3, j:j+3] * g32).sum(dtype=np.float32)
+        es.append((np.abs(yw - y).max(), np.abs(yd - y).max(), np.abs(y).max()))
+    es = np.array(es)
+    return es[:, 0].mean() / es[:, 2].mean(), es[:, 1].mean() / es[:, 2].mean()
+
+cands = {
+  'lavin 0,1,-1,2,-2': [0, 1, -1, 2, -2],
+  '0,1,-1,1/2,-1/2': [0, 1, -1, F(1,2), F(-1,2)],
+  '0,1,-1,1/2,-2': [0, 1, -1, F(1,2), -2],
+  '0,1,-1,2,-1/2': [0, 1, -1, 2, F(-1,2)],
+  '0,1/2,-1/2,3/2,-3/2': [0, F(1,2), F(-1,2), F(3,2), F(-3,2)],
+  '0,1,-1,3/2,-3/2': [0,1,-1,F(3,2),F(-3,2)],
+  '0,3/4,-3/4,3/2,-3/2': [0,F(3,4),F(-3,4),F(3,2),F(-3,2)],
+  '0,1/2,-1/2,1,-1 (dup)': [0,F(1,2),F(-1,2),1,-1],
+  '0,2/3,-2/3,4/3,-4/3': [0,F(2,3),F(-2,3),F(4,3),F(-4,3)],
+}
+for name, pts in cands.items():
+    AT, G, BT = derive(pts)
+    ew, ed = err2d(AT, G, BT)
+    print('%-28s winograd err %.2e   direct fp32 err %.2e   ratio %.1f   max|AT| %.1f max|BT| %.1f max|G| %.2f' % (name, ew, ed, ew / ed, np.abs(AT).max(), np.abs(BT).max(), np.abs(G).max()))
+print('---- symmetric scan {0, +-a, +-b}')
+best = []
+for a in [F(1,2), F(5,8), F(11,16), F(3,4), F(13,16), F(7,8), F(1)]:
+    for b in [F(5,4), F(11,8), F(3,2), F(13,8), F(7,4), F(2)]:
+        if b <= a: continue
+        AT, G, BT = derive([0, a, -a, b, -b])
+        e = np.mean([err2d(AT, G, BT, trials=30, seed=s)[0] for s in (1, 2)])
+        best.append((e, float(a), float(b)))
+for e, a, b in sorted(best)[:10]: print('a=%.4f b=%.4f err %.2e' % (a, b, e))
+print('lavin', np.mean([err2d(*derive([0,1,-1,2,-2]), trials=30, seed=s)[0] for s in (1,2)]))
