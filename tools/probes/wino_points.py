@@ -1,3 +1,6 @@
+"""CPU study (numpy): fp32 error of the Winograd F(4x4, 3x3) form by its interpolation points -- transforms and products in float32
+against a float64 convolution on relu-like inputs (64 channels), next to the direct fp32 sum's error.  Cook-Toom matrices for any five
+finite points + infinity (B^T solved from the bilinear identity).  DESIGN.md 4.9; output: profiles/r06_bs_wino_points_study.txt."""
 import numpy as np, itertools, fractions
 from fractions import Fraction as F
 
