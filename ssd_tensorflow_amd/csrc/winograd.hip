@@ -11,7 +11,8 @@
 //                  y = A^T M A + bias, relu                    (wino_out_kernel)
 //   data gradient  the same three steps on dy with U' = G rot180(g)^T G^T ([36][Co][Ci]), masked by the producer's relu
 //   weight grad.   dU_p = V_p^T . (A dy A^T)_p                 36 GEMMs [Ci x T] . [T x Co], split over T into slabs (wino_gemm_tn_kernel)
-//                  dg = G^T (sum of slabs, fixed order) G + weight_decay g;  dbias = column sums of dy = sum_t (A dy A^T)_(1,1)
+//                  dg = G^T (sum of slabs, fixed order) G + weight_decay g;  dbias = column sums of dy = a weighted sum of the
+//                  column sums of (A dy A^T) at 16 positions (bias_axis_weight)
 //                  (wino_wgrad_reduce_kernel)
 //
 // The same form serves the dilated layer (mod_conv6: every residue class of the dilation is an image of its own, wino_in_kernel) and the
@@ -34,24 +35,25 @@ namespace ssd {
 constexpr unsigned WOOB = 0xFFFFFFF0u;      // offset no buffer covers: the load returns / the DMA writes zeros
 
 // ---- the three transforms on 4-channel vectors --------------------------------------------------------------------------------
-// B^T (6x6), interpolation points 0, +-1, +-2, inf
+// Interpolation points 0, +-3/4, +-3/2, inf: Lavin & Gray's 0, +-1, +-2 scaled by 3/4 -- the same +- pairing, B^T and A^T still exact in
+// fp32, 2.3x less rounding error (tools/probes/wino_points.py: 8x the direct fp32 sum's error instead of 19x).
+// B^T (6x6)
 __device__ __forceinline__ void bt6(f32x4& d0, f32x4& d1, f32x4& d2, f32x4& d3, f32x4& d4, f32x4& d5) {
-    const f32x4 t0 = 4.f * d0 - 5.f * d2 + d4;
-    const f32x4 t1 = -4.f * (d1 + d2) + d3 + d4;
-    const f32x4 t2 = 4.f * (d1 - d2) - d3 + d4;
-    const f32x4 t3 = 2.f * (d3 - d1) - d2 + d4;
-    const f32x4 t4 = 2.f * (d1 - d3) - d2 + d4;
-    const f32x4 t5 = 4.f * d1 - 5.f * d3 + d5;
-    d0 = t0; d1 = t1; d2 = t2; d3 = t3; d4 = t4; d5 = t5;
+    const f32x4 t0 = 1.265625f * d0 - 2.8125f * d2 + d4;
+    const f32x4 e = d4 - 2.25f * d2, f = 1.6875f * d1 - 0.75f * d3;
+    const f32x4 g = d4 - 0.5625f * d2, h = 0.84375f * d1 - 1.5f * d3;
+    const f32x4 t5 = 1.265625f * d1 - 2.8125f * d3 + d5;
+    d0 = t0; d1 = e - f; d2 = e + f; d3 = g - h; d4 = g + h; d5 = t5;
 }
 // A (6x4) applied to a 4-vector: the weight gradient's transform of a dy tile
 __device__ __forceinline__ void a6(const f32x4 e0, const f32x4 e1, const f32x4 e2, const f32x4 e3, f32x4* u) {
-    const f32x4 s02 = e0 + e2, s13 = e1 + e3, q02 = e0 + 4.f * e2, q13 = 2.f * e1 + 8.f * e3;
+    const f32x4 p = e0 + 0.5625f * e2, q = 0.75f * e1 + 0.421875f * e3;
+    const f32x4 r = e0 + 2.25f * e2, t = 1.5f * e1 + 3.375f * e3;
     u[0] = e0;
-    u[1] = s02 + s13;
-    u[2] = s02 - s13;
-    u[3] = q02 + q13;
-    u[4] = q02 - q13;
+    u[1] = p + q;
+    u[2] = p - q;
+    u[3] = r + t;
+    u[4] = r - t;
     u[5] = e3;
 }
 // A^T (4x6) applied to a 6-vector: the output transform
@@ -59,9 +61,16 @@ __device__ __forceinline__ void at4(const f32x4 m0, const f32x4 m1, const f32x4 
                                     f32x4* y) {
     const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
     y[0] = m0 + s12 + s34;
-    y[1] = d12 + 2.f * d34;
-    y[2] = s12 + 4.f * s34;
-    y[3] = d12 + 8.f * d34 + m5;
+    y[1] = 0.75f * d12 + 1.5f * d34;
+    y[2] = 0.5625f * s12 + 2.25f * s34;
+    y[3] = 0.421875f * d12 + 3.375f * d34 + m5;
+}
+
+// The bias gradient is the sum of dy over the pixels = sum over tiles of 1^T e 1 = c^T (A e A^T) c with c^T A = 1^T: for these points
+// c = (-7/9, 14/9, 2/9, 0, 0, 7/16), i.e. a weighted sum of the column sums of Ya at the 16 positions (k, l), k, l in {0, 1, 2, 5}.
+__host__ __device__ inline int bias_axis_slot(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 2 : k == 5 ? 3 : -1; }
+__device__ __forceinline__ float bias_axis_weight(int slot) {
+    return slot == 0 ? -7.f / 9.f : slot == 1 ? 14.f / 9.f : slot == 2 ? 2.f / 9.f : 7.f / 16.f;
 }
 
 // ---- input transforms: one thread = 4 channels of one tile ---------------------------------------------------------------------
@@ -301,13 +310,13 @@ __global__ __launch_bounds__(256) void wino_out_kernel(WinoOutArgs p) {
 // ---- filter transforms ------------------------------------------------------------------------------------------------------------
 // G (6x3) applied to a 3-vector
 __device__ __forceinline__ void g6(const float g0, const float g1, const float g2, float* u) {
-    const float s = g0 + g2;
-    u[0] = 0.25f * g0;
-    u[1] = (-1.f / 6.f) * (s + g1);
-    u[2] = (-1.f / 6.f) * (s - g1);
-    const float a = (1.f / 24.f) * g0 + (1.f / 6.f) * g2, bq = (1.f / 12.f) * g1;
-    u[3] = a + bq;
-    u[4] = a - bq;
+    u[0] = (64.f / 81.f) * g0;
+    const float a = (-128.f / 243.f) * g0 - (8.f / 27.f) * g2, b = (32.f / 81.f) * g1;
+    u[1] = a - b;
+    u[2] = a + b;
+    const float c = (32.f / 243.f) * g0 + (8.f / 27.f) * g2, d = (16.f / 81.f) * g1;
+    u[3] = c + d;
+    u[4] = c - d;
     u[5] = g2;
 }
 // U[p][ci][co] = (G g G^T)_p of g = w[.][.][ci][co]; FLIP: U'[p][co][ci] of the filter rotated by 180 degrees (the data gradient's).
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256) void wino_gemm_nn_kernel(WinoGemmArgs p) {
 
 // ---- the 36 GEMMs of the weight gradient: dU_p[Ci x Co] = sum_t V_p[t][Ci] . Ya_p[t][Co], split over t into slabs ---------------------
 // Both operands keep their t-major global rows in LDS (conv_wgrad_dma_kernel's layout: ds_read_b32 fragments, a tile is a plain DMA
-// copy).  Slab s = [36][Ci][Co] partial sums + [Co] column sums of Ya at position (1,1) = the bias gradient's partial.
+// copy).  Slab s = [36][Ci][Co] partial sums + [16][Co] column sums of Ya at the positions the bias gradient is made of.
 struct WinoTnArgs {
     const float* X;      // V   [36][.][Ci]
     const float* Y;      // Ya  [36][.][Co]
@@ -500,7 +509,9 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(WinoTnArgs p) {
     const int c0 = ct * BKT, n0 = nt * BNT;
     const int tbeg = split * p.tchunk, tend = min(p.T, tbeg + p.tchunk);
     const int niter = (tend - tbeg + BP - 1) / BP;
-    const bool do_bias = pos == 7 && ct == 0;
+    const int bk = bias_axis_slot(pos / 6), bl = bias_axis_slot(pos % 6);
+    const int bslot = (bk >= 0 && bl >= 0) ? 4 * bk + bl : -1;      // this position's column sums are a term of the bias gradient
+    const bool do_bias = bslot >= 0 && ct == 0;
 
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (size_t)pos * p.x_ps), 0,
                                                                            (unsigned)((size_t)tend * p.x_ld * 4u), 0x00020000);
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(WinoTnArgs p) {
         compute(it & 1);
     }
     const size_t ucount = (size_t)36 * p.Ci * p.Co;
-    float* slab = p.ws + (size_t)split * (ucount + p.Co);
+    float* slab = p.ws + (size_t)split * (ucount + 16 * (size_t)p.Co);
     float* up = slab + (size_t)pos * p.Ci * p.Co;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
@@ -586,16 +597,16 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(WinoTnArgs p) {
                 if (kl < p.Ci) up[(size_t)kl * p.Co + n] = acc[mi][ni][r];
             }
         }
-    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[ucount + n0 + tid] = bsum;
+    if (do_bias && tid < BNT && n0 + tid < p.Co) slab[ucount + (size_t)bslot * p.Co + n0 + tid] = bsum;
 }
 
 // G^T (3x6) applied to a 6-vector
 __device__ __forceinline__ void gt3(const f32x4 s0, const f32x4 s1, const f32x4 s2, const f32x4 s3, const f32x4 s4, const f32x4 s5,
                                     f32x4* g) {
     const f32x4 a = s1 + s2, b = s2 - s1, c = s3 + s4, d = s3 - s4;
-    g[0] = 0.25f * s0 - (1.f / 6.f) * a + (1.f / 24.f) * c;
-    g[1] = (1.f / 6.f) * b + (1.f / 12.f) * d;
-    g[2] = -(1.f / 6.f) * a + (1.f / 6.f) * c + s5;
+    g[0] = (64.f / 81.f) * s0 - (128.f / 243.f) * a + (32.f / 243.f) * c;
+    g[1] = (32.f / 81.f) * b + (16.f / 81.f) * d;
+    g[2] = (8.f / 27.f) * (c - a) + s5;
 }
 // dw[tap][ci][co] = (G^T (sum_s slab_s) G)_tap + wd * w ; dbias = sum_s slab_s' bias part.  One thread = (ci, 4 co); slabs added in order.
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int Ci, int Co,
@@ -603,12 +614,16 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
                                                                 const float* __restrict__ w, float wd) {
     const int c4n = Co >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const size_t cc = (size_t)Ci * Co, ucount = 36 * cc, stride = ucount + Co;
+    const size_t cc = (size_t)Ci * Co, ucount = 36 * cc, stride = ucount + 16 * (size_t)Co;
     if (idx >= Ci * c4n) {
         const int q = idx - Ci * c4n;
         if (q < c4n && db) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(ws + (size_t)k * stride + ucount + q * 4);
+            for (int slot = 0; slot < 16; ++slot) {      // fixed order: position, then slab
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < nsplit; ++k) t += *reinterpret_cast<const f32x4*>(ws + (size_t)k * stride + ucount + (size_t)slot * Co + q * 4);
+                s += (bias_axis_weight(slot >> 2) * bias_axis_weight(slot & 3)) * t;
+            }
             *reinterpret_cast<f32x4*>(db + q * 4) = s;
         }
         return;
@@ -833,7 +848,7 @@ static int tn_splits(const ConvDesc& d) {
     }
     return best;
 }
-size_t wino_wgrad_ws_floats(const ConvDesc& d) { return (size_t)tn_splits(d) * ((size_t)36 * d.Ci * d.Co + d.Co); }
+size_t wino_wgrad_ws_floats(const ConvDesc& d) { return (size_t)tn_splits(d) * ((size_t)36 * d.Ci * d.Co + 16 * (size_t)d.Co); }
 
 template <int WM, int WN, int TM, int TN>
 static void launch_tn(WinoTnArgs& a, const char* label, double flops, double bytes, hipStream_t s) {
