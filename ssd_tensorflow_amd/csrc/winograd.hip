@@ -22,7 +22,7 @@
 // Tiles t = (image, tile row, tile column) in raster order; T = B * ceil(H/4) * ceil(W/4).  Every transformed tensor is position-major
 // [36][T][C] so that each of the 36 GEMMs reads plain row-major matrices and the transforms write whole 128-byte lines per (tile, position).
 // The transforms are exact-arithmetic identities; in fp32 their rounding error is ~1e-6 of the output scale (tests: 1e-3 relative
-// bound of BASELINE.json north_star, measured ~1e-5), summation orders are fixed, so a step stays bit-reproducible run to run.
+// bound of BASELINE.json north_star, measured 6e-7 ... 6e-6), summation orders are fixed, so a step stays bit-reproducible run to run.
 #include "conv.h"
 #include "conv_detail.h"
 #include "bf16.h"

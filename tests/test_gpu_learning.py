@@ -19,7 +19,8 @@ luck, not the form of the convolution: the tree as committed at the end of round
 runs the reference's 7.5e-4 to mAP 0.976 / 0.9996 without a spike, like the direct kernels (profiles/r06_bq_learn_probe_reference_lr.txt;
 the feeder's batch order does not depend on the number of workers: 2 and 8 give the same run to the last digit).  Left at 7.5e-4 for
 3,000 steps that tree spikes once (step ~1,090, back at mAP 1.000 within 700 steps) where the direct kernels' run shows a blip:
-profiles/r06_br_learn_probe_long_reference_lr.txt.)  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
+profiles/r06_br_learn_probe_long_reference_lr.txt; on the interpolation points the round ended with (0, +-3/4, +-3/2: 2.3-3.8x less
+rounding error) the same 3,520 steps run without any spike: profiles/r06_bu_learn_probe_long_scaled_points.txt.)  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
 fp32 passes mAP 0.5 on the training sample at step ~480, 0.9 at ~670 and sits at 1.000 / 1.000 (training / held-out)
 from step ~900 on, total loss 16.5 -> 2.6 (of which 2.18 is the l2 term); bf16 follows the same curve to 0.95 at step
 ~930.  Left at 7.5e-4 or 1e-3 for thousands of steps, a run in EITHER dtype occasionally collapses (a loss spike, mAP back to

@@ -1,6 +1,7 @@
 """-m gpu: the Winograd F(4x4, 3x3) forms of the fp32 3x3 / stride 1 / SAME passes (csrc/winograd.hip) against the CPU oracle
 (torch-CPU fp32 with TF semantics, oracle/ssdvgg_ref.py; tf.nn.conv2d at ssdvgg.py:195-207), through the C ABI.  Tolerance: 1e-3
-relative (BASELINE.json north_star); the minimal-filtering transforms are exact identities, their fp32 rounding measures ~1e-6..1e-5.
+relative (BASELINE.json north_star); the minimal-filtering transforms are exact identities, their fp32 rounding measures 6e-7..6e-6 on
+the interpolation points 0, +-3/4, +-3/2, inf (Lavin's 0, +-1, +-2: up to 1.7e-5).
 The fused-pool forms are checked bit for bit against the stand-alone pooling passes applied to the Winograd kernels' own output."""
 import zlib
 import numpy as np
