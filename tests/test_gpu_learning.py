@@ -8,19 +8,15 @@ channels and shifts hue / saturation.  Everything runs through the product's own
 (feeder with worker processes, StepLoop, decode + NMS of every batch from epoch 2 on, GPU APCalculator), from Xavier
 weights (there is no vgg.zip), SGD + momentum at the reference's magnitude of learning rate.
 
-Schedule: 96 steps at 3e-4, then 6e-4 until step 768, then 1e-4 -- 1280 steps at batch 32 over 1024 training images.  (Rounds 4-5 ran
-the middle phase at the reference's 7.5e-4, train.py:66.  Round 6 moved the fp32 trunk to the Winograd form: another rounding, i.e. another
-trajectory of the same chaotic run -- and the first such tree's
-spiked at step ~740 (loss 3.4 -> 8.5, mAP 0.91 -> 0.0, re-learning to 0.48 by the end) while the direct kernels' run of the same
-schedule reached 1.000: profiles/r06_ar_learn_probe.txt, which also shows both forms converging at 6e-4 and 5e-4, and
-profiles/r06_aq_wino_probe.txt: at the trained state every filter gradient of the Winograd step agrees with the direct step's to
-5e-5.  The spike is the collapse the next paragraph describes, so the asserted schedule keeps 20 % of margin to it.  Which trajectory spikes is
-luck, not the form of the convolution: the tree as committed at the end of round 6 -- more layers in the Winograd form, other roundings --
-runs the reference's 7.5e-4 to mAP 0.976 / 0.9996 without a spike, like the direct kernels (profiles/r06_bq_learn_probe_reference_lr.txt;
-the feeder's batch order does not depend on the number of workers: 2 and 8 give the same run to the last digit).  Left at 7.5e-4 for
-3,000 steps that tree spikes once (step ~1,090, back at mAP 1.000 within 700 steps) where the direct kernels' run shows a blip:
-profiles/r06_br_learn_probe_long_reference_lr.txt; on the interpolation points the round ended with (0, +-3/4, +-3/2: 2.3-3.8x less
-rounding error) the same 3,520 steps run without any spike: profiles/r06_bu_learn_probe_long_scaled_points.txt.)  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
+Schedule: 96 steps at 3e-4, the reference's 7.5e-4 (train.py:66) until step 768, then 1e-4 -- 1280 steps at batch 32 over
+1024 training images.  (Round 6 moved the fp32 trunk to the Winograd form.  On Lavin & Gray's interpolation points its rounding, 1e-5, was
+a hundred times the direct kernels' -- at this rate, the edge of stability (next paragraph), kick enough for a spike in two of two such trees
+(step ~740 of this schedule: loss 3.4 -> 8.5, mAP 0.91 -> 0.0; step ~1,090 of a 3,000-step run at 7.5e-4) where the direct kernels' runs
+had none: profiles/r06_ar_learn_probe.txt, r06_br_learn_probe_long_reference_lr.txt.  On the points the round ended with (0, +-3/4, +-3/2:
+2.3-3.8x less rounding) the same runs show no spike -- 3,520 steps at 7.5e-4 end at loss 2.219 / mAP 1.000, this schedule at 2.758 / 1.000 /
+1.000 against bf16's 2.721 / 0.977 / 1.000: profiles/r06_bu_learn_probe_long_scaled_points.txt, r06_bv_learn_probe_test_schedule.txt.  In between the
+test ran its middle phase at 6e-4; at the trained state every filter gradient of the Winograd step agrees with the direct step's to 5e-5:
+profiles/r06_aq_wino_probe.txt.)  Measured on an MI355X (profiles/r04_l_learning_probe.txt: the same run without the final decay):
 fp32 passes mAP 0.5 on the training sample at step ~480, 0.9 at ~670 and sits at 1.000 / 1.000 (training / held-out)
 from step ~900 on, total loss 16.5 -> 2.6 (of which 2.18 is the l2 term); bf16 follows the same curve to 0.95 at step
 ~930.  Left at 7.5e-4 or 1e-3 for thousands of steps, a run in EITHER dtype occasionally collapses (a loss spike, mAP back to
@@ -45,7 +41,7 @@ from ssd_tensorflow_amd.training_data import TrainingData
 pytestmark = pytest.mark.gpu
 
 EPOCHS, NTRAIN, NVALID, BATCH = 40, 1024, 128, 32
-LR_VALUES, LR_BOUNDARIES = '0.0003;0.0006;0.0001', '96;768'
+LR_VALUES, LR_BOUNDARIES = '0.0003;0.00075;0.0001', '96;768'
 
 
 def run_driver(tmp_path, tag, dtype, epochs=EPOCHS, augment='false', workers=4):
@@ -84,10 +80,10 @@ def test_shapes_training_converges_in_both_dtypes(tmp_path):
     # bf16 against fp32, same seed, same batches, at the end of training.  Measured (profiles/r04_m_gpu_learning_tests.log): mAP
     # 0.976 / 0.977 (bf16, training / held-out) against 0.999 / 0.976 (fp32); total loss 3.019 against 2.903 (+4.0 %), held-out
     # 3.395 against 3.293 (+3.1 %).  The two are different trajectories of the same chaotic training run, so the bounds leave room.
-    # Round 6 (6e-4 schedule, fp32 on the Winograd form): 0.9999 / 1.0000 against 0.9543 / 0.9993, total loss 2.812 against 2.926 (-3.9 %),
-    # held-out 3.231 against 3.296 -- the training-sample mAP is made of ~40 detections per class, one of them is 0.02: the bound on it is 0.08.
+    # Round 6 (fp32 on the Winograd form, scaled interpolation points): 0.977 / 1.000 against 1.000 / 1.000, total loss 2.721 against 2.758
+    # (-1.3 %), held-out 3.162 against 3.163.
     a, b = res['bf16'], res['f32']
-    assert abs(a['maps'][-1][0] - b['maps'][-1][0]) <= 0.08 and abs(a['maps'][-1][1] - b['maps'][-1][1]) <= 0.05
+    assert abs(a['maps'][-1][0] - b['maps'][-1][0]) <= 0.05 and abs(a['maps'][-1][1] - b['maps'][-1][1]) <= 0.05
     assert abs(a['train'][-1][0] - b['train'][-1][0]) <= 0.08 * b['train'][-1][0]
     assert abs(a['valid'][-1][0] - b['valid'][-1][0]) <= 0.08 * b['valid'][-1][0]
 
